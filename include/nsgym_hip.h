@@ -1,0 +1,272 @@
+/* nsgym_hip.h — C-ABI of the MI355X-native vectorised non-stationary env stepper.
+ *
+ * The reference (scope-lab-vu/ns_gym) is 100 % Python and has NO FFI/plugin ABI: its
+ * boundary is the gymnasium Python protocol (ns_gym/base.py:206,248).  This header is
+ * therefore the boundary a maintainer would bind with ctypes (INTEGRATION.md shows the
+ * stub); each entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every function returns 0 on success or a negative NSG_E* code; the message is in
+ *     nsg_last_error() (thread-local).  Nothing throws across the ABI.
+ *   - the CALLER owns every per-env device buffer (PyTorch tensors' data_ptr()); the
+ *     library owns only the small constant tables it uploads at nsg_create().
+ *   - all launches are enqueue-only on the caller's hipStream_t (passed as void*);
+ *     no internal synchronisation, graph-capturable.
+ *   - one host thread per handle.
+ *
+ * Data layout: struct-of-arrays over N parallel env instances.  Field f of env i
+ * lives at base[f * N + i] (coalesced across a wavefront).
+ */
+#ifndef NSGYM_HIP_H
+#define NSGYM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSG_ABI_VERSION 1
+#define NSG_MAX_PARAMS 8 /* tunable params per env (Acrobot has 8: ns_gym/base.py:622-631) */
+#define NSG_MAX_THETA 8
+#define NSG_MAX_SEGMENTS 8 /* env-type segments of one heterogeneous launch */
+
+/* error codes */
+#define NSG_OK 0
+#define NSG_EINVAL (-22)
+#define NSG_ENOMEM (-12)
+#define NSG_EHIP (-5)
+#define NSG_ENOTBOUND (-77)
+
+/* ---- env types; θ slot order = ATTRIBUTE_MAP order (ns_gym/base.py:611-635) ---------- */
+enum {
+  NSG_ENV_CARTPOLE = 0,          /* gravity masscart masspole force_mag tau length            */
+  NSG_ENV_PENDULUM = 1,          /* m l dt g                                                  */
+  NSG_ENV_ACROBOT = 2,           /* dt LINK_LENGTH_1 LINK_LENGTH_2 LINK_MASS_1 LINK_MASS_2
+                                    LINK_COM_POS_1 LINK_COM_POS_2 LINK_MOI                    */
+  NSG_ENV_MOUNTAINCAR = 3,       /* gravity force                                             */
+  NSG_ENV_MOUNTAINCAR_CONT = 4,  /* power                                                     */
+  NSG_ENV_FROZENLAKE = 5,        /* P  (3-way slip distribution, ns_gym/wrappers/toy_text.py) */
+  NSG_ENV_COUNT = 6
+};
+
+/* ---- schedulers (ns_gym/schedulers.py; range gate ns_gym/base.py:67-81) -------------- */
+enum {
+  NSG_SCHED_CONTINUOUS = 0, /* schedulers.py:46-53                                          */
+  NSG_SCHED_PERIODIC = 1,   /* :77-89   i0 = period                                         */
+  NSG_SCHED_BURST = 2,      /* :119-140 i0 = on, i1 = off                                   */
+  NSG_SCHED_TABLE = 3,      /* Discrete :56-74, Window :180-198, Custom :31-43 compiled to a
+                               bit table over t (tab_off, tab_len bits; i0 = value beyond)   */
+  NSG_SCHED_RANDOM = 4,     /* :9-28    p0 = probability, own PCG64 stream                  */
+  NSG_SCHED_DECAYING = 5,   /* :143-177 p0 = initial probability, p1 = decay rate            */
+  NSG_SCHED_MEMORYLESS = 6  /* :92-116  p0 = p (geometric gaps)                             */
+};
+
+/* ---- scalar update functions (ns_gym/update_functions/single_param.py) --------------- */
+enum {
+  NSG_UPD_INCREMENT = 0,      /* :154-175 u0=k                    */
+  NSG_UPD_DECREMENT = 1,      /* :178-199 u0=k                    */
+  NSG_UPD_TREND = 2,          /* :20-40   u0=slope                */
+  NSG_UPD_POLY = 3,           /* :451-473 coeffs in value table   */
+  NSG_UPD_GEOMETRIC = 4,      /* :290-307 u0=r                    */
+  NSG_UPD_EXPDECAY = 5,       /* :266-287 u0=decay_rate           */
+  NSG_UPD_OSCILLATING = 6,    /* :243-264 u0=delta                */
+  NSG_UPD_SIGMOID = 7,        /* :349-385 u0=a u1=b u2=k u3=t0    */
+  NSG_UPD_LERP = 8,           /* :476-508 u0=start u1=end u2=T    */
+  NSG_UPD_STEPWISE = 9,       /* :202-223 values in value table   */
+  NSG_UPD_CYCLIC = 10,        /* :388-408 values in value table   */
+  NSG_UPD_NOUPDATE = 11,      /* :226-240                         */
+  NSG_UPD_RANDOMWALK = 12,    /* :84-113  u0=mu u1=sigma          */
+  NSG_UPD_RW_DRIFT = 13,      /* :116-151 u0=alpha u1=mu u2=sigma */
+  NSG_UPD_RW_DRIFT_TREND = 14,/* :43-81   u0=alpha u1=mu u2=sigma u3=slope */
+  NSG_UPD_OU = 15,            /* :310-346 u0=theta u1=mu u2=sigma */
+  NSG_UPD_BOUNDED_RW = 16,    /* :411-448 u0=mu u1=sigma u2=lo u3=hi */
+  /* distribution update functions (ns_gym/update_functions/distribution.py), n = 3 */
+  NSG_UPD_D_INCREMENT = 32,   /* :41-67   u0=k                    */
+  NSG_UPD_D_DECREMENT = 33,   /* :70-97   u0=k                    */
+  NSG_UPD_D_STEPWISE = 34,    /* :100-130 triples in value table  */
+  NSG_UPD_D_CYCLIC = 35,      /* :334-356 triples in value table  */
+  NSG_UPD_D_NOUPDATE = 36,    /* :217-231                         */
+  NSG_UPD_D_UNIFORMDRIFT = 37,/* :234-261 u0=rate                 */
+  NSG_UPD_D_TARGETREV = 38,   /* :264-293 u0..u2=target u3=theta  */
+  NSG_UPD_D_LERP = 39         /* :296-331 u0..u2=start u3..u5=end u6=T */
+};
+
+/* flags of nsg_config.flags (constructor kwargs of NSWrapper, ns_gym/base.py:222-232) */
+#define NSG_F_CHANGE_NOTIFICATION 0x1u
+#define NSG_F_DELTA_NOTIFICATION 0x2u
+#define NSG_F_PERSISTENT_PARAMS 0x4u
+#define NSG_F_TRACK_RETURNS 0x8u   /* keep per-env episode return / length accumulators   */
+#define NSG_F_MODIFIED_REWARDS 0x10u /* FrozenLake modified_rewards (toy_text.py:465-468)  */
+#define NSG_F_COMPACT_DONE 0x20u   /* wave-ballot compaction of done env indices          */
+
+/* per-env status byte (buffers.status) */
+#define NSG_ST_NEEDS_RESET 0x1u
+
+/* device-side counters (uint32 each), index into buffers.counters */
+enum {
+  NSG_CNT_DONE = 0,       /* envs that finished an episode in the last step            */
+  NSG_CNT_FIRED = 1,      /* (env,param) updates applied in the last step              */
+  NSG_CNT_VIOLATION = 2,  /* (env,param) updates rejected by the constraint checker    */
+  NSG_CNT_EPISODES = 3,   /* running total of finished episodes                        */
+  NSG_CNT_COUNT = 8
+};
+
+/* One tunable parameter = (Scheduler, UpdateFn) pair: UpdateFn.__call__ (ns_gym/base.py:124-149). */
+typedef struct nsg_param_cfg {
+  int32_t theta_slot;   /* which θ of the env type this entry drives                       */
+  int32_t sched_kind;
+  int32_t upd_kind;
+  int32_t rng_child;    /* position in tunable_params dict order = SeedSequence child index
+                           (ns_gym/base.py:418-421); also the index of its stream buffer    */
+  double sched_start;   /* inclusive range gate, end may be +inf (ns_gym/base.py:56-81)     */
+  double sched_end;
+  int64_t sched_i0;
+  int64_t sched_i1;
+  double sched_p0;
+  double sched_p1;
+  int32_t sched_tab_off; /* bit table: offset in 32-bit words into the table blob          */
+  int32_t sched_tab_len; /* bit table: number of valid bits                                 */
+  int32_t val_tab_off;   /* value table: offset in doubles into the table blob              */
+  int32_t val_tab_len;   /* value table: number of entries (triples for distributions)      */
+  double u[8];
+  uint64_t fn_seed;      /* constructor seed of a stochastic fn (valid if has_fn_seed)      */
+  int32_t has_fn_seed;
+  int32_t uses_rng;      /* 1 if the update fn owns a PCG64 stream                          */
+} nsg_param_cfg;
+
+typedef struct nsg_config {
+  int32_t abi_version;
+  int32_t env_type;
+  int32_t n_params;
+  int32_t max_episode_steps;  /* gymnasium TimeLimit [UPSTREAM]; <= 0 means none            */
+  uint32_t flags;
+  int32_t nrow, ncol;         /* FrozenLake map (ns_gym/wrappers/toy_text.py:314-319)       */
+  int32_t desc_tab_off;       /* FrozenLake desc bytes: offset in BYTES into the table blob */
+  double base_theta[NSG_MAX_THETA]; /* construction-time θ (TUNABLE_PARAMS, base.py:1156)   */
+  double initial_prob[3];     /* FrozenLake initial_prob_dist (toy_text.py:291)             */
+  double letter_reward[4];    /* FrozenLake modified_rewards for S,F,H,G                    */
+  nsg_param_cfg params[NSG_MAX_PARAMS];
+} nsg_config;
+
+/* Caller-owned device buffers.  N = envs, F = phys dims of the env type, P = n_params,
+ * D = obs dim.  Pointers that a configuration does not need may be NULL (nsg_layout says
+ * which are needed). */
+typedef struct nsg_buffers {
+  double* phys;          /* [F][N] integrator state, fp64 like the reference              */
+  int32_t* cell;         /* [N]    FrozenLake state s                                     */
+  double* theta;         /* [P][N] tuned θ   (FrozenLake: [3][N] transition_prob)         */
+  double* table_prob;    /* [3][N] FrozenLake: probabilities baked into the wrapper's P table.
+                            Differs from theta after a reset: the reference's reset restores
+                            transition_prob (toy_text.py:396) but its next step re-installs the
+                            wrapper's un-reset self.P (toy_text.py:365-367), so the previous
+                            episode's slip probabilities stay in force until the next fire.   */
+  int32_t* t;            /* [N]    wrapper time t == obs["relative_time"] (base.py:314,347) */
+  uint8_t* status;       /* [N]    NSG_ST_* bits                                          */
+  uint64_t* rng_env;     /* [4][N] env np_random PCG64: state_hi,state_lo,inc_hi,inc_lo   */
+  uint64_t* rng_upd;     /* [P][4][N] update-fn PCG64 streams (only rows with uses_rng)   */
+  int32_t* cursor;       /* [P][N] StepWise/Cyclic list cursor                            */
+  float* obs;            /* [N][D] obs["state"] float32 (classic control)                 */
+  float* reward;         /* [N]                                                           */
+  uint8_t* terminated;   /* [N]                                                           */
+  uint8_t* truncated;    /* [N]                                                           */
+  uint8_t* env_change;   /* [P][N] ground-truth flags (info["Ground Truth Env Change"])   */
+  float* delta_change;   /* [P][N] ground-truth deltas (info["Ground Truth Delta Change"]) */
+  float* prob;           /* [N]    FrozenLake info["prob"]                                */
+  float* ep_return;      /* [N]    running episode return      (NSG_F_TRACK_RETURNS)      */
+  int32_t* ep_length;    /* [N]    running episode length                                 */
+  float* last_return;    /* [N]    return of the last finished episode                    */
+  int32_t* last_length;  /* [N]                                                           */
+  uint32_t* counters;    /* [NSG_CNT_COUNT]                                               */
+  int32_t* done_idx;     /* [N]    compacted indices of envs done this step (NSG_F_COMPACT_DONE) */
+} nsg_buffers;
+
+/* element counts the caller must allocate for each nsg_buffers member (0 = not needed) */
+typedef struct nsg_layout {
+  int64_t n;
+  int32_t phys_dim, obs_dim, n_params, n_theta_rows, action_is_float;
+  int32_t n_actions;           /* discrete action count, 0 for continuous                  */
+  int64_t phys, cell, theta, table_prob, t, status, rng_env, rng_upd, cursor, obs, reward, terminated,
+      truncated, env_change, delta_change, prob, ep_return, ep_length, last_return, last_length,
+      counters, done_idx;
+} nsg_layout;
+
+typedef struct nsg_handle nsg_handle;
+
+int nsg_abi_version(void);
+const char* nsg_last_error(void);
+size_t nsg_sizeof_config(void);
+size_t nsg_sizeof_buffers(void);
+size_t nsg_sizeof_layout(void);
+
+/* Buffer sizes for (cfg, n).  Pure host arithmetic. */
+int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out);
+
+/* Replaces NSClassicControlWrapper.__init__ / NSFrozenLakeWrapper.__init__
+ * (ns_gym/wrappers/classic_control.py:27-58, ns_gym/wrappers/toy_text.py:282-340) for N
+ * env instances: validates cfg, uploads the constant tables (`tables`: the blob that
+ * sched_tab_off / val_tab_off / desc_tab_off index). */
+int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, int64_t n,
+               nsg_handle** out);
+
+/* Attach caller-owned device buffers (sizes from nsg_layout_query). */
+int nsg_bind(nsg_handle* h, const nsg_buffers* bufs);
+
+/* Replaces NSWrapper.reset + subclass tails (ns_gym/base.py:365-431,
+ * classic_control.py:102-109, toy_text.py:382-399) for every env with mask[i] != 0
+ * (mask NULL = all).  seeds_dev NULL = reset(seed=None): env and update-fn streams
+ * continue; otherwise env i is seeded with seeds_dev[i] exactly like reset(seed=seeds[i]). */
+int nsg_reset(nsg_handle* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, void* stream);
+
+/* Replaces NSClassicControlWrapper.step / NSFrozenLakeWrapper.step -> NSWrapper.step ->
+ * gymnasium step (classic_control.py:60-100, toy_text.py:342-380, base.py:296-363) for all
+ * N envs in one fused launch.  actions_dev: int32[N] (discrete) or float[N] (continuous).
+ * Envs whose previous step ended an episode are reset (seed=None) instead of stepped
+ * (gymnasium next-step autoreset): reward 0, terminated/truncated 0, relative_time 0. */
+int nsg_step(nsg_handle* h, const void* actions_dev, void* stream);
+
+/* K fused steps with state held in registers between steps; actions [K][N]; per-step
+ * outputs are written to the caller's [K][...] trajectory buffers (any may be NULL). */
+typedef struct nsg_rollout_out {
+  float* obs;          /* [K][N][D]  (FrozenLake: int32 [K][N] passed through this pointer) */
+  float* reward;       /* [K][N] */
+  uint8_t* terminated; /* [K][N] */
+  uint8_t* truncated;  /* [K][N] */
+  uint8_t* env_change; /* [K][P][N] */
+  float* delta_change; /* [K][P][N] */
+} nsg_rollout_out;
+int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const nsg_rollout_out* out,
+                void* stream);
+
+/* Heterogeneous batch: one launch over up to NSG_MAX_SEGMENTS handles of different env
+ * types (per-env-type dispatch is wave-uniform because segments are block-aligned). */
+int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* actions_dev,
+                   void* stream);
+
+/* θ-schedule engine alone (Scheduler.__call__ + UpdateFn.__call__, base.py:67-81,124-149)
+ * on param slot `p` of the handle's config: n lanes, each starting from theta0[i] (3 doubles
+ * per lane for distributions) and its stream, iterated over t = t0 .. t0+T-1, θ fed back.
+ * Outputs [T][n] (theta: [T][n] or [T][3][n]).  rng_state: [4][n] or NULL. */
+int nsg_theta_trace(nsg_handle* h, int32_t p, int32_t n, int32_t t0, int32_t T, const double* theta0,
+                    uint64_t* rng_state, double* theta_out, uint8_t* fired_out, double* delta_out,
+                    void* stream);
+
+/* NumPy-compatible bit streams on device (SeedSequence -> PCG64; numpy Generator.random /
+ * normal).  kind 0: raw uint64, 1: random() double, 2: standard_normal double.
+ * seeds[n], spawn_key < 0 = root stream, else SeedSequence(seed).spawn(..)[spawn_key].
+ * out [count][n].  state_out [4][n] may be NULL. */
+int nsg_rng_fill(int32_t kind, const uint64_t* seeds_dev, int32_t n, int32_t spawn_key, int32_t count,
+                 void* out_dev, uint64_t* state_out_dev, void* stream);
+
+/* Timing helper: average device time (ms) of `iters` back-to-back nsg_step launches measured
+ * with hipEvents on `stream` (synchronises; not for use inside graph capture). */
+int nsg_time_steps(nsg_handle* h, const void* actions_dev, int32_t iters, void* stream, float* ms_avg);
+
+int nsg_destroy(nsg_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSGYM_HIP_H */

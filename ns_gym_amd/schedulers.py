@@ -1,0 +1,151 @@
+"""Schedulers with the reference's names and constructor signatures (ns_gym/schedulers.py).
+
+Deterministic schedulers that are pure functions of t compile either to a closed form the
+kernel evaluates (Continuous, Periodic, Burst) or to a bit table over t staged in LDS
+(Discrete, Window, Custom).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _abi as A
+from .base import Scheduler
+
+_DEFAULT_TABLE_HORIZON = 4096
+
+
+class ContinuousScheduler(Scheduler):
+    """Fires at every step in range (ns_gym/schedulers.py:46-53)."""
+
+    def __init__(self, start=0, end=np.inf) -> None:
+        super().__init__(start, end)
+
+    def _compile(self, tables, horizon):
+        return {"sched_kind": A.SCHED_CONTINUOUS, **self._range()}
+
+
+class PeriodicScheduler(Scheduler):
+    """Fires when t % period == 0 (ns_gym/schedulers.py:77-89)."""
+
+    def __init__(self, period: int, start=0, end=np.inf) -> None:
+        super().__init__(start, end)
+        self.period = period
+
+    def _compile(self, tables, horizon):
+        if int(self.period) != self.period or self.period <= 0:
+            raise ValueError("PeriodicScheduler: period must be a positive integer")
+        return {"sched_kind": A.SCHED_PERIODIC, "sched_i0": int(self.period), **self._range()}
+
+
+class BurstScheduler(Scheduler):
+    """on_duration firing steps then off_duration silent steps, cyclically
+    (ns_gym/schedulers.py:119-140)."""
+
+    def __init__(self, on_duration: int, off_duration: int, start=0, end=np.inf) -> None:
+        super().__init__(start, end)
+        self.on_duration = on_duration
+        self.off_duration = off_duration
+        self.cycle = on_duration + off_duration
+
+    def _compile(self, tables, horizon):
+        if self.cycle <= 0:
+            raise ValueError("BurstScheduler: on_duration + off_duration must be positive")
+        return {"sched_kind": A.SCHED_BURST, "sched_i0": int(self.on_duration),
+                "sched_i1": int(self.off_duration), **self._range()}
+
+
+class DiscreteScheduler(Scheduler):
+    """Fires at the listed time steps (ns_gym/schedulers.py:56-74)."""
+
+    def __init__(self, event_list: set, start=0, end=np.inf) -> None:
+        super().__init__(start, end)
+        self.event_list = event_list
+        assert min(event_list) >= start, "Scheduler start time occurs after first event in event list"
+        assert max(event_list) <= end, "Scheduler end time occurs before last event in event list"
+
+    def _compile(self, tables, horizon):
+        n = int(max(self.event_list)) + 1
+        bits = np.zeros(max(n, 1), dtype=np.uint8)
+        for e in self.event_list:
+            if e >= 0 and int(e) == e:
+                bits[int(e)] = 1
+        off, ln = tables.add_bits(bits)
+        return {"sched_kind": A.SCHED_TABLE, "sched_tab_off": off, "sched_tab_len": ln, "sched_i0": 0,
+                **self._range()}
+
+
+class WindowScheduler(Scheduler):
+    """Fires inside any inclusive (start, end) window (ns_gym/schedulers.py:180-198)."""
+
+    def __init__(self, windows: list, start=0, end=np.inf) -> None:
+        super().__init__(start, end)
+        self.windows = windows
+
+    def _compile(self, tables, horizon):
+        finite = [w_end for _, w_end in self.windows if np.isfinite(w_end)]
+        starts = [w_start for w_start, _ in self.windows]
+        n = int(max(finite + starts + [0])) + 2
+        t = np.arange(n)
+        bits = np.zeros(n, dtype=np.uint8)
+        for w_start, w_end in self.windows:
+            bits |= ((w_start <= t) & (t <= w_end)).astype(np.uint8)
+        beyond = int(any(not np.isfinite(w_end) for _, w_end in self.windows))
+        off, ln = tables.add_bits(bits)
+        return {"sched_kind": A.SCHED_TABLE, "sched_tab_off": off, "sched_tab_len": ln, "sched_i0": beyond,
+                **self._range()}
+
+
+class CustomScheduler(Scheduler):
+    """User-defined event function of t (ns_gym/schedulers.py:31-43).  An arbitrary Python
+    callable cannot run in the kernel; it is sampled once over the episode horizon
+    (TimeLimit's max_episode_steps, or `horizon=`) into a bit table."""
+
+    def __init__(self, event_function, start=0, end=np.inf, horizon: int | None = None) -> None:
+        super().__init__(start, end)
+        self.event_function = event_function
+        self.horizon = horizon
+
+    def _compile(self, tables, horizon):
+        h = self.horizon or horizon or _DEFAULT_TABLE_HORIZON
+        bits = np.array([1 if self.event_function(t) else 0 for t in range(int(h) + 1)], dtype=np.uint8)
+        off, ln = tables.add_bits(bits)
+        return {"sched_kind": A.SCHED_TABLE, "sched_tab_off": off, "sched_tab_len": ln, "sched_i0": 0,
+                **self._range()}
+
+
+class _StochasticScheduler(Scheduler):
+    """RandomScheduler / DecayingProbabilityScheduler / MemorylessScheduler
+    (ns_gym/schedulers.py:9-28,92-116,143-177) own a PCG64 stream; SURVEY §8(f) rank 3."""
+
+    def _compile(self, tables, horizon):
+        raise NotImplementedError(
+            f"{type(self).__name__}: stochastic schedulers are not fused into the kernel yet"
+        )
+
+
+class RandomScheduler(_StochasticScheduler):
+    def __init__(self, probability: float = 0.5, start=0, end=np.inf, seed=None) -> None:
+        super().__init__(start, end)
+        self.probability = probability
+        self.seed_value = seed
+
+
+class DecayingProbabilityScheduler(_StochasticScheduler):
+    def __init__(self, initial_probability: float, decay_rate: float, start=0, end=np.inf, seed=None) -> None:
+        super().__init__(start, end)
+        self.initial_probability = initial_probability
+        self.decay_rate = decay_rate
+        self.seed_value = seed
+
+
+class MemorylessScheduler(_StochasticScheduler):
+    def __init__(self, p: float, start=0, end=np.inf, seed=None) -> None:
+        super().__init__(start, end)
+        self.p = p
+        self.seed_value = seed
+
+
+__all__ = [
+    "BurstScheduler", "ContinuousScheduler", "CustomScheduler", "DecayingProbabilityScheduler",
+    "DiscreteScheduler", "MemorylessScheduler", "PeriodicScheduler", "RandomScheduler", "WindowScheduler",
+]

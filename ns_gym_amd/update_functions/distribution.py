@@ -1,0 +1,149 @@
+"""Distribution update functions with the reference's names and signatures
+(ns_gym/update_functions/distribution.py), specialised to the 3-way slip distribution that
+NSFrozenLakeWrapper accepts (ns_gym/wrappers/toy_text.py:332-334)."""
+from __future__ import annotations
+
+from .. import _abi as A
+from ..base import Scheduler, UpdateDistributionFn
+
+
+def _u(*vals):
+    u = [0.0] * 8
+    for i, v in enumerate(vals):
+        u[i] = float(v)
+    return u
+
+
+def _triples(rows, what):
+    out = []
+    for r in rows:
+        if len(r) != 3:
+            raise ValueError(f"{what}: every distribution must have length 3")
+        out.append([float(x) for x in r])
+    return out
+
+
+class DistributionIncrementUpdate(UpdateDistributionFn):
+    """p₀ = min(1, p₀ + k), rest uniform (distribution.py:41-67)."""
+
+    def __init__(self, scheduler: Scheduler, k: float) -> None:
+        super().__init__(scheduler)
+        self.k = k
+
+    def _compile(self, tables):
+        return {"upd_kind": A.UPD_D_INCREMENT, "u": _u(self.k)}
+
+
+class DistributionDecrementUpdate(UpdateDistributionFn):
+    """p₀ = max(0, p₀ − k), rest uniform (distribution.py:70-97)."""
+
+    def __init__(self, scheduler: Scheduler, k: float) -> None:
+        super().__init__(scheduler)
+        self.k = k
+
+    def _compile(self, tables):
+        return {"upd_kind": A.UPD_D_DECREMENT, "u": _u(self.k)}
+
+
+class DistributionStepWiseUpdate(UpdateDistributionFn):
+    """Next distribution of `update_values` on each fire (distribution.py:100-130)."""
+
+    def __init__(self, scheduler: Scheduler, update_values: list) -> None:
+        super().__init__(scheduler)
+        self.update_values = update_values
+
+    def _compile(self, tables):
+        rows = _triples(self.update_values, "DistributionStepWiseUpdate")
+        off, _ = tables.add_values([x for r in rows for x in r] or [0.0, 0.0, 0.0])
+        return {"upd_kind": A.UPD_D_STEPWISE, "val_tab_off": off, "val_tab_len": len(rows)}
+
+
+class DistributionCyclicUpdate(UpdateDistributionFn):
+    """Cycle through `dist_list` (distribution.py:334-356)."""
+
+    def __init__(self, scheduler: Scheduler, dist_list: list) -> None:
+        super().__init__(scheduler)
+        self.dist_list = dist_list
+        self._index = 0
+
+    def _compile(self, tables):
+        rows = _triples(self.dist_list, "DistributionCyclicUpdate")
+        if not rows:
+            raise ValueError("DistributionCyclicUpdate: dist_list must not be empty")
+        off, _ = tables.add_values([x for r in rows for x in r])
+        return {"upd_kind": A.UPD_D_CYCLIC, "val_tab_off": off, "val_tab_len": len(rows)}
+
+
+class DistributionNoUpdate(UpdateDistributionFn):
+    """p unchanged (distribution.py:217-231)."""
+
+    def __init__(self, scheduler: Scheduler) -> None:
+        super().__init__(scheduler)
+
+    def _compile(self, tables):
+        return {"upd_kind": A.UPD_D_NOUPDATE}
+
+
+class UniformDrift(UpdateDistributionFn):
+    """(1−rate)·p + rate/n (distribution.py:234-261)."""
+
+    def __init__(self, scheduler: Scheduler, rate: float) -> None:
+        super().__init__(scheduler)
+        self.rate = rate
+
+    def _compile(self, tables):
+        return {"upd_kind": A.UPD_D_UNIFORMDRIFT, "u": _u(self.rate)}
+
+
+class TargetReversion(UpdateDistributionFn):
+    """p + θ(target − p) (distribution.py:264-293)."""
+
+    def __init__(self, scheduler: Scheduler, target: list, theta: float) -> None:
+        super().__init__(scheduler)
+        self.target = target
+        self.theta = theta
+
+    def _compile(self, tables):
+        (t,) = _triples([self.target], "TargetReversion")
+        return {"upd_kind": A.UPD_D_TARGETREV, "u": _u(t[0], t[1], t[2], self.theta)}
+
+
+class DistributionLinearInterpolation(UpdateDistributionFn):
+    """start + (end − start)·min(t/T, 1) (distribution.py:296-331)."""
+
+    def __init__(self, scheduler: Scheduler, start_dist: list, end_dist: list, T: int) -> None:
+        super().__init__(scheduler)
+        self.start_dist, self.end_dist, self.T = start_dist, end_dist, T
+
+    def _compile(self, tables):
+        s, e = _triples([self.start_dist, self.end_dist], "DistributionLinearInterpolation")
+        return {"upd_kind": A.UPD_D_LERP, "u": _u(*s, *e, self.T)}
+
+
+class _NotFusedYet(UpdateDistributionFn):
+    def _compile(self, tables):
+        raise NotImplementedError(f"{type(self).__name__} is not fused into the kernel yet (SURVEY §8(f) rank 3)")
+
+
+class RandomCategorical(_NotFusedYet):
+    """rng.dirichlet(ones(n)) (distribution.py:11-38)."""
+
+    def __init__(self, scheduler: Scheduler, seed=None) -> None:
+        super().__init__(scheduler)
+        self.seed_value = seed
+
+
+class LCBoundedDistrubutionUpdate(_NotFusedYet):
+    """Rejection-sampled Lipschitz-bounded update (distribution.py:133-183)."""
+
+    def __init__(self, scheduler, L: float, update_fn=None) -> None:
+        super().__init__(scheduler)
+        self.L = L
+        self.update_fn = update_fn
+
+
+__all__ = [
+    "DistributionCyclicUpdate", "DistributionDecrementUpdate", "DistributionIncrementUpdate",
+    "DistributionLinearInterpolation", "DistributionNoUpdate", "DistributionStepWiseUpdate",
+    "LCBoundedDistrubutionUpdate", "RandomCategorical", "TargetReversion", "UniformDrift",
+]

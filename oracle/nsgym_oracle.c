@@ -1,0 +1,801 @@
+/* nsgym_oracle.c — TEST INFRASTRUCTURE ONLY.
+ *
+ * Scalar CPU restatement (plain C, one env at a time, float64 like the reference) of the
+ * hot path the HIP library accelerates:
+ *
+ *   NSClassicControlWrapper.step/reset   ns_gym/wrappers/classic_control.py:60-109,193-458
+ *   NSFrozenLakeWrapper.step/reset       ns_gym/wrappers/toy_text.py:342-399,426-469
+ *   NSWrapper.step/reset/_seed_update_fns ns_gym/base.py:296-431
+ *   Scheduler.__call__ / UpdateFn.__call__ ns_gym/base.py:67-81,124-149,182,192-203
+ *   schedulers / update functions        ns_gym/schedulers.py, ns_gym/update_functions/{single_param,distribution}.py
+ *   wasserstein_distance                 ns_gym/utils.py:55-94 (SciPy _cdf_distance, p=1)
+ *   base MDPs                            gymnasium 1.2.1 [UPSTREAM, uv.lock:958-959, absent]
+ *   bit streams                          NumPy SeedSequence/PCG64/Generator [UPSTREAM, uv.lock:1868-1869]
+ *
+ * Pinning (tests/test_oracle_*.py): every schedule/update/wrapper golden vector under
+ * tests/golden/ was produced by the reference's own classes; the NumPy stream vectors by
+ * the NumPy installed in the build container.  Integrator arithmetic (a20) is restated
+ * from the published gymnasium sources and is PARITY-UNPINNED by the reference's tests.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ * It shares with the product ONLY the data-format header (include/nsgym_hip.h) and the
+ * NumPy ziggurat table data; no code.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared  (see oracle/Makefile).  Contraction is off
+ * so every a*b+c rounds twice exactly like the reference's Python floats.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/nsgym_hip.h"
+#include "../include/nsg_zig_tables.inc"
+
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------ NumPy SeedSequence */
+/* numpy/random/bit_generator.pyx [UPSTREAM]: 32-bit hash-mix entropy pool, pool size 4. */
+#define SS_INIT_A 0x43b0d7e5u
+#define SS_MULT_A 0x931e8875u
+#define SS_INIT_B 0x8b51f9ddu
+#define SS_MULT_B 0x58f38dedu
+#define SS_MIX_L 0xca01f9ddu
+#define SS_MIX_R 0x4973f715u
+
+static uint32_t ss_hashmix(uint32_t v, uint32_t* hc) {
+  v ^= *hc;
+  *hc *= SS_MULT_A;
+  v *= *hc;
+  v ^= v >> 16;
+  return v;
+}
+static uint32_t ss_mix(uint32_t x, uint32_t y) {
+  uint32_t r = SS_MIX_L * x - SS_MIX_R * y;
+  r ^= r >> 16;
+  return r;
+}
+
+/* SeedSequence(entropy=seed, spawn_key=(child,) if child >= 0 else ()).generate_state(4, uint64) */
+static void ss_generate(uint64_t seed, int child, uint64_t out[4]) {
+  uint32_t ent[8];
+  int n = 0;
+  ent[n++] = (uint32_t)seed;
+  if (seed >> 32) ent[n++] = (uint32_t)(seed >> 32);
+  if (child >= 0) {
+    while (n < 4) ent[n++] = 0; /* entropy zero-padded to pool size before the spawn key */
+    ent[n++] = (uint32_t)child;
+  }
+  uint32_t pool[4], hc = SS_INIT_A;
+  for (int i = 0; i < 4; i++) pool[i] = ss_hashmix(i < n ? ent[i] : 0u, &hc);
+  for (int s = 0; s < 4; s++)
+    for (int d = 0; d < 4; d++)
+      if (s != d) pool[d] = ss_mix(pool[d], ss_hashmix(pool[s], &hc));
+  for (int s = 4; s < n; s++)
+    for (int d = 0; d < 4; d++) pool[d] = ss_mix(pool[d], ss_hashmix(ent[s], &hc));
+  uint32_t hb = SS_INIT_B, w[8];
+  for (int i = 0; i < 8; i++) {
+    uint32_t v = pool[i & 3];
+    v ^= hb;
+    hb *= SS_MULT_B;
+    v *= hb;
+    v ^= v >> 16;
+    w[i] = v;
+  }
+  for (int i = 0; i < 4; i++) out[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+}
+
+/* ------------------------------------------------------------------ NumPy PCG64 */
+typedef struct { u128 state, inc; } pcg64;
+#define PCG_MULT ((((u128)2549297995355413924ULL) << 64) | (u128)4865540595714422341ULL)
+
+static void pcg_seed(pcg64* r, uint64_t seed, int child) {
+  uint64_t v[4];
+  ss_generate(seed, child, v);
+  u128 initstate = ((u128)v[0] << 64) | v[1];
+  u128 initseq = ((u128)v[2] << 64) | v[3];
+  r->state = 0;
+  r->inc = (initseq << 1) | 1;
+  r->state = r->state * PCG_MULT + r->inc;
+  r->state += initstate;
+  r->state = r->state * PCG_MULT + r->inc;
+}
+static uint64_t pcg_next64(pcg64* r) {
+  r->state = r->state * PCG_MULT + r->inc;
+  uint64_t hi = (uint64_t)(r->state >> 64), lo = (uint64_t)r->state;
+  uint64_t x = hi ^ lo;
+  unsigned rot = (unsigned)(hi >> 58);
+  return (x >> rot) | (x << ((-rot) & 63));
+}
+static double pcg_double(pcg64* r) { return (double)(pcg_next64(r) >> 11) * (1.0 / 9007199254740992.0); }
+
+/* numpy/random/src/distributions/distributions.c random_standard_normal [UPSTREAM] */
+static double u2d(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
+#define ZIG_R 3.6541528853610087963519472518
+#define ZIG_INV_R 0.27366123732975827203338247596
+static double pcg_std_normal(pcg64* g) {
+  for (;;) {
+    uint64_t r = pcg_next64(g);
+    int idx = (int)(r & 0xff);
+    r >>= 8;
+    int sign = (int)(r & 1);
+    uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+    double x = (double)rabs * u2d(NSG_ZIG_WI_BITS[idx]);
+    if (sign) x = -x;
+    if (rabs < NSG_ZIG_KI[idx]) return x;
+    if (idx == 0) {
+      for (;;) {
+        double xx = -ZIG_INV_R * log1p(-pcg_double(g));
+        double yy = -log1p(-pcg_double(g));
+        if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? -(ZIG_R + xx) : ZIG_R + xx;
+      }
+    } else {
+      double f1 = u2d(NSG_ZIG_FI_BITS[idx - 1]), f0 = u2d(NSG_ZIG_FI_BITS[idx]);
+      if ((f1 - f0) * pcg_double(g) + f0 < exp(-0.5 * x * x)) return x;
+    }
+  }
+}
+static double pcg_normal(pcg64* g, double loc, double scale) { return loc + scale * pcg_std_normal(g); }
+
+static void rng_load(const uint64_t* base, int64_t N, int64_t i, pcg64* r) {
+  r->state = ((u128)base[0 * N + i] << 64) | base[1 * N + i];
+  r->inc = ((u128)base[2 * N + i] << 64) | base[3 * N + i];
+}
+static void rng_store(uint64_t* base, int64_t N, int64_t i, const pcg64* r) {
+  base[0 * N + i] = (uint64_t)(r->state >> 64);
+  base[1 * N + i] = (uint64_t)r->state;
+  base[2 * N + i] = (uint64_t)(r->inc >> 64);
+  base[3 * N + i] = (uint64_t)r->inc;
+}
+
+/* ------------------------------------------------------------------ schedulers */
+/* Scheduler.__call__ (ns_gym/base.py:67-81): start <= t <= end and _check(t). */
+static int sched_fire(const nsg_param_cfg* pc, const uint8_t* tables, int t) {
+  double td = (double)t;
+  if (!(pc->sched_start <= td && td <= pc->sched_end)) return 0;
+  switch (pc->sched_kind) {
+    case NSG_SCHED_CONTINUOUS: return 1;                          /* schedulers.py:52-53 */
+    case NSG_SCHED_PERIODIC: return (t % pc->sched_i0) == 0;      /* :88-89 */
+    case NSG_SCHED_BURST: return (t % (pc->sched_i0 + pc->sched_i1)) < pc->sched_i0; /* :139-140 */
+    case NSG_SCHED_TABLE: {                                       /* :73-74, :197-198, :42-43 */
+      if (t < 0) return 0;
+      if (t >= pc->sched_tab_len) return (int)pc->sched_i0;
+      const uint32_t* bits = (const uint32_t*)tables + pc->sched_tab_off;
+      return (bits[t >> 5] >> (t & 31)) & 1;
+    }
+    default: return 0;
+  }
+}
+
+/* ------------------------------------------------------------------ scalar update fns */
+static const double* val_table(const nsg_param_cfg* pc, const uint8_t* tables) {
+  return (const double*)tables + pc->val_tab_off;
+}
+
+/* UpdateFn._update for every scalar class (single_param.py); rng may be NULL if !uses_rng. */
+static double upd_scalar(const nsg_param_cfg* pc, const uint8_t* tables, double th, int t, pcg64* rng,
+                         int32_t* cursor) {
+  const double* u = pc->u;
+  double td = (double)t;
+  switch (pc->upd_kind) {
+    case NSG_UPD_INCREMENT: return th + u[0];                               /* :173-175 */
+    case NSG_UPD_DECREMENT: return th - u[0];                               /* :197-199 */
+    case NSG_UPD_TREND: return th + u[0] * td;                              /* :38-40 */
+    case NSG_UPD_POLY: {                                                    /* :471-473 */
+      const double* c = val_table(pc, tables);
+      double trend = 0.0, pw = 1.0;
+      for (int i = 0; i < pc->val_tab_len; i++) {
+        pw *= td; /* t**(i+1), exact in fp64 for the horizons used */
+        trend = trend + c[i] * pw;
+      }
+      return th + trend;
+    }
+    case NSG_UPD_GEOMETRIC: return th * u[0];                               /* :305-307 */
+    case NSG_UPD_EXPDECAY: return th * exp(-u[0] * td);                     /* :285-287 */
+    case NSG_UPD_OSCILLATING: return th + u[0] * sin(td);                   /* :262-264 */
+    case NSG_UPD_SIGMOID: {                                                 /* :383-385 */
+      double sg = 1.0 / (1.0 + exp(-u[2] * (td - u[3])));
+      return u[0] + (u[1] - u[0]) * sg;
+    }
+    case NSG_UPD_LERP: {                                                    /* :506-508 */
+      double frac = td / u[2];
+      if (!(frac < 1.0)) frac = 1.0; /* min(t / T, 1.0) */
+      return u[0] + (u[1] - u[0]) * frac;
+    }
+    case NSG_UPD_STEPWISE: {                                                /* :217-223 */
+      if (*cursor < pc->val_tab_len) return val_table(pc, tables)[(*cursor)++];
+      return th; /* exhausted list: value unchanged, still reported as fired */
+    }
+    case NSG_UPD_CYCLIC: {                                                  /* :405-408 */
+      double v = val_table(pc, tables)[*cursor];
+      *cursor = (*cursor + 1) % pc->val_tab_len;
+      return v;
+    }
+    case NSG_UPD_NOUPDATE: return th;                                       /* :239-240 */
+    case NSG_UPD_RANDOMWALK: return th + pcg_normal(rng, u[0], u[1]);       /* :110-113 */
+    case NSG_UPD_RW_DRIFT: {                                                /* :148-151 */
+      double w = pcg_normal(rng, u[1], u[2]);
+      return u[0] + th + w;
+    }
+    case NSG_UPD_RW_DRIFT_TREND: {                                          /* :78-81 */
+      double w = pcg_normal(rng, u[1], u[2]);
+      return u[0] + th + w + u[3] * td;
+    }
+    case NSG_UPD_OU: {                                                      /* :344-346 */
+      double noise = u[2] > 0 ? pcg_normal(rng, 0.0, u[2]) : 0.0;
+      return th + u[0] * (u[1] - th) + noise;
+    }
+    case NSG_UPD_BOUNDED_RW: {                                              /* :446-448 */
+      double v = th + pcg_normal(rng, u[0], u[1]);
+      if (v < u[2]) v = u[2];
+      if (v > u[3]) v = u[3];
+      return v;
+    }
+    default: return th;
+  }
+}
+
+/* ------------------------------------------------------------------ distribution update fns */
+/* ns_gym/utils.py:55-94 -> scipy.stats.wasserstein_distance(values=arange(3), weights) ->
+ * _cdf_distance(p=1): sum(|U_cdf - V_cdf| * deltas) with cdf_k = cumsum_k / cumsum_last. */
+static double w1_3(const double* a, const double* b) {
+  double a01 = a[0] + a[1], at = a01 + a[2];
+  double b01 = b[0] + b[1], bt = b01 + b[2];
+  double d0 = fabs(a[0] / at - b[0] / bt);
+  double d1 = fabs(a01 / at - b01 / bt);
+  /* np.sum over [0*d0', d0, 0*.., d1, 0*..] in index order */
+  return ((((0.0 + d0) + 0.0) + d1) + 0.0);
+}
+
+static void upd_dist(const nsg_param_cfg* pc, const uint8_t* tables, const double* p, int t, int32_t* cursor,
+                     double* q) {
+  const double* u = pc->u;
+  double td = (double)t;
+  q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+  switch (pc->upd_kind) {
+    case NSG_UPD_D_INCREMENT: {                        /* distribution.py:61-67 */
+      double v = p[0] + u[0];
+      q[0] = v > 1.0 ? 1.0 : v;                        /* min(1, p0 + k) */
+      q[1] = (1.0 - q[0]) / 2.0;
+      q[2] = (1.0 - q[0]) / 2.0;
+      break;
+    }
+    case NSG_UPD_D_DECREMENT: {                        /* :88-97 */
+      double v = p[0] - u[0];
+      q[0] = v < 0.0 ? 0.0 : v;                        /* max(0, p0 - k) */
+      q[1] = (1.0 - q[0]) / 2.0;
+      q[2] = (1.0 - q[0]) / 2.0;
+      break;
+    }
+    case NSG_UPD_D_STEPWISE:                           /* :116-130 */
+      if (*cursor < pc->val_tab_len) {
+        const double* v = val_table(pc, tables) + 3 * (*cursor)++;
+        q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+      }
+      break;
+    case NSG_UPD_D_CYCLIC: {                           /* :353-356 */
+      const double* v = val_table(pc, tables) + 3 * (*cursor);
+      q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+      *cursor = (*cursor + 1) % pc->val_tab_len;
+      break;
+    }
+    case NSG_UPD_D_NOUPDATE: break;                    /* :230-231 */
+    case NSG_UPD_D_UNIFORMDRIFT: {                     /* :256-261 */
+      double un = 1.0 / 3;
+      for (int k = 0; k < 3; k++) q[k] = (1 - u[0]) * p[k] + u[0] * un;
+      break;
+    }
+    case NSG_UPD_D_TARGETREV:                          /* :289-293 */
+      for (int k = 0; k < 3; k++) q[k] = p[k] + u[3] * (u[k] - p[k]);
+      break;
+    case NSG_UPD_D_LERP: {                             /* :326-331 */
+      double frac = td / u[6];
+      if (!(frac < 1.0)) frac = 1.0;
+      for (int k = 0; k < 3; k++) q[k] = u[k] + (u[3 + k] - u[k]) * frac;
+      break;
+    }
+    default: break;
+  }
+}
+
+/* ------------------------------------------------------------------ env tables */
+static const int PHYS_DIM[NSG_ENV_COUNT] = {4, 2, 4, 2, 2, 0};
+static const int OBS_DIM[NSG_ENV_COUNT] = {4, 3, 6, 2, 2, 1};
+static const int N_THETA[NSG_ENV_COUNT] = {6, 4, 8, 2, 1, 1};
+
+int orc_phys_dim(int env) { return PHYS_DIM[env]; }
+int orc_obs_dim(int env) { return OBS_DIM[env]; }
+
+/* constraint checker (ns_gym/wrappers/classic_control.py:193-422).  nv = proposed values for
+ * every θ slot (untuned slots carry their current value), cur = pre-update attributes,
+ * tuned = bit mask of slots present in new_vals.  Returns bit mask of violated slots. */
+static unsigned constraint_mask(int env, const double* nv, const double* cur, unsigned tuned) {
+  unsigned v = 0;
+  switch (env) {
+    case NSG_ENV_CARTPOLE: /* :208-235  gravity masscart masspole force_mag tau length */
+      if ((tuned & 1u) && nv[0] < 0) v |= 1u;
+      if ((tuned & 2u) && nv[1] <= 0) v |= 2u;
+      if ((tuned & 4u) && nv[2] <= 0) v |= 4u;
+      if ((tuned & 32u) && nv[5] <= 0) v |= 32u;
+      break;
+    case NSG_ENV_PENDULUM: /* :389-420  m l dt g */
+      if ((tuned & 1u) && nv[0] <= 0) v |= 1u;
+      if ((tuned & 2u) && nv[1] <= 0) v |= 2u;
+      if ((tuned & 4u) && nv[2] <= 0) v |= 4u;
+      if ((tuned & 8u) && nv[3] < 0) v |= 8u;
+      break;
+    case NSG_ENV_ACROBOT: { /* :237-357  dt L1 L2 M1 M2 C1 C2 MOI */
+      if (tuned & 2u) { /* LINK_LENGTH_1 :241-265 */
+        if (nv[1] <= 0) v |= 2u;
+        else if ((tuned & 32u) && nv[5] > nv[1]) v |= 2u;
+        else if (nv[1] < cur[5]) v |= 2u;
+      }
+      if ((tuned & 4u) && nv[2] <= 0) v |= 4u;  /* LINK_LENGTH_2: only <= 0 is live (:267) */
+      if ((tuned & 8u) && nv[3] <= 0) v |= 8u;  /* :293-298 */
+      if ((tuned & 16u) && nv[4] <= 0) v |= 16u; /* :300-305 */
+      if (tuned & 32u) { /* LINK_COM_POS_1 :307-331 */
+        if (nv[5] <= 0) v |= 32u;
+        else if ((tuned & 2u) && nv[1] < nv[5]) v |= 32u;
+        else if (nv[5] > cur[1]) v |= 32u;
+      }
+      if (tuned & 64u) { /* LINK_COM_POS_2 :333-357 */
+        if (nv[6] <= 0) v |= 64u;
+        else if ((tuned & 4u) && nv[2] < nv[6]) v |= 64u;
+        else if (nv[6] > cur[2]) v |= 64u;
+      }
+      break;
+    }
+    case NSG_ENV_MOUNTAINCAR: /* :359-376 gravity force */
+      if ((tuned & 1u) && nv[0] <= 0) v |= 1u;
+      if ((tuned & 2u) && nv[1] <= 0) v |= 2u;
+      break;
+    case NSG_ENV_MOUNTAINCAR_CONT: /* :378-387 power */
+      if ((tuned & 1u) && nv[0] <= 0) v |= 1u;
+      break;
+    default: break;
+  }
+  return v;
+}
+
+/* ------------------------------------------------------------------ base MDP steps [UPSTREAM gymnasium 1.2.1] */
+typedef struct { double s[4]; } phys4;
+
+static void env_reset_draw(int env, pcg64* g, double* s) {
+  switch (env) {
+    case NSG_ENV_CARTPOLE: /* np_random.uniform(-0.05, 0.05, size=4): low + (high-low)*u */
+      for (int k = 0; k < 4; k++) s[k] = -0.05 + (0.05 - -0.05) * pcg_double(g);
+      break;
+    case NSG_ENV_PENDULUM: { /* uniform(low=-[pi,1], high=[pi,1]) */
+      s[0] = -M_PI + (M_PI - -M_PI) * pcg_double(g);
+      s[1] = -1.0 + (1.0 - -1.0) * pcg_double(g);
+      break;
+    }
+    case NSG_ENV_ACROBOT: /* uniform(-0.1, 0.1, size=4).astype(float32) */
+      for (int k = 0; k < 4; k++) s[k] = (double)(float)(-0.1 + (0.1 - -0.1) * pcg_double(g));
+      break;
+    case NSG_ENV_MOUNTAINCAR:
+    case NSG_ENV_MOUNTAINCAR_CONT: /* [uniform(-0.6, -0.4), 0] */
+      s[0] = -0.6 + (-0.4 - -0.6) * pcg_double(g);
+      s[1] = 0.0;
+      break;
+    default: break;
+  }
+}
+
+static void env_obs(int env, const double* s, float* o) {
+  switch (env) {
+    case NSG_ENV_CARTPOLE: for (int k = 0; k < 4; k++) o[k] = (float)s[k]; break;
+    case NSG_ENV_PENDULUM: o[0] = (float)cos(s[0]); o[1] = (float)sin(s[0]); o[2] = (float)s[1]; break;
+    case NSG_ENV_ACROBOT:
+      o[0] = (float)cos(s[0]); o[1] = (float)sin(s[0]); o[2] = (float)cos(s[1]); o[3] = (float)sin(s[1]);
+      o[4] = (float)s[2]; o[5] = (float)s[3];
+      break;
+    case NSG_ENV_MOUNTAINCAR:
+    case NSG_ENV_MOUNTAINCAR_CONT: o[0] = (float)s[0]; o[1] = (float)s[1]; break;
+    default: break;
+  }
+}
+
+static double py_fmod_pos(double x, double m) { /* Python float % for m > 0 */
+  double r = fmod(x, m);
+  if (r != 0 && r < 0) r += m;
+  return r;
+}
+
+static void acrobot_dsdt(const double* th, const double* y, double a, double* d) {
+  /* AcrobotEnv._dsdt, "book" variant. th: dt L1 L2 M1 M2 C1 C2 MOI */
+  double m1 = th[3], m2 = th[4], l1 = th[1], lc1 = th[5], lc2 = th[6], I1 = th[7], I2 = th[7], g = 9.8;
+  double theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
+  double d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * cos(theta2)) + I1 + I2;
+  double d2 = m2 * (lc2 * lc2 + l1 * lc2 * cos(theta2)) + I2;
+  double phi2 = m2 * lc2 * g * cos(theta1 + theta2 - M_PI / 2.0);
+  double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * sin(theta2) - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * sin(theta2) +
+                (m1 * lc1 + m2 * l1) * g * cos(theta1 - M_PI / 2) + phi2;
+  double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * sin(theta2) - phi2) /
+                    (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+  double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+  d[0] = dtheta1; d[1] = dtheta2; d[2] = ddtheta1; d[3] = ddtheta2; d[4] = 0.0;
+}
+
+/* returns terminated; writes reward */
+static int env_step(int env, const double* th, double* s, int ai, float af, double* reward) {
+  switch (env) {
+    case NSG_ENV_CARTPOLE: { /* th: gravity masscart masspole force_mag tau length */
+      double gravity = th[0], masscart = th[1], masspole = th[2], force_mag = th[3], tau = th[4], length = th[5];
+      double total_mass = masspole + masscart;     /* _dependency_resolver classic_control.py:426-435 */
+      double polemass_length = length * masspole;  /* :436-444 */
+      double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+      double force = ai == 1 ? force_mag : -force_mag;
+      double costheta = cos(theta), sintheta = sin(theta);
+      double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
+      double thetaacc = (gravity * sintheta - costheta * temp) /
+                        (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
+      double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+      x = x + tau * x_dot;
+      x_dot = x_dot + tau * xacc;
+      theta = theta + tau * theta_dot;
+      theta_dot = theta_dot + tau * thetaacc;
+      s[0] = x; s[1] = x_dot; s[2] = theta; s[3] = theta_dot;
+      double thr = 12 * 2 * M_PI / 360;
+      *reward = 1.0;
+      return x < -2.4 || x > 2.4 || theta < -thr || theta > thr;
+    }
+    case NSG_ENV_PENDULUM: { /* th: m l dt g */
+      double m = th[0], l = th[1], dt = th[2], g = th[3];
+      double t0 = s[0], thdot = s[1];
+      double u = (double)af;
+      if (u < -2.0) u = -2.0;
+      if (u > 2.0) u = 2.0;
+      double an = py_fmod_pos(t0 + M_PI, 2 * M_PI) - M_PI;
+      double costs = an * an + 0.1 * (thdot * thdot) + 0.001 * (u * u);
+      double newthdot = thdot + (3 * g / (2 * l) * sin(t0) + 3.0 / (m * (l * l)) * u) * dt;
+      if (newthdot < -8.0) newthdot = -8.0;
+      if (newthdot > 8.0) newthdot = 8.0;
+      double newth = t0 + newthdot * dt;
+      s[0] = newth; s[1] = newthdot;
+      *reward = -costs;
+      return 0;
+    }
+    case NSG_ENV_ACROBOT: { /* rk4 over [0, dt] */
+      double a = (double)(ai - 1); /* AVAIL_TORQUE = [-1, 0, +1] */
+      double dt = th[0] - 0.0, dt2 = dt / 2.0;
+      double y0[5] = {s[0], s[1], s[2], s[3], a}, k1[5], k2[5], k3[5], k4[5], y[5];
+      acrobot_dsdt(th, y0, y0[4], k1);
+      for (int k = 0; k < 5; k++) y[k] = y0[k] + dt2 * k1[k];
+      acrobot_dsdt(th, y, y[4], k2);
+      for (int k = 0; k < 5; k++) y[k] = y0[k] + dt2 * k2[k];
+      acrobot_dsdt(th, y, y[4], k3);
+      for (int k = 0; k < 5; k++) y[k] = y0[k] + dt * k3[k];
+      acrobot_dsdt(th, y, y[4], k4);
+      double ns[4];
+      for (int k = 0; k < 4; k++) ns[k] = y0[k] + dt / 6.0 * (k1[k] + 2 * k2[k] + 2 * k3[k] + k4[k]);
+      for (int k = 0; k < 2; k++) { /* wrap(x, -pi, pi) */
+        double diff = M_PI - -M_PI;
+        while (ns[k] > M_PI) ns[k] = ns[k] - diff;
+        while (ns[k] < -M_PI) ns[k] = ns[k] + diff;
+      }
+      double mv1 = 4 * M_PI, mv2 = 9 * M_PI;
+      ns[2] = fmin(fmax(ns[2], -mv1), mv1);
+      ns[3] = fmin(fmax(ns[3], -mv2), mv2);
+      for (int k = 0; k < 4; k++) s[k] = ns[k];
+      int term = (-cos(s[0]) - cos(s[1] + s[0])) > 1.0;
+      *reward = term ? 0.0 : -1.0;
+      return term;
+    }
+    case NSG_ENV_MOUNTAINCAR: { /* th: gravity force */
+      double position = s[0], velocity = s[1];
+      velocity += (double)(ai - 1) * th[1] + cos(3 * position) * (-th[0]);
+      if (velocity < -0.07) velocity = -0.07;
+      if (velocity > 0.07) velocity = 0.07;
+      position += velocity;
+      if (position < -1.2) position = -1.2;
+      if (position > 0.6) position = 0.6;
+      if (position == -1.2 && velocity < 0) velocity = 0;
+      s[0] = position; s[1] = velocity;
+      *reward = -1.0;
+      return position >= 0.5 && velocity >= 0;
+    }
+    case NSG_ENV_MOUNTAINCAR_CONT: { /* th: power */
+      double position = s[0], velocity = s[1];
+      double a0 = (double)af;
+      double force = fmin(fmax(a0, -1.0), 1.0);
+      velocity += force * th[0] - 0.0025 * cos(3 * position);
+      if (velocity > 0.07) velocity = 0.07;
+      if (velocity < -0.07) velocity = -0.07;
+      position += velocity;
+      if (position > 0.6) position = 0.6;
+      if (position < -1.2) position = -1.2;
+      if (position == -1.2 && velocity < 0) velocity = 0;
+      int term = position >= 0.45 && velocity >= 0;
+      double r = 0;
+      if (term) r = 100.0;
+      r -= (a0 * a0) * 0.1;
+      s[0] = (double)(float)position; s[1] = (double)(float)velocity; /* state kept as float32 upstream */
+      *reward = r;
+      return term;
+    }
+    default: *reward = 0; return 0;
+  }
+}
+
+/* ------------------------------------------------------------------ wrapper-level reset */
+static int letter_index(uint8_t c) { return c == 'S' ? 0 : c == 'F' ? 1 : c == 'H' ? 2 : 3; }
+
+static void reset_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N, int64_t i,
+                      int has_seed, uint64_t seed) {
+  int env = cfg->env_type, P = cfg->n_params;
+  pcg64 g;
+  if (has_seed) pcg_seed(&g, seed, -1); /* gymnasium Env.reset(seed) -> np_random(seed) */
+  else rng_load(b->rng_env, N, i, &g);
+  if (env == NSG_ENV_FROZENLAKE) {
+    /* FrozenLakeEnv.reset: categorical_sample(initial_state_distrib) consumes one random();
+       the one-hot distribution always yields the S cell. */
+    double r = pcg_double(&g);
+    const uint8_t* desc = tables + cfg->desc_tab_off;
+    int nS = cfg->nrow * cfg->ncol, s0 = 0, found = 0;
+    double cs = 0;
+    for (int k = 0; k < nS; k++) {
+      cs += desc[k] == 'S' ? 1.0 : 0.0; /* exactly one S on the supported maps */
+      if (!found && cs > r) { s0 = k; found = 1; }
+    }
+    b->cell[i] = s0;
+    if (b->prob) b->prob[i] = 1.0f;
+  } else {
+    double s[4] = {0, 0, 0, 0};
+    env_reset_draw(env, &g, s);
+    for (int k = 0; k < PHYS_DIM[env]; k++) b->phys[k * N + i] = s[k];
+    env_obs(env, s, b->obs + i * OBS_DIM[env]);
+  }
+  rng_store(b->rng_env, N, i, &g);
+  b->t[i] = 0; /* base.py:379 */
+  int persistent = (cfg->flags & NSG_F_PERSISTENT_PARAMS) != 0;
+  for (int p = 0; p < P; p++) {
+    const nsg_param_cfg* pc = &cfg->params[p];
+    if (!persistent) { /* base.py:381-384 deepcopy(init_initial_params); classic_control.py:105-107 */
+      if (env == NSG_ENV_FROZENLAKE)
+        for (int k = 0; k < 3; k++) b->theta[k * N + i] = cfg->initial_prob[k]; /* toy_text.py:396;
+           table_prob is NOT restored: the wrapper's self.P survives reset (toy_text.py:365-367) */
+      else
+        b->theta[p * N + i] = cfg->base_theta[pc->theta_slot];
+      if (b->cursor) b->cursor[p * N + i] = 0;
+    }
+    if (pc->uses_rng && has_seed) { /* base.py:386-388,412-421: SeedSequence(seed).spawn(P)[j] */
+      pcg64 r;
+      pcg_seed(&r, seed, pc->rng_child);
+      rng_store(b->rng_upd + (int64_t)p * 4 * N, N, i, &r);
+    } /* no seed: streams continue (transplant, base.py:389-391) */
+    b->env_change[p * N + i] = 0;
+    b->delta_change[p * N + i] = 0.0f;
+  }
+  b->reward[i] = 0.0f;
+  b->terminated[i] = 0;
+  b->truncated[i] = 0;
+  b->status[i] = 0;
+  if (cfg->flags & NSG_F_TRACK_RETURNS) { b->ep_return[i] = 0.0f; b->ep_length[i] = 0; }
+}
+
+/* initial (pre-first-reset) streams of stochastic update fns: default_rng(fn_seed) */
+int orc_init_streams(const nsg_config* cfg, const nsg_buffers* b, int64_t N, const uint64_t* entropy) {
+  if (cfg->env_type == NSG_ENV_FROZENLAKE) /* __init__ builds P from initial_prob_dist (toy_text.py:337-340) */
+    for (int64_t i = 0; i < N; i++)
+      for (int k = 0; k < 3; k++) b->table_prob[k * N + i] = cfg->initial_prob[k];
+  for (int p = 0; p < cfg->n_params; p++) {
+    const nsg_param_cfg* pc = &cfg->params[p];
+    if (!pc->uses_rng) continue;
+    for (int64_t i = 0; i < N; i++) {
+      pcg64 r;
+      if (pc->has_fn_seed) pcg_seed(&r, pc->fn_seed, -1);
+      else pcg_seed(&r, entropy ? entropy[i] : (uint64_t)i, 1000 + p);
+      rng_store(b->rng_upd + (int64_t)p * 4 * N, N, i, &r);
+    }
+  }
+  return 0;
+}
+
+int orc_reset(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N,
+              const uint64_t* seeds, const uint8_t* mask) {
+  for (int64_t i = 0; i < N; i++) {
+    if (mask && !mask[i]) continue;
+    reset_one(cfg, tables, b, N, i, seeds != NULL, seeds ? seeds[i] : 0);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ wrapper-level step */
+static void frozenlake_move(const nsg_config* cfg, int row, int col, int a, int* nr, int* nc) {
+  /* toy_text.py:449-458 inc() */
+  if (a == 0) col = col - 1 > 0 ? col - 1 : 0;
+  else if (a == 1) row = row + 1 < cfg->nrow - 1 ? row + 1 : cfg->nrow - 1;
+  else if (a == 2) col = col + 1 < cfg->ncol - 1 ? col + 1 : cfg->ncol - 1;
+  else if (a == 3) row = row - 1 > 0 ? row - 1 : 0;
+  *nr = row; *nc = col;
+}
+
+static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N, int64_t i,
+                     const void* actions, uint32_t* cnt) {
+  int env = cfg->env_type, P = cfg->n_params;
+  if (b->status[i] & NSG_ST_NEEDS_RESET) { /* next-step autoreset == env.reset() with no seed */
+    reset_one(cfg, tables, b, N, i, 0, 0);
+    return;
+  }
+  int t = b->t[i];
+  double reward = 0;
+  int term = 0;
+  if (env == NSG_ENV_FROZENLAKE) {
+    /* toy_text.py:362-377 */
+    const nsg_param_cfg* pc = &cfg->params[0];
+    double p[3] = {b->theta[0 * N + i], b->theta[1 * N + i], b->theta[2 * N + i]}, q[3];
+    int fired = sched_fire(pc, tables, t);
+    double delta = 0.0;
+    if (fired) {
+      upd_dist(pc, tables, p, t, b->cursor ? &b->cursor[i] : NULL, q);
+      delta = w1_3(p, q); /* base.py:192-203 */
+      for (int k = 0; k < 3; k++) { b->theta[k * N + i] = q[k]; b->table_prob[k * N + i] = q[k]; }
+    } /* toy_text.py:365-366: the P table is rebuilt only on a fire */
+    for (int k = 0; k < 3; k++) p[k] = b->table_prob[k * N + i];
+    b->env_change[i] = (uint8_t)fired;
+    b->delta_change[i] = (float)delta;
+    if (fired) cnt[NSG_CNT_FIRED]++;
+    /* gymnasium FrozenLakeEnv.step over the NS table (toy_text.py:426-444) */
+    int a = ((const int32_t*)actions)[i];
+    int s = b->cell[i];
+    int row = s / cfg->ncol, col = s % cfg->ncol;
+    const uint8_t* desc = tables + cfg->desc_tab_off;
+    pcg64 g;
+    rng_load(b->rng_env, N, i, &g);
+    double r = pcg_double(&g);
+    rng_store(b->rng_env, N, i, &g);
+    uint8_t letter = desc[s];
+    double prob;
+    if (letter == 'G' || letter == 'H') { /* :435-436 single self-loop entry (1.0, s, 0, True) */
+      prob = 1.0; reward = 0; term = 1;
+      /* argmax(cumsum([1.0]) > r) == 0 either way */
+    } else {
+      double c0 = p[0], c1 = c0 + p[1], c2 = c1 + p[2];
+      int idx = c0 > r ? 0 : c1 > r ? 1 : c2 > r ? 2 : 0; /* argmax of all-False is 0 */
+      int dir = idx == 0 ? a : idx == 1 ? (a + 1) % 4 : (a + 3) % 4; /* [a, a+1, a-1] :438 */
+      int nr, nc;
+      frozenlake_move(cfg, row, col, dir, &nr, &nc);
+      int ns = nr * cfg->ncol + nc;
+      uint8_t nl = desc[ns];
+      term = nl == 'G' || nl == 'H';
+      reward = (cfg->flags & NSG_F_MODIFIED_REWARDS) ? cfg->letter_reward[letter_index(nl)] : (nl == 'G' ? 1.0 : 0.0);
+      prob = p[idx];
+      s = ns;
+    }
+    b->cell[i] = s;
+    if (b->prob) b->prob[i] = (float)prob;
+  } else {
+    int K = N_THETA[env];
+    double cur[NSG_MAX_THETA], nv[NSG_MAX_THETA];
+    for (int k = 0; k < K; k++) cur[k] = cfg->base_theta[k];
+    unsigned tuned = 0, firedmask = 0;
+    for (int p = 0; p < P; p++) cur[cfg->params[p].theta_slot] = b->theta[p * N + i];
+    for (int k = 0; k < K; k++) nv[k] = cur[k];
+    for (int p = 0; p < P; p++) { /* classic_control.py:80-85 */
+      const nsg_param_cfg* pc = &cfg->params[p];
+      int k = pc->theta_slot;
+      tuned |= 1u << k;
+      if (sched_fire(pc, tables, t)) {
+        pcg64 r;
+        if (pc->uses_rng) rng_load(b->rng_upd + (int64_t)p * 4 * N, N, i, &r);
+        nv[k] = upd_scalar(pc, tables, cur[k], t, pc->uses_rng ? &r : NULL, b->cursor ? &b->cursor[p * N + i] : NULL);
+        if (pc->uses_rng) rng_store(b->rng_upd + (int64_t)p * 4 * N, N, i, &r);
+        firedmask |= 1u << p;
+      }
+    }
+    unsigned viol = constraint_mask(env, nv, cur, tuned); /* :87 */
+    double th[NSG_MAX_THETA];
+    for (int k = 0; k < K; k++) th[k] = cur[k];
+    for (int p = 0; p < P; p++) { /* :87-92 */
+      int k = cfg->params[p].theta_slot;
+      int fired = (firedmask >> p) & 1;
+      double delta = fired ? nv[k] - cur[k] : 0.0; /* base.py:182 */
+      if ((viol >> k) & 1u) {
+        if (fired) cnt[NSG_CNT_VIOLATION]++;
+        fired = 0; delta = 0.0;
+      } else {
+        th[k] = nv[k];
+      }
+      b->theta[p * N + i] = th[k];
+      b->env_change[p * N + i] = (uint8_t)fired;
+      b->delta_change[p * N + i] = (float)delta;
+      if (fired) cnt[NSG_CNT_FIRED]++;
+    }
+    double s[4];
+    for (int k = 0; k < PHYS_DIM[env]; k++) s[k] = b->phys[k * N + i];
+    int ai = 0; float af = 0;
+    if (env == NSG_ENV_PENDULUM || env == NSG_ENV_MOUNTAINCAR_CONT) af = ((const float*)actions)[i];
+    else ai = ((const int32_t*)actions)[i];
+    term = env_step(env, th, s, ai, af, &reward);
+    for (int k = 0; k < PHYS_DIM[env]; k++) b->phys[k * N + i] = s[k];
+    env_obs(env, s, b->obs + i * OBS_DIM[env]);
+  }
+  t += 1; /* base.py:314 */
+  b->t[i] = t;
+  int trunc = cfg->max_episode_steps > 0 && t >= cfg->max_episode_steps; /* TimeLimit [UPSTREAM] */
+  b->reward[i] = (float)reward;
+  b->terminated[i] = (uint8_t)term;
+  b->truncated[i] = (uint8_t)trunc;
+  int done = term || trunc;
+  b->status[i] = done ? NSG_ST_NEEDS_RESET : 0;
+  if (cfg->flags & NSG_F_TRACK_RETURNS) {
+    float er = b->ep_return[i] + (float)reward;
+    int el = b->ep_length[i] + 1;
+    if (done) { b->last_return[i] = er; b->last_length[i] = el; er = 0.0f; el = 0; }
+    b->ep_return[i] = er; b->ep_length[i] = el;
+  }
+  if (done) {
+    if ((cfg->flags & NSG_F_COMPACT_DONE) && b->done_idx) b->done_idx[cnt[NSG_CNT_DONE]] = (int32_t)i;
+    cnt[NSG_CNT_DONE]++;
+    cnt[NSG_CNT_EPISODES]++;
+  }
+}
+
+int orc_step(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N, const void* actions) {
+  uint32_t* cnt = b->counters;
+  cnt[NSG_CNT_DONE] = cnt[NSG_CNT_FIRED] = cnt[NSG_CNT_VIOLATION] = 0;
+  for (int64_t i = 0; i < N; i++) step_one(cfg, tables, b, N, i, actions, cnt);
+  return 0;
+}
+
+/* range version for multi-threaded baselines (counters are per-call scratch of the caller) */
+int orc_step_range(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N, const void* actions,
+                   int64_t lo, int64_t hi, uint32_t* cnt) {
+  for (int64_t i = lo; i < hi; i++) step_one(cfg, tables, b, N, i, actions, cnt);
+  return 0;
+}
+
+/* θ-engine alone: mirrors nsg_theta_trace */
+int orc_theta_trace(const nsg_config* cfg, const uint8_t* tables, int p, int n, int t0, int T, const double* theta0,
+                    uint64_t* rng_state, double* theta_out, uint8_t* fired_out, double* delta_out) {
+  const nsg_param_cfg* pc = &cfg->params[p];
+  int dist = pc->upd_kind >= NSG_UPD_D_INCREMENT;
+  for (int i = 0; i < n; i++) {
+    pcg64 r;
+    if (pc->uses_rng && rng_state) rng_load(rng_state, n, i, &r);
+    int32_t cursor = 0;
+    double th[3] = {theta0[dist ? 3 * i : i], dist ? theta0[3 * i + 1] : 0, dist ? theta0[3 * i + 2] : 0};
+    for (int k = 0; k < T; k++) {
+      int t = t0 + k;
+      int fired = sched_fire(pc, tables, t);
+      double delta = 0.0;
+      if (fired) {
+        if (dist) {
+          double q[3];
+          upd_dist(pc, tables, th, t, &cursor, q);
+          delta = w1_3(th, q);
+          th[0] = q[0]; th[1] = q[1]; th[2] = q[2];
+        } else {
+          double nvv = upd_scalar(pc, tables, th[0], t, pc->uses_rng ? &r : NULL, &cursor);
+          delta = nvv - th[0];
+          th[0] = nvv;
+        }
+      }
+      if (dist) for (int c = 0; c < 3; c++) theta_out[((int64_t)k * 3 + c) * n + i] = th[c];
+      else theta_out[(int64_t)k * n + i] = th[0];
+      fired_out[(int64_t)k * n + i] = (uint8_t)fired;
+      delta_out[(int64_t)k * n + i] = delta;
+    }
+    if (pc->uses_rng && rng_state) rng_store(rng_state, n, i, &r);
+  }
+  return 0;
+}
+
+/* NumPy-compatible streams: mirrors nsg_rng_fill */
+int orc_rng_fill(int kind, const uint64_t* seeds, int n, int spawn_key, int count, void* out, uint64_t* state_out) {
+  for (int i = 0; i < n; i++) {
+    pcg64 r;
+    pcg_seed(&r, seeds[i], spawn_key);
+    if (state_out) rng_store(state_out, n, i, &r);
+    for (int k = 0; k < count; k++) {
+      if (kind == 0) ((uint64_t*)out)[(int64_t)k * n + i] = pcg_next64(&r);
+      else if (kind == 1) ((double*)out)[(int64_t)k * n + i] = pcg_double(&r);
+      else ((double*)out)[(int64_t)k * n + i] = pcg_std_normal(&r);
+    }
+  }
+  return 0;
+}
+
+size_t orc_sizeof_config(void) { return sizeof(nsg_config); }
+size_t orc_sizeof_buffers(void) { return sizeof(nsg_buffers); }

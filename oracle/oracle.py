@@ -1,0 +1,141 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes binding of oracle/libnsgym_oracle.so (the scalar C
+restatement of the reference's hot path, see nsgym_oracle.c).
+
+`OracleVecEnv` keeps N env instances in NumPy struct-of-arrays with exactly the data format
+of include/nsgym_hip.h so that tests compare the HIP library's device buffers with these
+arrays field by field.  It uses `ns_gym_amd.spec.compile_config` only as the config *format*
+encoder; no arithmetic of the product is involved.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from ns_gym_amd import _abi as A
+from ns_gym_amd.spec import compile_config
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libnsgym_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "nsgym_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_sizeof_config.restype = C.c_size_t
+        _lib.orc_sizeof_buffers.restype = C.c_size_t
+        assert _lib.orc_sizeof_config() == C.sizeof(A.Config)
+        assert _lib.orc_sizeof_buffers() == C.sizeof(A.Buffers)
+    return _lib
+
+
+_NP = {C.c_double: np.float64, C.c_int32: np.int32, C.c_uint8: np.uint8, C.c_uint64: np.uint64,
+       C.c_float: np.float32, C.c_uint32: np.uint32}
+
+PHYS_DIM = {A.ENV_CARTPOLE: 4, A.ENV_PENDULUM: 2, A.ENV_ACROBOT: 4, A.ENV_MOUNTAINCAR: 2,
+            A.ENV_MOUNTAINCAR_CONT: 2, A.ENV_FROZENLAKE: 0}
+OBS_DIM = {A.ENV_CARTPOLE: 4, A.ENV_PENDULUM: 3, A.ENV_ACROBOT: 6, A.ENV_MOUNTAINCAR: 2,
+           A.ENV_MOUNTAINCAR_CONT: 2, A.ENV_FROZENLAKE: 1}
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class OracleVecEnv:
+    def __init__(self, env, tunable_params, num_envs, **kwargs):
+        self.cfg, self.tables, self.spec, self.param_names = compile_config(env, tunable_params, **kwargs)
+        self.tab = np.frombuffer(self.tables, dtype=np.uint8).copy()
+        self.N = N = int(num_envs)
+        et = self.cfg.env_type
+        P = self.cfg.n_params
+        self.is_fl = et == A.ENV_FROZENLAKE
+        rows = 3 if self.is_fl else P
+        z = lambda shape, dt: np.zeros(shape, dtype=dt)  # noqa: E731
+        self.a = {
+            "phys": z((max(PHYS_DIM[et], 1), N), np.float64), "cell": z(N, np.int32),
+            "theta": z((max(rows, 1), N), np.float64), "table_prob": z((3, N), np.float64), "t": z(N, np.int32), "status": z(N, np.uint8),
+            "rng_env": z((4, N), np.uint64), "rng_upd": z((max(P, 1), 4, N), np.uint64),
+            "cursor": z((max(P, 1), N), np.int32), "obs": z((N, OBS_DIM[et]), np.float32),
+            "reward": z(N, np.float32), "terminated": z(N, np.uint8), "truncated": z(N, np.uint8),
+            "env_change": z((max(P, 1), N), np.uint8), "delta_change": z((max(P, 1), N), np.float32),
+            "prob": z(N, np.float32), "ep_return": z(N, np.float32), "ep_length": z(N, np.int32),
+            "last_return": z(N, np.float32), "last_length": z(N, np.int32),
+            "counters": z(A.CNT_COUNT, np.uint32), "done_idx": z(N, np.int32),
+        }
+        self.bufs = A.Buffers(**{k: _ptr(v) for k, v in self.a.items()})
+        lib().orc_init_streams(C.byref(self.cfg), C.byref(self.bufs), C.c_int64(N), None)
+        self.action_is_float = et in (A.ENV_PENDULUM, A.ENV_MOUNTAINCAR_CONT)
+
+    def reset(self, seed=None, mask=None):
+        seeds = None
+        if seed is not None:
+            seeds = (np.arange(self.N, dtype=np.uint64) + np.uint64(seed)) if np.isscalar(seed) \
+                else np.asarray(seed, dtype=np.uint64)
+            assert seeds.shape == (self.N,)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        lib().orc_reset(C.byref(self.cfg), _ptr(self.tab), C.byref(self.bufs), C.c_int64(self.N), _ptr(seeds), _ptr(m))
+        return self.a
+
+    def step(self, actions):
+        dt = np.float32 if self.action_is_float else np.int32
+        act = np.ascontiguousarray(actions, dtype=dt)
+        assert act.shape == (self.N,)
+        lib().orc_step(C.byref(self.cfg), _ptr(self.tab), C.byref(self.bufs), C.c_int64(self.N), _ptr(act))
+        return self.a
+
+    # convenience views -----------------------------------------------------------------
+    def state(self):
+        return self.a["cell"].copy() if self.is_fl else self.a["obs"].copy()
+
+    def theta(self):
+        return self.a["theta"].copy()
+
+
+def theta_trace(fn, theta0, t0=0, T=1, n=1, seeds=None):
+    """Oracle twin of ns_gym_amd.functional.theta_trace: drive one (scheduler, update fn)
+    pair for t = t0..t0+T-1 with θ fed back; returns (theta[T,...], fired[T,n], delta[T,n])."""
+    from ns_gym_amd.base import UpdateDistributionFn
+    from ns_gym_amd.envs import make
+
+    dist = isinstance(fn, UpdateDistributionFn)
+    env = make("FrozenLake-v1") if dist else make("CartPole-v1")
+    cfg, tables, _, _ = compile_config(env, {"P" if dist else "gravity": fn})
+    tab = np.frombuffer(tables, dtype=np.uint8).copy()
+    th0 = np.ascontiguousarray(np.broadcast_to(np.asarray(theta0, dtype=np.float64), (n, 3) if dist else (n,)))
+    rng = None
+    if cfg.params[0].uses_rng:
+        sd = np.asarray(seeds if seeds is not None else [cfg.params[0].fn_seed] * n, dtype=np.uint64)
+        rng = np.zeros((4, n), dtype=np.uint64)
+        scratch = np.zeros((1, n), dtype=np.uint64)
+        lib().orc_rng_fill(0, _ptr(sd), n, -1, 0, _ptr(scratch), _ptr(rng))
+    th = np.zeros((T, 3, n) if dist else (T, n), dtype=np.float64)
+    fired = np.zeros((T, n), dtype=np.uint8)
+    delta = np.zeros((T, n), dtype=np.float64)
+    lib().orc_theta_trace(C.byref(cfg), _ptr(tab), 0, n, int(t0), int(T), _ptr(th0), _ptr(rng), _ptr(th),
+                          _ptr(fired), _ptr(delta))
+    return th, fired, delta
+
+
+def rng_fill(kind, seeds, count, spawn_key=-1):
+    seeds = np.asarray(seeds, dtype=np.uint64)
+    n = seeds.size
+    out = np.zeros((count, n), dtype=np.uint64 if kind == 0 else np.float64)
+    st = np.zeros((4, n), dtype=np.uint64)
+    lib().orc_rng_fill(int(kind), _ptr(seeds), n, int(spawn_key), int(count), _ptr(out), _ptr(st))
+    return out, st

@@ -506,7 +506,7 @@ def main():
         print(name, "episodes:", int(rec["was_reset"].sum()), "fired:", int(rec["gt_env_change"].sum()))
     np.savez_compressed(os.path.join(HERE, "reset_semantics.npz"), **gen_reset_semantics(gym, S, U, CC))
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
-        json.dump(manifest, f, indent=1, sort_keys=True)
+        json.dump(manifest, f, indent=1)  # dict order is semantic (child-seed index)
     print("golden vectors written to", HERE)
 
 

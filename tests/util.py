@@ -1,0 +1,90 @@
+"""Shared helpers: golden-vector loading and the trajectory comparison used for BOTH the
+CPU oracle (not-gpu tests) and the HIP library (gpu tests)."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+with open(os.path.join(GOLDEN, "manifest.json")) as _f:
+    MANIFEST = json.load(_f)
+
+TRAJ_SPECS = MANIFEST["traj_specs"]
+
+STATE_ATOL = 1e-5      # north_star: float32 |Δ| < 1e-5 on classic-control state ...
+STATE_RTOL = 1e-5      # ... scaled by max(1,|x|): Acrobot velocities reach 9π where one f32 ulp is 2e-6
+THETA_RTOL = 1e-5      # θ / delta compared at 1e-5 rel
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def make_env_from_spec(factory, spec, n=None, seeds=None, **extra):
+    from ns_gym_amd.envs import make
+    from ns_gym_amd.spec import build_tunable_params
+
+    env = make(spec["env_id"], **spec.get("make_kwargs", {}))
+    tp = build_tunable_params(spec["params"])
+    n = n if n is not None else len(spec["seeds"])
+    return factory(env, tp, n, **spec["flags"], **spec.get("wrapper_kwargs", {}), **extra)
+
+
+def check_trajectory(view, spec, rec, T=None, strict_theta=False):
+    """`view` adapts an implementation: view.reset(seeds) / view.step(actions) return a dict of
+    NumPy arrays: state[N,D] (or [N] ints), reward[N], terminated[N], truncated[N],
+    env_change[P,N], delta_change[P,N] (ground truth), t[N], theta[rows,N]."""
+    seeds = np.asarray(spec["seeds"], dtype=np.uint64)
+    T = T or spec["T"]
+    is_fl = spec["env_id"] == "FrozenLake-v1"
+    out = view.reset(seeds)
+    _cmp(out, rec, 0, is_fl, None, strict_theta)
+    for k in range(T):
+        out = view.step(rec["actions"][k])
+        _cmp(out, rec, k + 1, is_fl, k, strict_theta)
+
+
+def _cmp(out, rec, k, is_fl, kk, strict_theta):
+    tag = f"step index {k}"
+    if is_fl:
+        np.testing.assert_array_equal(out["state"].reshape(-1), rec["state"][k, :, 0], err_msg=tag)
+    else:
+        np.testing.assert_allclose(out["state"], rec["state"][k], rtol=STATE_RTOL, atol=STATE_ATOL, err_msg=tag)
+    np.testing.assert_array_equal(out["t"], rec["relative_time"][k], err_msg=tag)
+    np.testing.assert_array_equal(out["env_change"].T, rec["gt_env_change"][k], err_msg=tag)
+    np.testing.assert_allclose(out["delta_change"].T, rec["gt_delta_change"][k], rtol=THETA_RTOL, atol=1e-7, err_msg=tag)
+    if strict_theta:
+        np.testing.assert_array_equal(out["theta"].T, rec["theta"][k], err_msg=tag)
+    else:
+        np.testing.assert_allclose(out["theta"].T, rec["theta"][k], rtol=THETA_RTOL, atol=1e-12, err_msg=tag)
+    if kk is not None:
+        np.testing.assert_allclose(out["reward"], rec["reward"][kk], rtol=1e-5, atol=1e-5, err_msg=tag)
+        np.testing.assert_array_equal(out["terminated"], rec["terminated"][kk], err_msg=tag)
+        np.testing.assert_array_equal(out["truncated"], rec["truncated"][kk], err_msg=tag)
+        if is_fl and "prob" in out:
+            np.testing.assert_allclose(out["prob"], rec["prob"][kk], rtol=1e-6, atol=0, err_msg=tag)
+
+
+class OracleView:
+    def __init__(self, env):
+        self.env = env
+
+    def _out(self):
+        a = self.env.a
+        e = self.env
+        return {
+            "state": a["cell"].copy() if e.is_fl else a["obs"].copy(),
+            "reward": a["reward"].copy(), "terminated": a["terminated"].copy(),
+            "truncated": a["truncated"].copy(), "env_change": a["env_change"][: e.cfg.n_params].copy(),
+            "delta_change": a["delta_change"][: e.cfg.n_params].copy(), "t": a["t"].copy(),
+            "theta": a["theta"].copy(), "prob": a["prob"].copy(),
+        }
+
+    def reset(self, seeds):
+        self.env.reset(seed=seeds)
+        return self._out()
+
+    def step(self, actions):
+        self.env.step(actions)
+        return self._out()
