@@ -578,7 +578,13 @@ static void reset_one(const nsg_config* cfg, const uint8_t* tables, const nsg_bu
 int orc_init_streams(const nsg_config* cfg, const nsg_buffers* b, int64_t N, const uint64_t* entropy) {
   if (cfg->env_type == NSG_ENV_FROZENLAKE) /* __init__ builds P from initial_prob_dist (toy_text.py:337-340) */
     for (int64_t i = 0; i < N; i++)
-      for (int k = 0; k < 3; k++) b->table_prob[k * N + i] = cfg->initial_prob[k];
+      for (int k = 0; k < 3; k++) b->table_prob[k * N + i] = b->theta[k * N + i] = cfg->initial_prob[k];
+  /* construction-time θ (what persistent_params keeps across resets) and fresh list cursors */
+  for (int p = 0; p < cfg->n_params; p++)
+    for (int64_t i = 0; i < N; i++) {
+      if (cfg->env_type != NSG_ENV_FROZENLAKE) b->theta[p * N + i] = cfg->base_theta[cfg->params[p].theta_slot];
+      if (b->cursor) b->cursor[p * N + i] = 0;
+    }
   for (int p = 0; p < cfg->n_params; p++) {
     const nsg_param_cfg* pc = &cfg->params[p];
     if (!pc->uses_rng) continue;
