@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — non-stationary env-steps/sec of the fused HIP stepper (BASELINE.json metric).
+
+A "step" is one pass of the hot path (one nsg_step launch) over one batch of N envs with
+synthetic random actions already resident in HBM.  Workload at every N_gpus: the C1/C5
+configuration of BASELINE.json — CartPole-v1 + masspole IncrementUpdate(+0.1) via
+ContinuousScheduler — at 2^20 envs PER GPU (weak scaling; 8 GPUs = C5's 8,388,608 envs).
+Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL); envs are sharded by
+contiguous index with no per-step collective; the only exchange is one all-gather of the
+per-env episode returns at rollout end, inside the timed region.
+
+Prints ONE JSON line on rank 0 (see the task contract) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PER_GPU = 1 << 20
+BYTES_PER_ENV_STEP = 120       # C1/C5, fp64 internal state
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(n_envs, steps, threads):
+    """The oracle (C port of the reference path) on the host cores: bounded sample of the same
+    workload.  Test infrastructure used only as the reported CPU baseline."""
+    import numpy as np
+
+    from ns_gym_amd import make
+    from ns_gym_amd.schedulers import ContinuousScheduler
+    from ns_gym_amd.update_functions import IncrementUpdate
+    from oracle.oracle import OracleVecEnv
+
+    env = OracleVecEnv(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)}, n_envs,
+                       change_notification=True, delta_change_notification=True, track_returns=True)
+    env.reset(seed=0)
+    acts = np.random.default_rng(123).integers(2, size=(8, n_envs)).astype(np.int32)
+    for k in range(3):
+        env.step_mt(acts[k % 8], threads)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        env.step_mt(acts[k % 8], threads)
+    dt = time.perf_counter() - t0
+    return n_envs * steps / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs-per-gpu", type=int, default=N_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from ns_gym_amd import make
+    from ns_gym_amd.distributed import all_gather_returns
+    from ns_gym_amd.schedulers import ContinuousScheduler
+    from ns_gym_amd.update_functions import IncrementUpdate
+    from ns_gym_amd.vec_env import VecNSEnv
+
+    n = args.envs_per_gpu
+    env = VecNSEnv(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)}, n,
+                   change_notification=True, delta_change_notification=True, track_returns=True, device=dev)
+    # env i of the whole job is seeded base_seed + global index: results do not depend on the sharding
+    env.reset(seed=torch.arange(rank * n, (rank + 1) * n, dtype=torch.int64).numpy().astype("uint64"))
+    g = torch.Generator(device=dev)
+    g.manual_seed(123 + rank)
+    pool = [torch.randint(0, 2, (n,), dtype=torch.int32, device=dev, generator=g) for _ in range(8)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for k in range(args.warmup):
+        env.step(pool[k % 8])
+    if dist is not None:
+        all_gather_returns(env)  # warm the RCCL communicator
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)   # HIP events on the stream the kernels are enqueued on
+    e1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for k in range(args.steps):
+        env.step(pool[k % 8])
+    e1.record()
+    gathered = all_gather_returns(env) if dist is not None else env.episode_returns()[0]
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = e0.elapsed_time(e1) / args.steps   # average launch duration incl. back-to-back gap
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+    total_env_steps = float(n) * world * args.steps
+    value = total_env_steps / dt_max
+
+    if rank == 0:
+        achieved = BYTES_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "non-stationary env-steps/sec",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "CartPole-v1 + masspole IncrementUpdate(+0.1)/ContinuousScheduler (BASELINE C1/C5 config), "
+                            f"{n} envs per GPU, random actions, next-step autoreset, episode returns tracked",
+                "envs_per_gpu": n, "total_envs": n * world,
+                "parallelism": f"env-sharded x{world}, no per-step collective; 1 all-gather of episode returns at rollout end"
+                               if world > 1 else "single GPU",
+                "episodes_finished_rank0": env.counters()["episodes"],
+                "gathered_returns": int(gathered.numel()),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(),
+                "kernel": "nsg::step_kernel<CARTPOLE>", "avg_launch_us": kern_ms * 1e3,
+                "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
+            },
+        }
+        if not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            cpu_baseline(1 << 14, 8, threads)  # warm the OpenMP pool / page in the oracle
+            # bounded sample of the same workload: 2^18 envs x 40 steps (scaled down from 2^20 x K)
+            v, secs = cpu_baseline(1 << 18, 40, threads)
+            if secs < 5.0:  # fast host: lengthen the sample towards ~10 s of CPU work
+                reps = min(int(10.0 / max(secs, 1e-3)), 20)
+                v, secs = cpu_baseline(1 << 18, 40 * max(reps, 1), threads)
+            out["cpu_baseline"] = {
+                "value": v, "unit": "env-steps/s", "cores": threads, "kind": "port",
+                "sample": f"oracle C port (OpenMP), 262144 envs, same config, {secs:.1f} s wall",
+            }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("step_kernel_cartpole_bytes_per_launch")
+    except Exception:
+        return None
+
+
+if __name__ == "__main__":
+    main()

@@ -100,19 +100,21 @@ enum {
 #define NSG_F_PERSISTENT_PARAMS 0x4u
 #define NSG_F_TRACK_RETURNS 0x8u   /* keep per-env episode return / length accumulators   */
 #define NSG_F_MODIFIED_REWARDS 0x10u /* FrozenLake modified_rewards (toy_text.py:465-468)  */
-#define NSG_F_COMPACT_DONE 0x20u   /* wave-ballot compaction of done env indices          */
 
 /* per-env status byte (buffers.status) */
 #define NSG_ST_NEEDS_RESET 0x1u
 
-/* device-side counters (uint32 each), index into buffers.counters */
+/* device-side counters: uint64 running totals, sharded to keep atomics off one address.
+ * buffers.counters is [NSG_CNT_COUNT][NSG_CNT_SHARDS]; a total is the sum over its shards.
+ * Produced by wavefront ballots + popcounts, reduced per workgroup in LDS. */
 enum {
-  NSG_CNT_DONE = 0,       /* envs that finished an episode in the last step            */
-  NSG_CNT_FIRED = 1,      /* (env,param) updates applied in the last step              */
-  NSG_CNT_VIOLATION = 2,  /* (env,param) updates rejected by the constraint checker    */
-  NSG_CNT_EPISODES = 3,   /* running total of finished episodes                        */
-  NSG_CNT_COUNT = 8
+  NSG_CNT_DONE = 0,       /* episodes finished (terminated or truncated)                */
+  NSG_CNT_FIRED = 1,      /* (env,param) updates applied (notification flags raised)    */
+  NSG_CNT_VIOLATION = 2,  /* (env,param) updates rejected by the constraint checker     */
+  NSG_CNT_STEPS = 3,      /* env transitions executed (autoreset lanes excluded)        */
+  NSG_CNT_COUNT = 4
 };
+#define NSG_CNT_SHARDS 64
 
 /* One tunable parameter = (Scheduler, UpdateFn) pair: UpdateFn.__call__ (ns_gym/base.py:124-149). */
 typedef struct nsg_param_cfg {
@@ -179,8 +181,9 @@ typedef struct nsg_buffers {
   int32_t* ep_length;    /* [N]    running episode length                                 */
   float* last_return;    /* [N]    return of the last finished episode                    */
   int32_t* last_length;  /* [N]                                                           */
-  uint32_t* counters;    /* [NSG_CNT_COUNT]                                               */
-  int32_t* done_idx;     /* [N]    compacted indices of envs done this step (NSG_F_COMPACT_DONE) */
+  uint64_t* counters;    /* [NSG_CNT_COUNT][NSG_CNT_SHARDS] running totals                */
+  uint64_t* done_bits;   /* [ceil(N/64)] wavefront ballot of "episode ended this step":
+                            bit l of word w = env 64*w + l   (input of nsg_compact_done)   */
 } nsg_buffers;
 
 /* element counts the caller must allocate for each nsg_buffers member (0 = not needed) */
@@ -190,7 +193,7 @@ typedef struct nsg_layout {
   int32_t n_actions;           /* discrete action count, 0 for continuous                  */
   int64_t phys, cell, theta, table_prob, t, status, rng_env, rng_upd, cursor, obs, reward, terminated,
       truncated, env_change, delta_change, prob, ep_return, ep_length, last_return, last_length,
-      counters, done_idx;
+      counters, done_bits;
 } nsg_layout;
 
 typedef struct nsg_handle nsg_handle;
@@ -259,6 +262,10 @@ int nsg_theta_trace(nsg_handle* h, int32_t p, int32_t n, int32_t t0, int32_t T, 
  * out [count][n].  state_out [4][n] may be NULL. */
 int nsg_rng_fill(int32_t kind, const uint64_t* seeds_dev, int32_t n, int32_t spawn_key, int32_t count,
                  void* out_dev, uint64_t* state_out_dev, void* stream);
+
+/* Done-mask compaction: expands the ballot words of the last step into a dense list of env
+ * indices (order unspecified).  idx_out_dev: int32[N], count_out_dev: uint64[1] (zeroed here). */
+int nsg_compact_done(nsg_handle* h, int32_t* idx_out_dev, uint64_t* count_out_dev, void* stream);
 
 /* Timing helper: average device time (ms) of `iters` back-to-back nsg_step launches measured
  * with hipEvents on `stream` (synchronises; not for use inside graph capture). */

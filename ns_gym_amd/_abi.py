@@ -28,12 +28,12 @@ F_DELTA_NOTIFICATION = 0x2
 F_PERSISTENT_PARAMS = 0x4
 F_TRACK_RETURNS = 0x8
 F_MODIFIED_REWARDS = 0x10
-F_COMPACT_DONE = 0x20
 
 ST_NEEDS_RESET = 0x1
 
-CNT_DONE, CNT_FIRED, CNT_VIOLATION, CNT_EPISODES = 0, 1, 2, 3
-CNT_COUNT = 8
+CNT_DONE, CNT_FIRED, CNT_VIOLATION, CNT_STEPS = 0, 1, 2, 3
+CNT_COUNT = 4
+CNT_SHARDS = 64
 
 
 class ParamCfg(C.Structure):
@@ -82,7 +82,7 @@ BUFFER_FIELDS = [
     ("obs", C.c_float), ("reward", C.c_float), ("terminated", C.c_uint8), ("truncated", C.c_uint8),
     ("env_change", C.c_uint8), ("delta_change", C.c_float), ("prob", C.c_float),
     ("ep_return", C.c_float), ("ep_length", C.c_int32), ("last_return", C.c_float),
-    ("last_length", C.c_int32), ("counters", C.c_uint32), ("done_idx", C.c_int32),
+    ("last_length", C.c_int32), ("counters", C.c_uint64), ("done_bits", C.c_uint64),
 ]
 
 

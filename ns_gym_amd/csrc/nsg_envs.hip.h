@@ -1,0 +1,227 @@
+// nsg_envs.hip.h — per-env-type transition dynamics, reset draws, observations and the
+// wrapper's constraint checker, in device code.
+//
+// Base MDPs: gymnasium 1.2.1 [UPSTREAM, uv.lock:958-959 — not in the reference tree]; the
+// reference calls them at ns_gym/base.py:313 (step) and :377 (reset).  The CartPole block is
+// corroborated in-tree by rats-experiments/code/envs/nscartpole_v0.py:24-36,92-108.
+// Constraint checker and dependency resolver: ns_gym/wrappers/classic_control.py:193-458.
+//
+// Everything is float64 in the reference's operation order (obs cast to float32 at the end,
+// like gymnasium); θ arrives as a fixed-size register array indexed only by compile-time
+// constants (slot order = ATTRIBUTE_MAP, ns_gym/base.py:611-635).
+#pragma once
+#include "../../include/nsgym_hip.h"
+#include "nsg_rng.hip.h"
+
+namespace nsg {
+
+#define NSG_PI 3.141592653589793238462643383279502884
+
+template <int ENV> struct EnvTraits;
+template <> struct EnvTraits<NSG_ENV_CARTPOLE> { static constexpr int PHYS = 4, OBS = 4, NTHETA = 6; static constexpr bool FLOAT_ACT = false; };
+template <> struct EnvTraits<NSG_ENV_PENDULUM> { static constexpr int PHYS = 2, OBS = 3, NTHETA = 4; static constexpr bool FLOAT_ACT = true; };
+template <> struct EnvTraits<NSG_ENV_ACROBOT> { static constexpr int PHYS = 4, OBS = 6, NTHETA = 8; static constexpr bool FLOAT_ACT = false; };
+template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR> { static constexpr int PHYS = 2, OBS = 2, NTHETA = 2; static constexpr bool FLOAT_ACT = false; };
+template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR_CONT> { static constexpr int PHYS = 2, OBS = 2, NTHETA = 1; static constexpr bool FLOAT_ACT = true; };
+
+// ---- reset draws: np_random.uniform(low, high) = low + (high - low) * next_double ----------
+template <int ENV> __device__ __forceinline__ void env_reset_draw(Pcg& g, double* s) {
+  if constexpr (ENV == NSG_ENV_CARTPOLE) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) s[k] = -0.05 + (0.05 - -0.05) * pcg_double(g);
+  } else if constexpr (ENV == NSG_ENV_PENDULUM) {
+    s[0] = -NSG_PI + (NSG_PI - -NSG_PI) * pcg_double(g);
+    s[1] = -1.0 + (1.0 - -1.0) * pcg_double(g);
+  } else if constexpr (ENV == NSG_ENV_ACROBOT) {  // .astype(np.float32) upstream
+#pragma unroll
+    for (int k = 0; k < 4; k++) s[k] = (double)(float)(-0.1 + (0.1 - -0.1) * pcg_double(g));
+  } else {  // MountainCar / MountainCarContinuous: [uniform(-0.6, -0.4), 0]
+    s[0] = -0.6 + (-0.4 - -0.6) * pcg_double(g);
+    s[1] = 0.0;
+  }
+}
+
+// ---- observation (float32, like gymnasium's _get_obs) -------------------------------------
+template <int ENV> __device__ __forceinline__ void env_obs(const double* s, float* o) {
+  if constexpr (ENV == NSG_ENV_CARTPOLE) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = (float)s[k];
+  } else if constexpr (ENV == NSG_ENV_PENDULUM) {
+    double sn, cs;
+    sincos(s[0], &sn, &cs);
+    o[0] = (float)cs; o[1] = (float)sn; o[2] = (float)s[1];
+  } else if constexpr (ENV == NSG_ENV_ACROBOT) {
+    double s0, c0, s1, c1;
+    sincos(s[0], &s0, &c0);
+    sincos(s[1], &s1, &c1);
+    o[0] = (float)c0; o[1] = (float)s0; o[2] = (float)c1; o[3] = (float)s1; o[4] = (float)s[2]; o[5] = (float)s[3];
+  } else {
+    o[0] = (float)s[0]; o[1] = (float)s[1];
+  }
+}
+
+// ---- constraint checker (classic_control.py:193-422) --------------------------------------
+// nv: proposed value per θ slot, cur: pre-update attribute, tuned: bit mask of slots that are
+// in tunable_params (wave-uniform).  Returns the bit mask of rejected slots.
+template <int ENV> __device__ __forceinline__ unsigned constraint_mask(const double* nv, const double* cur, unsigned tuned) {
+  unsigned v = 0;
+  if constexpr (ENV == NSG_ENV_CARTPOLE) {  // gravity masscart masspole force_mag tau length
+    if ((tuned & 1u) && nv[0] < 0) v |= 1u;
+    if ((tuned & 2u) && nv[1] <= 0) v |= 2u;
+    if ((tuned & 4u) && nv[2] <= 0) v |= 4u;
+    if ((tuned & 32u) && nv[5] <= 0) v |= 32u;
+  } else if constexpr (ENV == NSG_ENV_PENDULUM) {  // m l dt g
+    if ((tuned & 1u) && nv[0] <= 0) v |= 1u;
+    if ((tuned & 2u) && nv[1] <= 0) v |= 2u;
+    if ((tuned & 4u) && nv[2] <= 0) v |= 4u;
+    if ((tuned & 8u) && nv[3] < 0) v |= 8u;
+  } else if constexpr (ENV == NSG_ENV_ACROBOT) {  // dt L1 L2 M1 M2 C1 C2 MOI
+    if (tuned & 2u) {
+      if (nv[1] <= 0) v |= 2u;
+      else if ((tuned & 32u) && nv[5] > nv[1]) v |= 2u;
+      else if (nv[1] < cur[5]) v |= 2u;
+    }
+    if ((tuned & 4u) && nv[2] <= 0) v |= 4u;  // the COM cross-checks of LINK_LENGTH_2 are dead code (:267)
+    if ((tuned & 8u) && nv[3] <= 0) v |= 8u;
+    if ((tuned & 16u) && nv[4] <= 0) v |= 16u;
+    if (tuned & 32u) {
+      if (nv[5] <= 0) v |= 32u;
+      else if ((tuned & 2u) && nv[1] < nv[5]) v |= 32u;
+      else if (nv[5] > cur[1]) v |= 32u;
+    }
+    if (tuned & 64u) {
+      if (nv[6] <= 0) v |= 64u;
+      else if ((tuned & 4u) && nv[2] < nv[6]) v |= 64u;
+      else if (nv[6] > cur[2]) v |= 64u;
+    }
+  } else if constexpr (ENV == NSG_ENV_MOUNTAINCAR) {  // gravity force
+    if ((tuned & 1u) && nv[0] <= 0) v |= 1u;
+    if ((tuned & 2u) && nv[1] <= 0) v |= 2u;
+  } else {  // power
+    if ((tuned & 1u) && nv[0] <= 0) v |= 1u;
+  }
+  return v;
+}
+
+// ---- transitions ----------------------------------------------------------------------------
+__device__ __forceinline__ void acrobot_dsdt(const double* th, const double* y, double a, double* d) {
+  const double m1 = th[3], m2 = th[4], l1 = th[1], lc1 = th[5], lc2 = th[6], I1 = th[7], I2 = th[7], g = 9.8;
+  const double theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
+  double sin2, cos2;
+  sincos(theta2, &sin2, &cos2);
+  double d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * cos2) + I1 + I2;
+  double d2 = m2 * (lc2 * lc2 + l1 * lc2 * cos2) + I2;
+  double phi2 = m2 * lc2 * g * cos(theta1 + theta2 - NSG_PI / 2.0);
+  double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * sin2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * sin2 +
+                (m1 * lc1 + m2 * l1) * g * cos(theta1 - NSG_PI / 2) + phi2;
+  double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * sin2 - phi2) /
+                    (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+  double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
+  d[0] = dtheta1; d[1] = dtheta2; d[2] = ddtheta1; d[3] = ddtheta2;
+}
+
+// Advances s in place with parameters th (post-update θ), returns terminated, writes reward.
+template <int ENV>
+__device__ __forceinline__ bool env_step(const double* th, double* s, int ai, float af, double& reward) {
+  if constexpr (ENV == NSG_ENV_CARTPOLE) {
+    const double gravity = th[0], masscart = th[1], masspole = th[2], force_mag = th[3], tau = th[4], length = th[5];
+    const double total_mass = masspole + masscart;     // _dependency_resolver, classic_control.py:426-435
+    const double polemass_length = length * masspole;  // :436-444
+    double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
+    double force = ai == 1 ? force_mag : -force_mag;
+    double sintheta, costheta;
+    sincos(theta, &sintheta, &costheta);
+    double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
+    double thetaacc = (gravity * sintheta - costheta * temp) /
+                      (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
+    double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+    x = x + tau * x_dot;
+    x_dot = x_dot + tau * xacc;
+    theta = theta + tau * theta_dot;
+    theta_dot = theta_dot + tau * thetaacc;
+    s[0] = x; s[1] = x_dot; s[2] = theta; s[3] = theta_dot;
+    const double thr = 12 * 2 * NSG_PI / 360;
+    reward = 1.0;
+    return x < -2.4 || x > 2.4 || theta < -thr || theta > thr;
+  } else if constexpr (ENV == NSG_ENV_PENDULUM) {
+    const double m = th[0], l = th[1], dt = th[2], g = th[3];
+    double t0 = s[0], thdot = s[1];
+    double u = (double)af;
+    if (u < -2.0) u = -2.0;
+    if (u > 2.0) u = 2.0;
+    double r = fmod(t0 + NSG_PI, 2 * NSG_PI);  // Python float %: result takes the divisor's sign
+    if (r != 0 && r < 0) r += 2 * NSG_PI;
+    double an = r - NSG_PI;
+    double costs = an * an + 0.1 * (thdot * thdot) + 0.001 * (u * u);
+    double newthdot = thdot + (3 * g / (2 * l) * sin(t0) + 3.0 / (m * (l * l)) * u) * dt;
+    if (newthdot < -8.0) newthdot = -8.0;
+    if (newthdot > 8.0) newthdot = 8.0;
+    double newth = t0 + newthdot * dt;
+    s[0] = newth; s[1] = newthdot;
+    reward = -costs;
+    return false;
+  } else if constexpr (ENV == NSG_ENV_ACROBOT) {
+    const double a = (double)(ai - 1);  // AVAIL_TORQUE = [-1, 0, +1]
+    const double dt = th[0] - 0.0, dt2 = dt / 2.0;
+    double y0[4] = {s[0], s[1], s[2], s[3]}, k1[4], k2[4], k3[4], k4[4], y[4];
+    acrobot_dsdt(th, y0, a, k1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) y[k] = y0[k] + dt2 * k1[k];
+    acrobot_dsdt(th, y, a, k2);   // the torque component has derivative 0.0: a + dt2 * 0.0 == a
+#pragma unroll
+    for (int k = 0; k < 4; k++) y[k] = y0[k] + dt2 * k2[k];
+    acrobot_dsdt(th, y, a, k3);
+#pragma unroll
+    for (int k = 0; k < 4; k++) y[k] = y0[k] + dt * k3[k];
+    acrobot_dsdt(th, y, a, k4);
+    double ns[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) ns[k] = y0[k] + dt / 6.0 * (k1[k] + 2 * k2[k] + 2 * k3[k] + k4[k]);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {  // wrap(x, -pi, pi): bounded trip count (|dθ| <= 9π per 0.2 s step)
+      const double diff = NSG_PI - -NSG_PI;
+      for (int it = 0; it < 64 && ns[k] > NSG_PI; it++) ns[k] = ns[k] - diff;
+      for (int it = 0; it < 64 && ns[k] < -NSG_PI; it++) ns[k] = ns[k] + diff;
+    }
+    const double mv1 = 4 * NSG_PI, mv2 = 9 * NSG_PI;
+    ns[2] = fmin(fmax(ns[2], -mv1), mv1);
+    ns[3] = fmin(fmax(ns[3], -mv2), mv2);
+#pragma unroll
+    for (int k = 0; k < 4; k++) s[k] = ns[k];
+    bool term = (-cos(s[0]) - cos(s[1] + s[0])) > 1.0;
+    reward = term ? 0.0 : -1.0;
+    return term;
+  } else if constexpr (ENV == NSG_ENV_MOUNTAINCAR) {
+    double position = s[0], velocity = s[1];
+    velocity += (double)(ai - 1) * th[1] + cos(3 * position) * (-th[0]);
+    if (velocity < -0.07) velocity = -0.07;
+    if (velocity > 0.07) velocity = 0.07;
+    position += velocity;
+    if (position < -1.2) position = -1.2;
+    if (position > 0.6) position = 0.6;
+    if (position == -1.2 && velocity < 0) velocity = 0;
+    s[0] = position; s[1] = velocity;
+    reward = -1.0;
+    return position >= 0.5 && velocity >= 0;
+  } else {  // MountainCarContinuous
+    double position = s[0], velocity = s[1];
+    double a0 = (double)af;
+    double force = fmin(fmax(a0, -1.0), 1.0);
+    velocity += force * th[0] - 0.0025 * cos(3 * position);
+    if (velocity > 0.07) velocity = 0.07;
+    if (velocity < -0.07) velocity = -0.07;
+    position += velocity;
+    if (position > 0.6) position = 0.6;
+    if (position < -1.2) position = -1.2;
+    if (position == -1.2 && velocity < 0) velocity = 0;
+    bool term = position >= 0.45 && velocity >= 0;
+    double r = 0;
+    if (term) r = 100.0;
+    r -= (a0 * a0) * 0.1;
+    s[0] = (double)(float)position; s[1] = (double)(float)velocity;  // state stored as float32 upstream
+    reward = r;
+    return term;
+  }
+}
+
+}  // namespace nsg

@@ -1,0 +1,647 @@
+// nsg_kernels.hip.h — the fused struct-of-arrays kernels (gfx950 / CDNA4, wave64).
+//
+// One launch = one wrapper step for every env instance:
+//   θ-schedule (schedulers + update fns)  ->  constraint checker  ->  dependency resolver
+//   ->  base-MDP transition  ->  t += 1 / TimeLimit  ->  notification ground truth  ->
+//   autoreset bookkeeping  ->  wave-ballot done mask + block-reduced counters,
+// i.e. NSClassicControlWrapper.step (ns_gym/wrappers/classic_control.py:60-100) /
+// NSFrozenLakeWrapper.step (ns_gym/wrappers/toy_text.py:342-380) -> NSWrapper.step
+// (ns_gym/base.py:296-363) -> gymnasium step, for N envs at once.
+//
+// Mapping: one env per lane, 256-thread workgroups (4 wavefronts), grid-stride over 256-env
+// chunks.  Every per-env array is SoA ([field][N]) so a wavefront's access to a field is one
+// contiguous 256/512-byte run.  The path is HBM-bound elementwise work: no MFMA, no
+// inter-workgroup communication; constant tables (ziggurat, bit/value tables, FrozenLake
+// map) are staged in LDS once per workgroup.  Workgroups touch disjoint env ranges, so the
+// blockIdx -> XCD mapping has no L2-sharing consequence and is left as dispatched.
+#pragma once
+#include "../../include/nsgym_hip.h"
+#include "nsg_envs.hip.h"
+#include "nsg_rng.hip.h"
+#include "nsg_theta.hip.h"
+
+namespace nsg {
+
+constexpr int kBlock = 256;
+constexpr int kMaxTableBytes = 16384;
+constexpr int kCntShards = NSG_CNT_SHARDS;
+
+// Device-resident description of one homogeneous env segment (read through scalar loads).
+struct Segment {
+  nsg_config cfg;
+  nsg_buffers buf;
+  int64_t N;
+  const uint8_t* tables;   // constant-table blob (global copy)
+  const uint64_t* zig;     // ki[256] | wi[256] | fi[256] (global copy)
+  int32_t table_bytes;
+  int32_t uses_normal;     // some update fn draws normals -> stage the ziggurat tables
+  int32_t block_begin;     // first block of this segment in a heterogeneous launch
+  int32_t block_count;
+};
+
+struct ActionPtrs {
+  const void* p[NSG_MAX_SEGMENTS];
+};
+
+struct LdsTables {
+  uint64_t zig[768];
+  uint64_t blob[kMaxTableBytes / 8];
+  unsigned cnt[NSG_CNT_COUNT];
+};
+
+// Cooperative staging of the constant tables into LDS (once per workgroup).
+__device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, Tables& tb, ZigLds& zg) {
+  const int tid = threadIdx.x;
+  if (sg.uses_normal) {
+    for (int k = tid; k < 768; k += kBlock) lds.zig[k] = sg.zig[k];
+  }
+  const int words = (sg.table_bytes + 7) >> 3;
+  const uint64_t* src = (const uint64_t*)sg.tables;
+  for (int k = tid; k < words; k += kBlock) lds.blob[k] = src[k];
+  if (tid < NSG_CNT_COUNT) lds.cnt[tid] = 0;
+  __syncthreads();
+  tb.base = (const uint8_t*)lds.blob;
+  zg.ki = lds.zig;
+  zg.wi = (const double*)(lds.zig + 256);
+  zg.fi = (const double*)(lds.zig + 512);
+}
+
+// Where one step's per-env outputs go: the handle's own buffers (nsg_step) or the k-th slice of
+// a trajectory (nsg_rollout).  Wave-uniform, lives in SGPRs.
+struct StepOut {
+  float* obs;
+  float* reward;
+  uint8_t* terminated;
+  uint8_t* truncated;
+  uint8_t* env_change;
+  float* delta_change;
+};
+__device__ __forceinline__ StepOut default_out(const nsg_buffers& b) {
+  return StepOut{b.obs, b.reward, b.terminated, b.truncated, b.env_change, b.delta_change};
+}
+
+// Per-wave running counts (lane-uniform), flushed once per workgroup.
+struct WaveCounts {
+  unsigned done = 0, fired = 0, viol = 0, steps = 0;
+};
+
+__device__ __forceinline__ void flush_counts(const Segment& sg, LdsTables& lds, const WaveCounts& wc) {
+  if ((threadIdx.x & 63) == 0) {
+    if (wc.done) atomicAdd(&lds.cnt[NSG_CNT_DONE], wc.done);
+    if (wc.fired) atomicAdd(&lds.cnt[NSG_CNT_FIRED], wc.fired);
+    if (wc.viol) atomicAdd(&lds.cnt[NSG_CNT_VIOLATION], wc.viol);
+    if (wc.steps) atomicAdd(&lds.cnt[NSG_CNT_STEPS], wc.steps);
+  }
+  __syncthreads();
+  if (threadIdx.x < NSG_CNT_COUNT && sg.buf.counters) {
+    unsigned v = lds.cnt[threadIdx.x];
+    if (v) atomicAdd((unsigned long long*)&sg.buf.counters[threadIdx.x * kCntShards + (blockIdx.x % kCntShards)],
+                     (unsigned long long)v);
+  }
+}
+
+template <int N_> struct Unroll {
+  template <typename F> static __device__ __forceinline__ void run(F&& f) {
+    Unroll<N_ - 1>::run(f);
+    f(N_ - 1);
+  }
+};
+template <> struct Unroll<0> {
+  template <typename F> static __device__ __forceinline__ void run(F&&) {}
+};
+
+template <int ENV> __device__ __forceinline__ void store_obs(float* __restrict__ obs, int64_t i, const float* o) {
+  if constexpr (ENV == NSG_ENV_CARTPOLE) {
+    reinterpret_cast<float4*>(obs)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  } else if constexpr (ENV == NSG_ENV_PENDULUM) {
+    obs[3 * i + 0] = o[0]; obs[3 * i + 1] = o[1]; obs[3 * i + 2] = o[2];
+  } else if constexpr (ENV == NSG_ENV_ACROBOT) {
+    float2* q = reinterpret_cast<float2*>(obs) + 3 * i;
+    q[0] = make_float2(o[0], o[1]); q[1] = make_float2(o[2], o[3]); q[2] = make_float2(o[4], o[5]);
+  } else {
+    reinterpret_cast<float2*>(obs)[i] = make_float2(o[0], o[1]);
+  }
+}
+
+// ============================================================================================
+// classic-control step for env i (one lane).  `active` = i < N; inactive lanes only take part
+// in the ballots.
+// ============================================================================================
+template <int ENV>
+__device__ __forceinline__ void step_classic(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
+                                             const StepOut& out, int64_t i, bool active, WaveCounts& wc) {
+  using T = EnvTraits<ENV>;
+  const nsg_config& cfg = sg.cfg;
+  const nsg_buffers& b = sg.buf;
+  const int64_t N = sg.N;
+  const int P = cfg.n_params;
+  const bool persistent = (cfg.flags & NSG_F_PERSISTENT_PARAMS) != 0;
+
+  const unsigned st = active ? b.status[i] : 0u;
+  const int t = active ? b.t[i] : 0;
+  const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);  // next-step autoreset == reset(seed=None)
+  const bool do_step = active && !do_reset;
+
+  double s[T::PHYS];
+#pragma unroll
+  for (int k = 0; k < T::PHYS; k++) s[k] = do_step ? b.phys[(int64_t)k * N + i] : 0.0;
+  int ai = 0;
+  float af = 0.f;
+  if (do_step) {
+    if constexpr (T::FLOAT_ACT) af = ((const float*)actions)[i];
+    else ai = ((const int32_t*)actions)[i];
+  }
+
+  // ---- pass 1: every update fn proposes a value (classic_control.py:80-85) -----------------
+  double cur[T::NTHETA], nv[T::NTHETA];
+#pragma unroll
+  for (int k = 0; k < T::NTHETA; k++) cur[k] = nv[k] = cfg.base_theta[k];
+  unsigned tuned = 0, firedmask = 0;
+  for (int p = 0; p < P; p++) {
+    const nsg_param_cfg& pc = cfg.params[p];
+    const int slot = pc.theta_slot;
+    double c = active ? b.theta[(int64_t)p * N + i] : cfg.base_theta[slot];
+    double n = c;
+    const bool fire = do_step && sched_fire(pc, tb, t);
+    if (fire) {
+      Pcg r = {0, 0, 0, 0};
+      int cursor = 0;
+      const bool has_cur = upd_uses_cursor(pc.upd_kind);
+      if (pc.uses_rng) pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
+      if (has_cur) cursor = b.cursor[(int64_t)p * N + i];
+      n = upd_scalar(pc, tb, zg, c, t, r, cursor);
+      if (pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
+      if (has_cur) b.cursor[(int64_t)p * N + i] = cursor;
+      firedmask |= 1u << p;
+    }
+    Unroll<T::NTHETA>::run([&](int k) {
+      if (k == slot) { cur[k] = c; nv[k] = n; }
+    });
+    tuned |= 1u << slot;
+  }
+
+  // ---- constraint checker on all proposals at once (classic_control.py:87, 193-422) --------
+  const unsigned viol = constraint_mask<ENV>(nv, cur, tuned);
+
+  // ---- pass 2: commit / reject, notification ground truth (classic_control.py:87-92) -------
+  double th[T::NTHETA];
+#pragma unroll
+  for (int k = 0; k < T::NTHETA; k++) th[k] = cur[k];
+  unsigned n_fired = 0, n_viol = 0;
+  for (int p = 0; p < P; p++) {
+    const nsg_param_cfg& pc = cfg.params[p];
+    const int slot = pc.theta_slot;
+    double c = 0.0, n = 0.0;
+    Unroll<T::NTHETA>::run([&](int k) {
+      if (k == slot) { c = cur[k]; n = nv[k]; }
+    });
+    bool fired = (firedmask >> p) & 1u;
+    const bool rejected = (viol >> slot) & 1u;
+    double delta = fired ? n - c : 0.0;  // UpdateFn._get_delta_change, base.py:182
+    double fin = rejected ? c : n;
+    if (rejected) {
+      n_viol += fired ? 1u : 0u;
+      fired = false;
+      delta = 0.0;
+    }
+    if (do_reset) {  // base.py:381-384 + classic_control.py:105-107; streams continue (base.py:389-391)
+      fin = persistent ? c : cfg.base_theta[slot];
+      if (!persistent && upd_uses_cursor(pc.upd_kind)) b.cursor[(int64_t)p * N + i] = 0;
+    }
+    Unroll<T::NTHETA>::run([&](int k) {
+      if (k == slot) th[k] = fin;
+    });
+    if (active) {
+      if (fin != c) b.theta[(int64_t)p * N + i] = fin;
+      out.env_change[(int64_t)p * N + i] = fired ? 1 : 0;
+      out.delta_change[(int64_t)p * N + i] = (float)delta;
+    }
+    n_fired += fired ? 1u : 0u;
+  }
+
+  // ---- base MDP transition with the updated θ (base.py:313) or the reset draw (base.py:377) --
+  double reward = 0.0;
+  bool term = false, trunc = false;
+  int tnew = 0;
+  if (do_reset) {
+    Pcg g;
+    pcg_load(b.rng_env, N, i, g);
+    env_reset_draw<ENV>(g, s);
+    pcg_store_state(b.rng_env, N, i, g);
+  } else if (do_step) {
+    term = env_step<ENV>(th, s, ai, af, reward);
+    tnew = t + 1;                                                      // base.py:314
+    trunc = cfg.max_episode_steps > 0 && tnew >= cfg.max_episode_steps;  // TimeLimit [UPSTREAM]
+  }
+  const bool done = term || trunc;
+
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < T::PHYS; k++) b.phys[(int64_t)k * N + i] = s[k];
+    float o[T::OBS];
+    env_obs<ENV>(s, o);
+    store_obs<ENV>(out.obs, i, o);
+    b.t[i] = tnew;
+    out.reward[i] = (float)reward;
+    out.terminated[i] = term ? 1 : 0;
+    out.truncated[i] = trunc ? 1 : 0;
+    b.status[i] = done ? NSG_ST_NEEDS_RESET : 0;
+    if (cfg.flags & NSG_F_TRACK_RETURNS) {
+      float er = do_reset ? 0.f : b.ep_return[i] + (float)reward;
+      int el = do_reset ? 0 : b.ep_length[i] + 1;
+      if (done) {
+        b.last_return[i] = er;
+        b.last_length[i] = el;
+        er = 0.f;
+        el = 0;
+      }
+      b.ep_return[i] = er;
+      b.ep_length[i] = el;
+    }
+  }
+
+  // ---- wavefront ballot: done mask word + counters -----------------------------------------
+  const unsigned long long done_mask = __ballot(done);
+  if (b.done_bits && (threadIdx.x & 63) == 0 && i < N) b.done_bits[i >> 6] = done_mask;
+  wc.done += __popcll(done_mask);
+  wc.steps += __popcll(__ballot(do_step));
+  // per-lane small integers: sum across the wave with a ballot per bit
+  for (unsigned bit = 0; bit < 4; bit++) {
+    wc.fired += __popcll(__ballot((n_fired >> bit) & 1u)) << bit;
+    wc.viol += __popcll(__ballot((n_viol >> bit) & 1u)) << bit;
+  }
+}
+
+// ============================================================================================
+// FrozenLake step for env i (integer / categorical path, bit-exact).
+// ============================================================================================
+__device__ __forceinline__ void step_frozenlake(const Segment& sg, const Tables& tb, const void* actions, const StepOut& out,
+                                                int64_t i, bool active, WaveCounts& wc) {
+  const nsg_config& cfg = sg.cfg;
+  const nsg_buffers& b = sg.buf;
+  const int64_t N = sg.N;
+  const nsg_param_cfg& pc = cfg.params[0];
+  const bool persistent = (cfg.flags & NSG_F_PERSISTENT_PARAMS) != 0;
+  const uint8_t* desc = tb.base + cfg.desc_tab_off;
+
+  const unsigned st = active ? b.status[i] : 0u;
+  const int t = active ? b.t[i] : 0;
+  const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);
+  const bool do_step = active && !do_reset;
+
+  int cell = do_step ? b.cell[i] : 0;
+  const int a = do_step ? ((const int32_t*)actions)[i] : 0;
+  Pcg g = {0, 0, 0, 0};
+  if (active) pcg_load(b.rng_env, N, i, g);
+  // both paths consume exactly one random(): FrozenLakeEnv.step's categorical_sample and
+  // FrozenLakeEnv.reset's categorical_sample over the one-hot initial_state_distrib
+  const double r = active ? pcg_double(g) : 0.0;
+  if (active) pcg_store_state(b.rng_env, N, i, g);
+
+  bool fired = false;
+  double delta = 0.0, reward = 0.0, prob = 1.0;
+  bool term = false, trunc = false;
+  int tnew = 0;
+  if (do_step) {
+    fired = sched_fire(pc, tb, t);
+    double p0, p1, p2;
+    if (fired) {  // toy_text.py:362-366
+      double p[3] = {b.theta[0 * N + i], b.theta[1 * N + i], b.theta[2 * N + i]}, q[3];
+      int cursor = 0;
+      const bool has_cur = upd_uses_cursor(pc.upd_kind);
+      if (has_cur) cursor = b.cursor[i];
+      upd_dist(pc, tb, p, t, cursor, q);
+      if (has_cur) b.cursor[i] = cursor;
+      delta = w1_3(p, q);  // base.py:192-203
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        b.theta[(int64_t)k * N + i] = q[k];
+        b.table_prob[(int64_t)k * N + i] = q[k];  // _update_transition_prob_table(): P rebuilt on a fire only
+      }
+      p0 = q[0]; p1 = q[1]; p2 = q[2];
+    } else {
+      p0 = b.table_prob[0 * N + i]; p1 = b.table_prob[1 * N + i]; p2 = b.table_prob[2 * N + i];
+    }
+    // gymnasium FrozenLakeEnv.step over the wrapper's P table (toy_text.py:426-469)
+    const int letter = desc[cell];
+    if (letter == 'G' || letter == 'H') {  // single self-loop entry (1.0, s, 0, True), :435-436
+      prob = 1.0; reward = 0.0; term = true;
+    } else {
+      const double c0 = p0, c1 = c0 + p1, c2 = c1 + p2;               // np.cumsum
+      const int idx = c0 > r ? 0 : c1 > r ? 1 : c2 > r ? 2 : 0;        // np.argmax(cs > r); all-False -> 0
+      const int dir = idx == 0 ? a : idx == 1 ? ((a + 1) & 3) : ((a + 3) & 3);  // [a, a+1, a-1], :438
+      int row = cell / cfg.ncol, col = cell - row * cfg.ncol;
+      if (dir == 0) col = col - 1 > 0 ? col - 1 : 0;                    // inc(), :449-458
+      else if (dir == 1) row = row + 1 < cfg.nrow - 1 ? row + 1 : cfg.nrow - 1;
+      else if (dir == 2) col = col + 1 < cfg.ncol - 1 ? col + 1 : cfg.ncol - 1;
+      else row = row - 1 > 0 ? row - 1 : 0;
+      cell = row * cfg.ncol + col;
+      const int nl = desc[cell];
+      term = nl == 'G' || nl == 'H';
+      if (cfg.flags & NSG_F_MODIFIED_REWARDS) reward = cfg.letter_reward[nl == 'S' ? 0 : nl == 'F' ? 1 : nl == 'H' ? 2 : 3];
+      else reward = nl == 'G' ? 1.0 : 0.0;
+      prob = idx == 0 ? p0 : idx == 1 ? p1 : p2;
+    }
+    tnew = t + 1;
+    trunc = cfg.max_episode_steps > 0 && tnew >= cfg.max_episode_steps;
+  } else if (do_reset) {
+    // start cell: argmax(cumsum(one-hot S) > r)
+    const int nS = cfg.nrow * cfg.ncol;
+    int s0 = 0;
+    for (int k = 0; k < nS; k++)
+      if (desc[k] == 'S') { s0 = k; break; }
+    cell = 1.0 > r ? s0 : 0;
+    if (!persistent) {  // toy_text.py:394-399; the P table itself is NOT restored (see nsgym_hip.h)
+#pragma unroll
+      for (int k = 0; k < 3; k++) b.theta[(int64_t)k * N + i] = cfg.initial_prob[k];
+      if (upd_uses_cursor(pc.upd_kind)) b.cursor[i] = 0;
+    }
+  }
+  const bool done = term || trunc;
+  if (active) {
+    b.cell[i] = cell;
+    if (out.obs) ((int32_t*)out.obs)[i] = cell;  // trajectory slice (rollout); NULL for nsg_step: cell[] is the obs
+    b.t[i] = tnew;
+    out.reward[i] = (float)reward;
+    out.terminated[i] = term ? 1 : 0;
+    out.truncated[i] = trunc ? 1 : 0;
+    b.status[i] = done ? NSG_ST_NEEDS_RESET : 0;
+    out.env_change[i] = fired ? 1 : 0;
+    out.delta_change[i] = (float)delta;
+    if (b.prob) b.prob[i] = (float)prob;
+    if (cfg.flags & NSG_F_TRACK_RETURNS) {
+      float er = do_reset ? 0.f : b.ep_return[i] + (float)reward;
+      int el = do_reset ? 0 : b.ep_length[i] + 1;
+      if (done) {
+        b.last_return[i] = er;
+        b.last_length[i] = el;
+        er = 0.f;
+        el = 0;
+      }
+      b.ep_return[i] = er;
+      b.ep_length[i] = el;
+    }
+  }
+  const unsigned long long done_mask = __ballot(done);
+  if (b.done_bits && (threadIdx.x & 63) == 0 && i < N) b.done_bits[i >> 6] = done_mask;
+  wc.done += __popcll(done_mask);
+  wc.steps += __popcll(__ballot(do_step));
+  wc.fired += __popcll(__ballot(fired));
+}
+
+template <int ENV>
+__device__ __forceinline__ void step_any(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
+                                         const StepOut& out, int64_t i, bool active, WaveCounts& wc) {
+  if constexpr (ENV == NSG_ENV_FROZENLAKE) step_frozenlake(sg, tb, actions, out, i, active, wc);
+  else step_classic<ENV>(sg, tb, zg, actions, out, i, active, wc);
+}
+
+// Homogeneous launch: grid-stride over 256-env chunks.
+template <int ENV>
+__global__ __launch_bounds__(kBlock) void step_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions) {
+  __shared__ LdsTables lds;
+  const Segment& sg = *seg;
+  Tables tb;
+  ZigLds zg;
+  stage_tables(sg, lds, tb, zg);
+  WaveCounts wc;
+  const StepOut out = default_out(sg.buf);
+  const int64_t chunks = (sg.N + kBlock - 1) / kBlock;
+  for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const int64_t i = c * kBlock + threadIdx.x;
+    step_any<ENV>(sg, tb, zg, actions, out, i, i < sg.N, wc);
+  }
+  flush_counts(sg, lds, wc);
+}
+
+// Heterogeneous launch: block ranges are assigned to env-type segments, so the env-type switch
+// is uniform per workgroup (no intra-wave divergence between Pendulum and Acrobot lanes).
+__global__ __launch_bounds__(kBlock) void step_group_kernel(const Segment* __restrict__ segs, int nseg, ActionPtrs acts) {
+  __shared__ LdsTables lds;
+  int sidx = 0;
+  for (int k = 1; k < nseg; k++)
+    if ((int)blockIdx.x >= segs[k].block_begin) sidx = k;
+  const Segment& sg = segs[sidx];
+  Tables tb;
+  ZigLds zg;
+  stage_tables(sg, lds, tb, zg);
+  WaveCounts wc;
+  const int64_t chunks = (sg.N + kBlock - 1) / kBlock;
+  const void* actions = acts.p[sidx];
+  const StepOut out = default_out(sg.buf);
+  for (int64_t c = (int)blockIdx.x - sg.block_begin; c < chunks; c += sg.block_count) {
+    const int64_t i = c * kBlock + threadIdx.x;
+    const bool active = i < sg.N;
+    switch (sg.cfg.env_type) {
+      case NSG_ENV_CARTPOLE: step_any<NSG_ENV_CARTPOLE>(sg, tb, zg, actions, out, i, active, wc); break;
+      case NSG_ENV_PENDULUM: step_any<NSG_ENV_PENDULUM>(sg, tb, zg, actions, out, i, active, wc); break;
+      case NSG_ENV_ACROBOT: step_any<NSG_ENV_ACROBOT>(sg, tb, zg, actions, out, i, active, wc); break;
+      case NSG_ENV_MOUNTAINCAR: step_any<NSG_ENV_MOUNTAINCAR>(sg, tb, zg, actions, out, i, active, wc); break;
+      case NSG_ENV_MOUNTAINCAR_CONT: step_any<NSG_ENV_MOUNTAINCAR_CONT>(sg, tb, zg, actions, out, i, active, wc); break;
+      default: step_any<NSG_ENV_FROZENLAKE>(sg, tb, zg, actions, out, i, active, wc); break;
+    }
+  }
+  flush_counts(sg, lds, wc);
+}
+
+// ============================================================================================
+// reset(seed) / reset(): NSWrapper.reset + subclass tails (base.py:365-431,
+// classic_control.py:102-109, toy_text.py:382-399).
+// ============================================================================================
+template <int ENV>
+__global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict__ seg, const uint64_t* __restrict__ seeds,
+                                                       const uint8_t* __restrict__ mask) {
+  const Segment& sg = *seg;
+  const nsg_config& cfg = sg.cfg;
+  const nsg_buffers& b = sg.buf;
+  const int64_t N = sg.N;
+  const int P = cfg.n_params;
+  const bool persistent = (cfg.flags & NSG_F_PERSISTENT_PARAMS) != 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
+    if (mask && !mask[i]) continue;
+    Pcg g;
+    if (seeds) pcg_seed(g, seeds[i], -1);  // gymnasium Env.reset(seed) -> np_random(seed) [UPSTREAM]
+    else pcg_load(b.rng_env, N, i, g);
+    if constexpr (ENV == NSG_ENV_FROZENLAKE) {
+      const uint8_t* desc = sg.tables + cfg.desc_tab_off;
+      const double r = pcg_double(g);
+      int s0 = 0;
+      for (int k = 0; k < cfg.nrow * cfg.ncol; k++)
+        if (desc[k] == 'S') { s0 = k; break; }
+      b.cell[i] = 1.0 > r ? s0 : 0;
+      if (b.prob) b.prob[i] = 1.0f;
+    } else {
+      using T = EnvTraits<ENV>;
+      double s[T::PHYS];
+      env_reset_draw<ENV>(g, s);
+#pragma unroll
+      for (int k = 0; k < T::PHYS; k++) b.phys[(int64_t)k * N + i] = s[k];
+      float o[T::OBS];
+      env_obs<ENV>(s, o);
+      store_obs<ENV>(b.obs, i, o);
+    }
+    pcg_store_all(b.rng_env, N, i, g);
+    b.t[i] = 0;
+    for (int p = 0; p < P; p++) {
+      const nsg_param_cfg& pc = cfg.params[p];
+      if (!persistent) {
+        if constexpr (ENV == NSG_ENV_FROZENLAKE) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) b.theta[(int64_t)k * N + i] = cfg.initial_prob[k];
+        } else {
+          b.theta[(int64_t)p * N + i] = cfg.base_theta[pc.theta_slot];
+        }
+        if (b.cursor) b.cursor[(int64_t)p * N + i] = 0;
+      }
+      if (pc.uses_rng && seeds) {  // SeedSequence(seed).spawn(P)[rng_child], base.py:412-421
+        Pcg r;
+        pcg_seed(r, seeds[i], pc.rng_child);
+        pcg_store_all(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
+      }
+      b.env_change[(int64_t)p * N + i] = 0;
+      b.delta_change[(int64_t)p * N + i] = 0.f;
+    }
+    b.reward[i] = 0.f;
+    b.terminated[i] = 0;
+    b.truncated[i] = 0;
+    b.status[i] = 0;
+    if (cfg.flags & NSG_F_TRACK_RETURNS) {
+      b.ep_return[i] = 0.f;
+      b.ep_length[i] = 0;
+    }
+    if (b.done_bits && (i & 63) == 0) b.done_bits[i >> 6] = 0;
+  }
+}
+
+// Construction-time state (what the wrapper constructors set up): θ = construction values,
+// fresh cursors, FrozenLake P table from initial_prob_dist, update-fn streams
+// default_rng(fn.seed) (single_param.py:76,108,146,342,444), zeroed outputs / counters.
+__global__ __launch_bounds__(kBlock) void init_kernel(const Segment* __restrict__ seg) {
+  const Segment& sg = *seg;
+  const nsg_config& cfg = sg.cfg;
+  const nsg_buffers& b = sg.buf;
+  const int64_t N = sg.N;
+  const bool fl = cfg.env_type == NSG_ENV_FROZENLAKE;
+  if (blockIdx.x == 0 && b.counters)
+    for (int k = threadIdx.x; k < NSG_CNT_COUNT * kCntShards; k += kBlock) b.counters[k] = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
+    if (fl) {
+      for (int k = 0; k < 3; k++) b.theta[(int64_t)k * N + i] = b.table_prob[(int64_t)k * N + i] = cfg.initial_prob[k];
+      b.cell[i] = 0;
+      if (b.prob) b.prob[i] = 1.f;
+    }
+    for (int p = 0; p < cfg.n_params; p++) {
+      const nsg_param_cfg& pc = cfg.params[p];
+      if (!fl) b.theta[(int64_t)p * N + i] = cfg.base_theta[pc.theta_slot];
+      if (b.cursor) b.cursor[(int64_t)p * N + i] = 0;
+      if (pc.uses_rng) {
+        Pcg r;
+        if (pc.has_fn_seed) pcg_seed(r, pc.fn_seed, -1);
+        else pcg_seed(r, (uint64_t)i, 1000 + p);  // reference: OS entropy; here a fixed per-env stream
+        pcg_store_all(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
+      }
+      b.env_change[(int64_t)p * N + i] = 0;
+      b.delta_change[(int64_t)p * N + i] = 0.f;
+    }
+    Pcg g;
+    pcg_seed(g, (uint64_t)i, 999);
+    pcg_store_all(b.rng_env, N, i, g);
+    b.t[i] = 0;
+    b.status[i] = 0;
+    b.reward[i] = 0.f;
+    b.terminated[i] = 0;
+    b.truncated[i] = 0;
+    if (cfg.flags & NSG_F_TRACK_RETURNS) {
+      b.ep_return[i] = 0.f; b.ep_length[i] = 0; b.last_return[i] = 0.f; b.last_length[i] = 0;
+    }
+    if (b.done_bits && (i & 63) == 0) b.done_bits[i >> 6] = 0;
+  }
+}
+
+// ============================================================================================
+// done-mask compaction: ballot words -> dense list of env indices (wave prefix via mbcnt).
+// ============================================================================================
+__global__ __launch_bounds__(kBlock) void compact_done_kernel(const uint64_t* __restrict__ done_bits, int64_t N,
+                                                              int32_t* __restrict__ out_idx,
+                                                              unsigned long long* __restrict__ out_count) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ((N + 63) & ~63LL); i += (int64_t)gridDim.x * kBlock) {
+    const unsigned long long m = done_bits[i >> 6];  // wave-uniform load
+    if (m == 0) continue;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(out_count, (unsigned long long)__popcll(m));
+    base = __shfl(base, 0);
+    if ((m >> lane) & 1ULL) {
+      const int rank = __popcll(m & ((1ULL << lane) - 1ULL));
+      out_idx[base + rank] = (int32_t)i;
+    }
+  }
+}
+
+// ============================================================================================
+// θ-engine alone and raw NumPy-compatible streams (known-answer tests through the C-ABI).
+// ============================================================================================
+__global__ __launch_bounds__(kBlock) void theta_trace_kernel(const Segment* __restrict__ seg, int p, int n, int t0, int T,
+                                                             const double* __restrict__ theta0, uint64_t* rng_state,
+                                                             double* __restrict__ theta_out, uint8_t* __restrict__ fired_out,
+                                                             double* __restrict__ delta_out) {
+  __shared__ LdsTables lds;
+  const Segment& sg = *seg;
+  Tables tb;
+  ZigLds zg;
+  stage_tables(sg, lds, tb, zg);
+  const nsg_param_cfg& pc = sg.cfg.params[p];
+  const bool dist = pc.upd_kind >= NSG_UPD_D_INCREMENT;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  Pcg r = {0, 0, 0, 0};
+  if (pc.uses_rng && rng_state) pcg_load(rng_state, n, i, r);
+  int cursor = 0;
+  double th[3] = {theta0[dist ? 3 * i : i], dist ? theta0[3 * i + 1] : 0.0, dist ? theta0[3 * i + 2] : 0.0};
+  for (int k = 0; k < T; k++) {
+    const int t = t0 + k;
+    const bool fired = sched_fire(pc, tb, t);
+    double delta = 0.0;
+    if (fired) {
+      if (dist) {
+        double q[3];
+        upd_dist(pc, tb, th, t, cursor, q);
+        delta = w1_3(th, q);
+        th[0] = q[0]; th[1] = q[1]; th[2] = q[2];
+      } else {
+        double nvv = upd_scalar(pc, tb, zg, th[0], t, r, cursor);
+        delta = nvv - th[0];
+        th[0] = nvv;
+      }
+    }
+    if (dist) {
+      for (int c = 0; c < 3; c++) theta_out[((int64_t)k * 3 + c) * n + i] = th[c];
+    } else {
+      theta_out[(int64_t)k * n + i] = th[0];
+    }
+    fired_out[(int64_t)k * n + i] = fired ? 1 : 0;
+    delta_out[(int64_t)k * n + i] = delta;
+  }
+  if (pc.uses_rng && rng_state) pcg_store_all(rng_state, n, i, r);
+}
+
+__global__ __launch_bounds__(kBlock) void rng_fill_kernel(int kind, const uint64_t* __restrict__ seeds, int n, int spawn_key,
+                                                          int count, void* out, uint64_t* state_out,
+                                                          const uint64_t* __restrict__ zig) {
+  __shared__ uint64_t lz[768];
+  for (int k = threadIdx.x; k < 768; k += kBlock) lz[k] = zig[k];
+  __syncthreads();
+  ZigLds zg = {lz, (const double*)(lz + 256), (const double*)(lz + 512)};
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  Pcg r;
+  pcg_seed(r, seeds[i], spawn_key);
+  if (state_out) pcg_store_all(state_out, n, i, r);
+  for (int k = 0; k < count; k++) {
+    if (kind == 0) ((uint64_t*)out)[(int64_t)k * n + i] = pcg_next64(r);
+    else if (kind == 1) ((double*)out)[(int64_t)k * n + i] = pcg_double(r);
+    else ((double*)out)[(int64_t)k * n + i] = pcg_std_normal(r, zg);
+  }
+}
+
+}  // namespace nsg

@@ -1,0 +1,159 @@
+// nsg_rng.hip.h — NumPy-compatible bit streams on gfx950 (device code).
+//
+// The reference draws every random number through NumPy: env.np_random (gymnasium seeding,
+// called at ns_gym/base.py:377) and one `np.random.default_rng` per stochastic update fn
+// (ns_gym/update_functions/single_param.py:76,108,146,342,444), re-seeded by
+// SeedSequence(seed).spawn(n) in NSWrapper._seed_update_fns (ns_gym/base.py:412-421).
+// Seed-matched trajectory parity therefore needs NumPy's exact algorithms [UPSTREAM numpy,
+// uv.lock:1868-1869]: SeedSequence hash-mix -> PCG64 (128-bit LCG, XSL-RR output) ->
+// next_double = (u64 >> 11) * 2^-53 -> 256-layer ziggurat normal.
+//
+// Layout: a stream is 4 x u64 per env, struct-of-arrays [4][N]:
+//   row 0 state_hi, row 1 state_lo, row 2 inc_hi, row 3 inc_lo   (coalesced 8-byte lanes).
+// The ziggurat tables (6 KiB) are staged in LDS once per workgroup: lookups are per-lane
+// random indices, which LDS serves at full rate and HBM/L2 would not.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nsg {
+
+struct Pcg {
+  uint64_t sh, sl, ih, il;
+};
+
+__device__ __forceinline__ void pcg_step(Pcg& r) {
+  // state = state * 0x2360ED051FC65DA44385DF649FCCF645 + inc  (mod 2^128), 64-bit limbs
+  const uint64_t MH = 2549297995355413924ULL, ML = 4865540595714422341ULL;
+  uint64_t lo = r.sl * ML;
+  uint64_t hi = __umul64hi(r.sl, ML) + r.sh * ML + r.sl * MH;
+  uint64_t lo2 = lo + r.il;
+  uint64_t carry = lo2 < lo ? 1ULL : 0ULL;
+  r.sl = lo2;
+  r.sh = hi + r.ih + carry;
+}
+
+__device__ __forceinline__ uint64_t pcg_next64(Pcg& r) {
+  pcg_step(r);
+  uint64_t x = r.sh ^ r.sl;
+  unsigned rot = (unsigned)(r.sh >> 58);
+  return (x >> rot) | (x << ((64u - rot) & 63u));
+}
+
+__device__ __forceinline__ double pcg_double(Pcg& r) {
+  return (double)(pcg_next64(r) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ---- SeedSequence(entropy=seed, spawn_key=(child,) or ()).generate_state(4, uint64) ----
+__device__ __forceinline__ uint32_t ss_hashmix(uint32_t v, uint32_t& hc) {
+  v ^= hc;
+  hc *= 0x931e8875u;
+  v *= hc;
+  v ^= v >> 16;
+  return v;
+}
+__device__ __forceinline__ uint32_t ss_mix(uint32_t x, uint32_t y) {
+  uint32_t r = 0xca01f9ddu * x - 0x4973f715u * y;
+  r ^= r >> 16;
+  return r;
+}
+
+// Seeds PCG64 exactly like np.random.PCG64(SeedSequence(seed[, spawn_key=(child,)])).
+__device__ inline void pcg_seed(Pcg& r, uint64_t seed, int child) {
+  uint32_t e0 = (uint32_t)seed, e1 = (uint32_t)(seed >> 32);
+  // entropy words; with a spawn key the entropy is zero-padded to the pool size (4) first
+  uint32_t p0, p1, p2, p3, hc = 0x43b0d7e5u;
+  p0 = ss_hashmix(e0, hc);
+  p1 = ss_hashmix(e1, hc);  // e1 == 0 when seed < 2^32: identical to "word absent"
+  p2 = ss_hashmix(0u, hc);
+  p3 = ss_hashmix(0u, hc);
+  // mix all bits together so late bits can affect earlier bits (src-major order)
+  p1 = ss_mix(p1, ss_hashmix(p0, hc)); p2 = ss_mix(p2, ss_hashmix(p0, hc)); p3 = ss_mix(p3, ss_hashmix(p0, hc));
+  p0 = ss_mix(p0, ss_hashmix(p1, hc)); p2 = ss_mix(p2, ss_hashmix(p1, hc)); p3 = ss_mix(p3, ss_hashmix(p1, hc));
+  p0 = ss_mix(p0, ss_hashmix(p2, hc)); p1 = ss_mix(p1, ss_hashmix(p2, hc)); p3 = ss_mix(p3, ss_hashmix(p2, hc));
+  p0 = ss_mix(p0, ss_hashmix(p3, hc)); p1 = ss_mix(p1, ss_hashmix(p3, hc)); p2 = ss_mix(p2, ss_hashmix(p3, hc));
+  if (child >= 0) {  // fifth entropy word = the spawn key
+    uint32_t k = (uint32_t)child;
+    p0 = ss_mix(p0, ss_hashmix(k, hc));
+    p1 = ss_mix(p1, ss_hashmix(k, hc));
+    p2 = ss_mix(p2, ss_hashmix(k, hc));
+    p3 = ss_mix(p3, ss_hashmix(k, hc));
+  }
+  uint32_t hb = 0x8b51f9ddu, w[8];
+  const uint32_t pool[4] = {p0, p1, p2, p3};
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint32_t v = pool[i & 3];
+    v ^= hb;
+    hb *= 0x58f38dedu;
+    v *= hb;
+    v ^= v >> 16;
+    w[i] = v;
+  }
+  uint64_t s_hi = (uint64_t)w[0] | ((uint64_t)w[1] << 32), s_lo = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+  uint64_t q_hi = (uint64_t)w[4] | ((uint64_t)w[5] << 32), q_lo = (uint64_t)w[6] | ((uint64_t)w[7] << 32);
+  // pcg64_srandom_r: state = 0; inc = (initseq << 1) | 1; step; state += initstate; step
+  r.ih = (q_hi << 1) | (q_lo >> 63);
+  r.il = (q_lo << 1) | 1ULL;
+  r.sh = 0;
+  r.sl = 0;
+  pcg_step(r);
+  uint64_t lo = r.sl + s_lo;
+  r.sh = r.sh + s_hi + (lo < r.sl ? 1ULL : 0ULL);
+  r.sl = lo;
+  pcg_step(r);
+}
+
+__device__ __forceinline__ void pcg_load(const uint64_t* __restrict__ base, int64_t N, int64_t i, Pcg& r) {
+  r.sh = base[0 * N + i];
+  r.sl = base[1 * N + i];
+  r.ih = base[2 * N + i];
+  r.il = base[3 * N + i];
+}
+__device__ __forceinline__ void pcg_store_state(uint64_t* __restrict__ base, int64_t N, int64_t i, const Pcg& r) {
+  base[0 * N + i] = r.sh;  // the increment never changes after seeding
+  base[1 * N + i] = r.sl;
+}
+__device__ __forceinline__ void pcg_store_all(uint64_t* __restrict__ base, int64_t N, int64_t i, const Pcg& r) {
+  base[0 * N + i] = r.sh;
+  base[1 * N + i] = r.sl;
+  base[2 * N + i] = r.ih;
+  base[3 * N + i] = r.il;
+}
+
+// ---- ziggurat normal (numpy random_standard_normal), tables in LDS --------------------
+struct ZigLds {
+  const uint64_t* ki;
+  const double* wi;
+  const double* fi;
+};
+
+__device__ inline double pcg_std_normal(Pcg& g, const ZigLds& z) {
+  const double ZR = 3.6541528853610087963519472518, ZINV = 0.27366123732975827203338247596;
+  for (;;) {
+    uint64_t r = pcg_next64(g);
+    int idx = (int)(r & 0xff);
+    r >>= 8;
+    int sign = (int)(r & 1);
+    uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+    double x = (double)rabs * z.wi[idx];
+    if (sign) x = -x;
+    if (rabs < z.ki[idx]) return x;  // 99.3 % of draws
+    if (idx == 0) {
+      for (;;) {
+        double xx = -ZINV * log1p(-pcg_double(g));
+        double yy = -log1p(-pcg_double(g));
+        if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? -(ZR + xx) : ZR + xx;
+      }
+    } else {
+      double f1 = z.fi[idx - 1], f0 = z.fi[idx];
+      if ((f1 - f0) * pcg_double(g) + f0 < exp(-0.5 * x * x)) return x;
+    }
+  }
+}
+
+__device__ __forceinline__ double pcg_normal(Pcg& g, const ZigLds& z, double loc, double scale) {
+  return loc + scale * pcg_std_normal(g, z);
+}
+
+}  // namespace nsg

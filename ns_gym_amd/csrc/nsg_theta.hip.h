@@ -1,0 +1,176 @@
+// nsg_theta.hip.h — the θ-schedule engine in device code: "when" (Scheduler) and "how"
+// (UpdateFn) a parameter changes at wrapper time t.
+//
+// Replaces, per (env, param) and per step:
+//   Scheduler.__call__ / _check         ns_gym/base.py:67-81, ns_gym/schedulers.py
+//   UpdateFn.__call__ / _update          ns_gym/base.py:124-149, ns_gym/update_functions/single_param.py
+//   UpdateDistributionFn + W1 delta      ns_gym/base.py:185-203, ns_gym/utils.py:55-94,
+//                                        ns_gym/update_functions/distribution.py
+//
+// The (scheduler kind, update kind, constants) of a param are identical for all envs of a
+// batch, so every switch below is wave-uniform (scalar branch, no divergence); only the
+// fire predicate and θ are per-lane.  All arithmetic is float64 in the reference's operation
+// order; the translation unit is compiled with -ffp-contract=off so a*b+c rounds twice like
+// Python floats (Increment/Decrement/W1 results are bit-identical to the reference).
+#pragma once
+#include "../../include/nsgym_hip.h"
+#include "nsg_rng.hip.h"
+
+namespace nsg {
+
+struct Tables {       // constant-table blob staged in LDS (bit tables, value tables, FrozenLake desc)
+  const uint8_t* base;
+  __device__ __forceinline__ const uint32_t* bits(int off_words) const { return (const uint32_t*)base + off_words; }
+  __device__ __forceinline__ const double* vals(int off_doubles) const { return (const double*)base + off_doubles; }
+};
+
+// Scheduler.__call__: start <= t <= end and _check(t)
+__device__ __forceinline__ bool sched_fire(const nsg_param_cfg& pc, const Tables& tb, int t) {
+  double td = (double)t;
+  if (!(pc.sched_start <= td && td <= pc.sched_end)) return false;
+  switch (pc.sched_kind) {
+    case NSG_SCHED_CONTINUOUS: return true;
+    case NSG_SCHED_PERIODIC: return (t % (int)pc.sched_i0) == 0;
+    case NSG_SCHED_BURST: return (t % (int)(pc.sched_i0 + pc.sched_i1)) < (int)pc.sched_i0;
+    case NSG_SCHED_TABLE: {
+      if (t < 0) return false;
+      if (t >= pc.sched_tab_len) return pc.sched_i0 != 0;
+      return (tb.bits(pc.sched_tab_off)[t >> 5] >> (t & 31)) & 1u;
+    }
+    default: return false;
+  }
+}
+
+// UpdateFn._update for the scalar classes.  `rng` is touched only by the stochastic kinds.
+__device__ inline double upd_scalar(const nsg_param_cfg& pc, const Tables& tb, const ZigLds& zg, double th, int t,
+                                    Pcg& rng, int& cursor) {
+  const double* u = pc.u;
+  const double td = (double)t;
+  switch (pc.upd_kind) {
+    case NSG_UPD_INCREMENT: return th + u[0];
+    case NSG_UPD_DECREMENT: return th - u[0];
+    case NSG_UPD_TREND: return th + u[0] * td;
+    case NSG_UPD_POLY: {
+      const double* c = tb.vals(pc.val_tab_off);
+      double trend = 0.0, pw = 1.0;
+      for (int i = 0; i < pc.val_tab_len; i++) {
+        pw *= td;
+        trend = trend + c[i] * pw;
+      }
+      return th + trend;
+    }
+    case NSG_UPD_GEOMETRIC: return th * u[0];
+    case NSG_UPD_EXPDECAY: return th * exp(-u[0] * td);
+    case NSG_UPD_OSCILLATING: return th + u[0] * sin(td);
+    case NSG_UPD_SIGMOID: {
+      double sg = 1.0 / (1.0 + exp(-u[2] * (td - u[3])));
+      return u[0] + (u[1] - u[0]) * sg;
+    }
+    case NSG_UPD_LERP: {
+      double frac = td / u[2];
+      if (!(frac < 1.0)) frac = 1.0;
+      return u[0] + (u[1] - u[0]) * frac;
+    }
+    case NSG_UPD_STEPWISE: {
+      if (cursor < pc.val_tab_len) return tb.vals(pc.val_tab_off)[cursor++];
+      return th;
+    }
+    case NSG_UPD_CYCLIC: {
+      double v = tb.vals(pc.val_tab_off)[cursor];
+      cursor = cursor + 1 == pc.val_tab_len ? 0 : cursor + 1;
+      return v;
+    }
+    case NSG_UPD_NOUPDATE: return th;
+    case NSG_UPD_RANDOMWALK: return th + pcg_normal(rng, zg, u[0], u[1]);
+    case NSG_UPD_RW_DRIFT: {
+      double w = pcg_normal(rng, zg, u[1], u[2]);
+      return u[0] + th + w;
+    }
+    case NSG_UPD_RW_DRIFT_TREND: {
+      double w = pcg_normal(rng, zg, u[1], u[2]);
+      return u[0] + th + w + u[3] * td;
+    }
+    case NSG_UPD_OU: {
+      double noise = u[2] > 0 ? pcg_normal(rng, zg, 0.0, u[2]) : 0.0;
+      return th + u[0] * (u[1] - th) + noise;
+    }
+    case NSG_UPD_BOUNDED_RW: {
+      double v = th + pcg_normal(rng, zg, u[0], u[1]);
+      if (v < u[2]) v = u[2];
+      if (v > u[3]) v = u[3];
+      return v;
+    }
+    default: return th;
+  }
+}
+
+__device__ __forceinline__ bool upd_uses_cursor(int kind) {
+  return kind == NSG_UPD_STEPWISE || kind == NSG_UPD_CYCLIC || kind == NSG_UPD_D_STEPWISE || kind == NSG_UPD_D_CYCLIC;
+}
+
+// 1-Wasserstein distance between two pmfs on {0,1,2}: SciPy's _cdf_distance(p=1) with
+// values = arange(3): sum |cdf_u - cdf_v| * diff(all_values); weights normalised by their sums.
+__device__ __forceinline__ double w1_3(const double* a, const double* b) {
+  double a01 = a[0] + a[1], at = a01 + a[2];
+  double b01 = b[0] + b[1], bt = b01 + b[2];
+  double d0 = fabs(a[0] / at - b[0] / bt);
+  double d1 = fabs(a01 / at - b01 / bt);
+  return ((((0.0 + d0) + 0.0) + d1) + 0.0);
+}
+
+// UpdateDistributionFn._update for the 3-way FrozenLake slip distribution.
+__device__ inline void upd_dist(const nsg_param_cfg& pc, const Tables& tb, const double* p, int t, int& cursor, double* q) {
+  const double* u = pc.u;
+  const double td = (double)t;
+  q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+  switch (pc.upd_kind) {
+    case NSG_UPD_D_INCREMENT: {
+      double v = p[0] + u[0];
+      q[0] = v > 1.0 ? 1.0 : v;
+      q[1] = (1.0 - q[0]) / 2.0;
+      q[2] = (1.0 - q[0]) / 2.0;
+      break;
+    }
+    case NSG_UPD_D_DECREMENT: {
+      double v = p[0] - u[0];
+      q[0] = v < 0.0 ? 0.0 : v;
+      q[1] = (1.0 - q[0]) / 2.0;
+      q[2] = (1.0 - q[0]) / 2.0;
+      break;
+    }
+    case NSG_UPD_D_STEPWISE:
+      if (cursor < pc.val_tab_len) {
+        const double* v = tb.vals(pc.val_tab_off) + 3 * cursor;
+        q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+        cursor++;
+      }
+      break;
+    case NSG_UPD_D_CYCLIC: {
+      const double* v = tb.vals(pc.val_tab_off) + 3 * cursor;
+      q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+      cursor = cursor + 1 == pc.val_tab_len ? 0 : cursor + 1;
+      break;
+    }
+    case NSG_UPD_D_NOUPDATE: break;
+    case NSG_UPD_D_UNIFORMDRIFT: {
+      double un = 1.0 / 3;
+#pragma unroll
+      for (int k = 0; k < 3; k++) q[k] = (1 - u[0]) * p[k] + u[0] * un;
+      break;
+    }
+    case NSG_UPD_D_TARGETREV:
+#pragma unroll
+      for (int k = 0; k < 3; k++) q[k] = p[k] + u[3] * (u[k] - p[k]);
+      break;
+    case NSG_UPD_D_LERP: {
+      double frac = td / u[6];
+      if (!(frac < 1.0)) frac = 1.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) q[k] = u[k] + (u[3 + k] - u[k]) * frac;
+      break;
+    }
+    default: break;
+  }
+}
+
+}  // namespace nsg

@@ -1,0 +1,378 @@
+// nsgym_hip.hip — C-ABI host side of libnsgym_hip.so (see include/nsgym_hip.h).
+// Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/nsg_zig_tables.inc"
+#include "../../include/nsgym_hip.h"
+#include "nsg_kernels.hip.h"
+#include "nsg_rollout.hip.h"
+
+using namespace nsg;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) return fail(NSG_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+const int kPhysDim[NSG_ENV_COUNT] = {4, 2, 4, 2, 2, 0};
+const int kObsDim[NSG_ENV_COUNT] = {4, 3, 6, 2, 2, 1};
+const int kNTheta[NSG_ENV_COUNT] = {6, 4, 8, 2, 1, 1};
+const int kNActions[NSG_ENV_COUNT] = {2, 0, 3, 3, 0, 4};
+
+bool upd_is_normal(int k) {
+  return k == NSG_UPD_RANDOMWALK || k == NSG_UPD_RW_DRIFT || k == NSG_UPD_RW_DRIFT_TREND || k == NSG_UPD_OU ||
+         k == NSG_UPD_BOUNDED_RW;
+}
+
+int validate(const nsg_config* cfg, size_t table_bytes) {
+  if (!cfg) return fail(NSG_EINVAL, "cfg is NULL");
+  if (cfg->abi_version != NSG_ABI_VERSION) return fail(NSG_EINVAL, "abi_version %d != %d", cfg->abi_version, NSG_ABI_VERSION);
+  if (cfg->env_type < 0 || cfg->env_type >= NSG_ENV_COUNT) return fail(NSG_EINVAL, "bad env_type %d", cfg->env_type);
+  if (cfg->n_params < 0 || cfg->n_params > NSG_MAX_PARAMS) return fail(NSG_EINVAL, "bad n_params %d", cfg->n_params);
+  if (table_bytes > (size_t)kMaxTableBytes) return fail(NSG_EINVAL, "constant tables are %zu bytes, limit %d", table_bytes, kMaxTableBytes);
+  const bool fl = cfg->env_type == NSG_ENV_FROZENLAKE;
+  if (fl) {
+    if (cfg->n_params != 1) return fail(NSG_EINVAL, "FrozenLake takes exactly one tunable parameter (P)");
+    if (cfg->nrow <= 0 || cfg->ncol <= 0) return fail(NSG_EINVAL, "bad FrozenLake map %dx%d", cfg->nrow, cfg->ncol);
+    if ((size_t)cfg->desc_tab_off + (size_t)cfg->nrow * cfg->ncol > table_bytes) return fail(NSG_EINVAL, "desc table out of range");
+  }
+  unsigned seen = 0;
+  for (int p = 0; p < cfg->n_params; p++) {
+    const nsg_param_cfg& pc = cfg->params[p];
+    if (pc.theta_slot < 0 || pc.theta_slot >= kNTheta[cfg->env_type]) return fail(NSG_EINVAL, "param %d: bad theta_slot %d", p, pc.theta_slot);
+    if (!fl && (seen & (1u << pc.theta_slot))) return fail(NSG_EINVAL, "param %d: theta_slot %d configured twice", p, pc.theta_slot);
+    seen |= 1u << pc.theta_slot;
+    const bool dist = pc.upd_kind >= NSG_UPD_D_INCREMENT;
+    if (dist != fl) return fail(NSG_EINVAL, "param %d: update kind %d does not fit env type %d", p, pc.upd_kind, cfg->env_type);
+    if (dist ? pc.upd_kind > NSG_UPD_D_LERP : (pc.upd_kind < 0 || pc.upd_kind > NSG_UPD_BOUNDED_RW))
+      return fail(NSG_EINVAL, "param %d: unknown update kind %d", p, pc.upd_kind);
+    switch (pc.sched_kind) {
+      case NSG_SCHED_CONTINUOUS: break;
+      case NSG_SCHED_PERIODIC:
+        if (pc.sched_i0 <= 0 || pc.sched_i0 > 0x7fffffff) return fail(NSG_EINVAL, "param %d: period must be in [1, 2^31)", p);
+        break;
+      case NSG_SCHED_BURST:
+        if (pc.sched_i0 < 0 || pc.sched_i1 < 0 || pc.sched_i0 + pc.sched_i1 <= 0 || pc.sched_i0 + pc.sched_i1 > 0x7fffffff)
+          return fail(NSG_EINVAL, "param %d: bad burst durations", p);
+        break;
+      case NSG_SCHED_TABLE:
+        if (pc.sched_tab_len < 0 || pc.sched_tab_off < 0 ||
+            (size_t)pc.sched_tab_off * 4 + ((size_t)pc.sched_tab_len + 31) / 32 * 4 > table_bytes)
+          return fail(NSG_EINVAL, "param %d: schedule bit table out of range", p);
+        break;
+      default: return fail(NSG_EINVAL, "param %d: scheduler kind %d is not supported by the kernels", p, pc.sched_kind);
+    }
+    const int k = pc.upd_kind;
+    const bool needs_tab = k == NSG_UPD_POLY || k == NSG_UPD_STEPWISE || k == NSG_UPD_CYCLIC || k == NSG_UPD_D_STEPWISE || k == NSG_UPD_D_CYCLIC;
+    if (needs_tab) {
+      const size_t per = dist ? 3 : 1;
+      if (pc.val_tab_len < 0 || pc.val_tab_off < 0 || ((size_t)pc.val_tab_off + (size_t)pc.val_tab_len * per) * 8 > table_bytes)
+        return fail(NSG_EINVAL, "param %d: value table out of range", p);
+      if ((k == NSG_UPD_CYCLIC || k == NSG_UPD_D_CYCLIC) && pc.val_tab_len == 0) return fail(NSG_EINVAL, "param %d: empty cyclic list", p);
+    }
+    if (pc.uses_rng != (upd_is_normal(k) ? 1 : 0)) return fail(NSG_EINVAL, "param %d: uses_rng does not match update kind %d", p, k);
+  }
+  return NSG_OK;
+}
+
+}  // namespace
+
+struct nsg_handle {
+  Segment host;        // host copy of the device segment
+  Segment* dev;        // device copy (read by the kernels through scalar loads)
+  uint8_t* d_tables;
+  uint64_t* d_zig;
+  int64_t n;
+  bool bound;
+  int device;
+};
+
+extern "C" {
+
+int nsg_abi_version(void) { return NSG_ABI_VERSION; }
+const char* nsg_last_error(void) { return g_err; }
+size_t nsg_sizeof_config(void) { return sizeof(nsg_config); }
+size_t nsg_sizeof_buffers(void) { return sizeof(nsg_buffers); }
+size_t nsg_sizeof_layout(void) { return sizeof(nsg_layout); }
+
+int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
+  if (!out) return fail(NSG_EINVAL, "out is NULL");
+  if (n <= 0) return fail(NSG_EINVAL, "n must be positive");
+  if (!cfg || cfg->env_type < 0 || cfg->env_type >= NSG_ENV_COUNT) return fail(NSG_EINVAL, "bad config");
+  memset(out, 0, sizeof(*out));
+  const int e = cfg->env_type, P = cfg->n_params;
+  const bool fl = e == NSG_ENV_FROZENLAKE;
+  bool any_rng = false, any_cursor = false;
+  for (int p = 0; p < P; p++) {
+    any_rng |= cfg->params[p].uses_rng != 0;
+    const int k = cfg->params[p].upd_kind;
+    any_cursor |= k == NSG_UPD_STEPWISE || k == NSG_UPD_CYCLIC || k == NSG_UPD_D_STEPWISE || k == NSG_UPD_D_CYCLIC;
+  }
+  out->n = n;
+  out->phys_dim = kPhysDim[e];
+  out->obs_dim = kObsDim[e];
+  out->n_params = P;
+  out->n_theta_rows = fl ? 3 : P;
+  out->action_is_float = (e == NSG_ENV_PENDULUM || e == NSG_ENV_MOUNTAINCAR_CONT) ? 1 : 0;
+  out->n_actions = kNActions[e];
+  out->phys = (int64_t)kPhysDim[e] * n;
+  out->cell = fl ? n : 0;
+  out->theta = (int64_t)out->n_theta_rows * n;
+  out->table_prob = fl ? 3 * n : 0;
+  out->t = n;
+  out->status = n;
+  out->rng_env = 4 * n;
+  out->rng_upd = any_rng ? (int64_t)P * 4 * n : 0;
+  out->cursor = any_cursor ? (int64_t)P * n : 0;
+  out->obs = fl ? 0 : (int64_t)kObsDim[e] * n;
+  out->reward = n;
+  out->terminated = n;
+  out->truncated = n;
+  out->env_change = (int64_t)(P > 0 ? P : 1) * n;
+  out->delta_change = (int64_t)(P > 0 ? P : 1) * n;
+  out->prob = fl ? n : 0;
+  const bool tr = (cfg->flags & NSG_F_TRACK_RETURNS) != 0;
+  out->ep_return = tr ? n : 0;
+  out->ep_length = tr ? n : 0;
+  out->last_return = tr ? n : 0;
+  out->last_length = tr ? n : 0;
+  out->counters = NSG_CNT_COUNT * NSG_CNT_SHARDS;
+  out->done_bits = (n + 63) / 64;
+  return NSG_OK;
+}
+
+int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, int64_t n, nsg_handle** out) {
+  if (!out) return fail(NSG_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (n <= 0 || n > (int64_t)1 << 31) return fail(NSG_EINVAL, "n must be in [1, 2^31]");
+  if (table_bytes && !tables) return fail(NSG_EINVAL, "tables is NULL");
+  int rc = validate(cfg, table_bytes);
+  if (rc) return rc;
+  nsg_handle* h = new (std::nothrow) nsg_handle();
+  if (!h) return fail(NSG_ENOMEM, "out of host memory");
+  memset(h, 0, sizeof(*h));
+  h->n = n;
+  HIP_TRY(hipGetDevice(&h->device));
+  const size_t tb = ((table_bytes + 7) / 8) * 8 + 8;
+  HIP_TRY(hipMalloc((void**)&h->d_tables, tb));
+  HIP_TRY(hipMemset(h->d_tables, 0, tb));
+  if (table_bytes) HIP_TRY(hipMemcpy(h->d_tables, tables, table_bytes, hipMemcpyHostToDevice));
+  uint64_t zig[768];
+  memcpy(zig, NSG_ZIG_KI, 2048);
+  memcpy(zig + 256, NSG_ZIG_WI_BITS, 2048);
+  memcpy(zig + 512, NSG_ZIG_FI_BITS, 2048);
+  HIP_TRY(hipMalloc((void**)&h->d_zig, sizeof(zig)));
+  HIP_TRY(hipMemcpy(h->d_zig, zig, sizeof(zig), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&h->dev, sizeof(Segment)));
+  h->host.cfg = *cfg;
+  h->host.N = n;
+  h->host.tables = h->d_tables;
+  h->host.zig = h->d_zig;
+  h->host.table_bytes = (int32_t)table_bytes;
+  h->host.uses_normal = 0;
+  for (int p = 0; p < cfg->n_params; p++) h->host.uses_normal |= cfg->params[p].uses_rng;
+  h->host.block_begin = 0;
+  h->host.block_count = 0;
+  *out = h;
+  return NSG_OK;
+}
+
+static int grid_for(int64_t n) {
+  int64_t chunks = (n + kBlock - 1) / kBlock;
+  return (int)(chunks < 4096 ? chunks : 4096);
+}
+
+int nsg_bind(nsg_handle* h, const nsg_buffers* bufs) {
+  if (!h || !bufs) return fail(NSG_EINVAL, "NULL argument");
+  nsg_layout lay;
+  int rc = nsg_layout_query(&h->host.cfg, h->n, &lay);
+  if (rc) return rc;
+#define NEED(field) \
+  if (lay.field > 0 && !bufs->field) return fail(NSG_EINVAL, "buffer '%s' is required (%lld elements)", #field, (long long)lay.field)
+  NEED(phys); NEED(cell); NEED(theta); NEED(table_prob); NEED(t); NEED(status); NEED(rng_env); NEED(rng_upd); NEED(cursor);
+  NEED(obs); NEED(reward); NEED(terminated); NEED(truncated); NEED(env_change); NEED(delta_change);
+  NEED(ep_return); NEED(ep_length); NEED(last_return); NEED(last_length);
+#undef NEED
+  h->host.buf = *bufs;
+  HIP_TRY(hipMemcpy(h->dev, &h->host, sizeof(Segment), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(init_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, 0, h->dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  h->bound = true;
+  return NSG_OK;
+}
+
+#define DISPATCH_ENV(env, CALL)                                                              \
+  switch (env) {                                                                             \
+    case NSG_ENV_CARTPOLE: { constexpr int E = NSG_ENV_CARTPOLE; CALL; } break;              \
+    case NSG_ENV_PENDULUM: { constexpr int E = NSG_ENV_PENDULUM; CALL; } break;              \
+    case NSG_ENV_ACROBOT: { constexpr int E = NSG_ENV_ACROBOT; CALL; } break;                \
+    case NSG_ENV_MOUNTAINCAR: { constexpr int E = NSG_ENV_MOUNTAINCAR; CALL; } break;        \
+    case NSG_ENV_MOUNTAINCAR_CONT: { constexpr int E = NSG_ENV_MOUNTAINCAR_CONT; CALL; } break; \
+    default: { constexpr int E = NSG_ENV_FROZENLAKE; CALL; } break;                          \
+  }
+
+int nsg_reset(nsg_handle* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, void* stream) {
+  if (!h) return fail(NSG_EINVAL, "handle is NULL");
+  if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_ENV(h->host.cfg.env_type,
+               hipLaunchKernelGGL(reset_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, seeds_dev, mask_dev));
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
+int nsg_step(nsg_handle* h, const void* actions_dev, void* stream) {
+  if (!h) return fail(NSG_EINVAL, "handle is NULL");
+  if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
+  if (!actions_dev) return fail(NSG_EINVAL, "actions_dev is NULL");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_ENV(h->host.cfg.env_type,
+               hipLaunchKernelGGL(step_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, actions_dev));
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
+int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const nsg_rollout_out* out, void* stream) {
+  if (!h) return fail(NSG_EINVAL, "handle is NULL");
+  if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
+  if (!actions_dev || k_steps <= 0) return fail(NSG_EINVAL, "bad rollout arguments");
+  nsg_rollout_out o;
+  memset(&o, 0, sizeof(o));
+  if (out) o = *out;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_ENV(h->host.cfg.env_type,
+               hipLaunchKernelGGL(rollout_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, actions_dev, k_steps, o));
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
+int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* actions_dev, void* stream) {
+  if (!hs || !actions_dev || n_handles <= 0 || n_handles > NSG_MAX_SEGMENTS) return fail(NSG_EINVAL, "bad group arguments");
+  // The group's segment table lives next to the first handle's device segment; it is
+  // (re)built only when the membership changes.
+  static thread_local Segment* d_group = nullptr;
+  static thread_local nsg_handle* members[NSG_MAX_SEGMENTS];
+  static thread_local int n_members = 0;
+  static thread_local int total_blocks = 0;
+  bool same = n_members == n_handles;
+  for (int k = 0; same && k < n_handles; k++) same = members[k] == hs[k];
+  if (!same) {
+    Segment tmp[NSG_MAX_SEGMENTS];
+    int begin = 0;
+    for (int k = 0; k < n_handles; k++) {
+      if (!hs[k] || !hs[k]->bound) return fail(NSG_ENOTBOUND, "group member %d is not bound", k);
+      tmp[k] = hs[k]->host;
+      tmp[k].block_begin = begin;
+      tmp[k].block_count = grid_for(hs[k]->n);
+      begin += tmp[k].block_count;
+    }
+    if (!d_group) HIP_TRY(hipMalloc((void**)&d_group, sizeof(Segment) * NSG_MAX_SEGMENTS));
+    HIP_TRY(hipMemcpy(d_group, tmp, sizeof(Segment) * n_handles, hipMemcpyHostToDevice));
+    for (int k = 0; k < n_handles; k++) members[k] = hs[k];
+    n_members = n_handles;
+    total_blocks = begin;
+  }
+  ActionPtrs ap;
+  memset(&ap, 0, sizeof(ap));
+  for (int k = 0; k < n_handles; k++) {
+    if (!actions_dev[k]) return fail(NSG_EINVAL, "actions_dev[%d] is NULL", k);
+    ap.p[k] = actions_dev[k];
+  }
+  hipLaunchKernelGGL(step_group_kernel, dim3(total_blocks), dim3(kBlock), 0, (hipStream_t)stream, d_group, n_handles, ap);
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
+int nsg_compact_done(nsg_handle* h, int32_t* idx_out_dev, uint64_t* count_out_dev, void* stream) {
+  if (!h || !idx_out_dev || !count_out_dev) return fail(NSG_EINVAL, "NULL argument");
+  if (!h->bound || !h->host.buf.done_bits) return fail(NSG_ENOTBOUND, "done_bits buffer is not bound");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(count_out_dev, 0, sizeof(uint64_t), s));
+  hipLaunchKernelGGL(compact_done_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->host.buf.done_bits, h->n, idx_out_dev,
+                     (unsigned long long*)count_out_dev);
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
+int nsg_theta_trace(nsg_handle* h, int32_t p, int32_t n, int32_t t0, int32_t T, const double* theta0, uint64_t* rng_state,
+                    double* theta_out, uint8_t* fired_out, double* delta_out, void* stream) {
+  if (!h) return fail(NSG_EINVAL, "handle is NULL");
+  if (p < 0 || p >= h->host.cfg.n_params || n <= 0 || T <= 0) return fail(NSG_EINVAL, "bad theta_trace arguments");
+  if (!theta0 || !theta_out || !fired_out || !delta_out) return fail(NSG_EINVAL, "NULL buffer");
+  if (h->host.cfg.params[p].uses_rng && !rng_state) return fail(NSG_EINVAL, "rng_state required for a stochastic update fn");
+  if (!h->bound) HIP_TRY(hipMemcpy(h->dev, &h->host, sizeof(Segment), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(theta_trace_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, h->dev, p, n, t0, T,
+                     theta0, rng_state, theta_out, fired_out, delta_out);
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
+int nsg_rng_fill(int32_t kind, const uint64_t* seeds_dev, int32_t n, int32_t spawn_key, int32_t count, void* out_dev,
+                 uint64_t* state_out_dev, void* stream) {
+  if (kind < 0 || kind > 2 || !seeds_dev || n <= 0 || count < 0 || (count > 0 && !out_dev)) return fail(NSG_EINVAL, "bad rng_fill arguments");
+  static thread_local uint64_t* d_zig = nullptr;
+  if (!d_zig) {
+    uint64_t zig[768];
+    memcpy(zig, NSG_ZIG_KI, 2048);
+    memcpy(zig + 256, NSG_ZIG_WI_BITS, 2048);
+    memcpy(zig + 512, NSG_ZIG_FI_BITS, 2048);
+    HIP_TRY(hipMalloc((void**)&d_zig, sizeof(zig)));
+    HIP_TRY(hipMemcpy(d_zig, zig, sizeof(zig), hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(rng_fill_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, kind, seeds_dev, n,
+                     spawn_key, count, out_dev, state_out_dev, d_zig);
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
+int nsg_time_steps(nsg_handle* h, const void* actions_dev, int32_t iters, void* stream, float* ms_avg) {
+  if (!h || !ms_avg || iters <= 0) return fail(NSG_EINVAL, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, s));
+  for (int k = 0; k < iters; k++) {
+    int rc = nsg_step(h, actions_dev, stream);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_avg = ms / (float)iters;
+  return NSG_OK;
+}
+
+int nsg_destroy(nsg_handle* h) {
+  if (!h) return NSG_OK;
+  if (h->d_tables) (void)hipFree(h->d_tables);
+  if (h->d_zig) (void)hipFree(h->d_zig);
+  if (h->dev) (void)hipFree(h->dev);
+  delete h;
+  return NSG_OK;
+}
+
+}  // extern "C"

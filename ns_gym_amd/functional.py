@@ -1,0 +1,78 @@
+"""Device evaluation of the θ-engine and of NumPy-compatible streams through the C-ABI
+(nsg_theta_trace / nsg_rng_fill).  Used by `Scheduler.__call__`, `UpdateFn.__call__` and the
+known-answer parity tests."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi as A
+from . import _lib
+from .base import Scheduler, UpdateDistributionFn, UpdateFn
+from .envs import make
+from .spec import compile_config
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise _lib.NsgError("the θ-engine runs on the GPU only (no CPU path)")
+    return torch.device(f"cuda:{torch.cuda.current_device()}")
+
+
+def rng_fill(kind: int, seeds, count: int, spawn_key: int = -1):
+    """kind 0 raw uint64, 1 Generator.random(), 2 Generator.standard_normal(); returns
+    (out[count, n], state[4, n]) as NumPy arrays."""
+    lib, dev = _lib.load(), _dev()
+    s = np.asarray(seeds, dtype=np.uint64).reshape(-1)
+    n = s.size
+    sd = torch.from_numpy(s.view(np.int64)).to(dev)
+    out = torch.zeros((max(count, 1), n), dtype=torch.int64 if kind == 0 else torch.float64, device=dev)
+    st = torch.zeros((4, n), dtype=torch.int64, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.nsg_rng_fill(kind, sd.data_ptr(), n, spawn_key, count, out.data_ptr(), st.data_ptr(), stream), "nsg_rng_fill")
+    torch.cuda.synchronize(dev)
+    o = out[:count].cpu().numpy()
+    return (o.view(np.uint64) if kind == 0 else o), st.cpu().numpy().view(np.uint64)
+
+
+def theta_trace(fn: UpdateFn, theta0, t0: int = 0, T: int = 1, n: int = 1, seeds=None):
+    """Drive one (scheduler, update fn) pair for t = t0..t0+T-1 with θ fed back, on `n` lanes.
+    Returns (theta[T, n] or [T, 3, n], fired[T, n], delta[T, n]) as NumPy arrays."""
+    lib, dev = _lib.load(), _dev()
+    dist = isinstance(fn, UpdateDistributionFn)
+    cfg, tables, _, _ = compile_config(make("FrozenLake-v1") if dist else make("CartPole-v1"),
+                                       {"P" if dist else "gravity": fn})
+    h = C.c_void_p()
+    _lib.check(lib.nsg_create(C.byref(cfg), tables, len(tables), max(n, 1), C.byref(h)), "nsg_create")
+    try:
+        th0 = np.ascontiguousarray(np.broadcast_to(np.asarray(theta0, dtype=np.float64), (n, 3) if dist else (n,)))
+        d_th0 = torch.from_numpy(th0).to(dev)
+        rng = None
+        if cfg.params[0].uses_rng:
+            sd = np.asarray(seeds if seeds is not None else [cfg.params[0].fn_seed] * n, dtype=np.uint64)
+            _, st = rng_fill(0, sd, 0)
+            rng = torch.from_numpy(st.view(np.int64)).to(dev)
+        th = torch.zeros((T, 3, n) if dist else (T, n), dtype=torch.float64, device=dev)
+        fired = torch.zeros((T, n), dtype=torch.uint8, device=dev)
+        delta = torch.zeros((T, n), dtype=torch.float64, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.nsg_theta_trace(h, 0, n, int(t0), int(T), d_th0.data_ptr(), rng.data_ptr() if rng is not None else None,
+                                       th.data_ptr(), fired.data_ptr(), delta.data_ptr(), stream), "nsg_theta_trace")
+        torch.cuda.synchronize(dev)
+        return th.cpu().numpy(), fired.cpu().numpy(), delta.cpu().numpy()
+    finally:
+        lib.nsg_destroy(h)
+
+
+def schedule_fires(scheduler: Scheduler, ts) -> np.ndarray:
+    """Scheduler.__call__ for each t in `ts` (device)."""
+    from .update_functions import NoUpdate
+
+    ts = [int(t) for t in ts]
+    if not ts:
+        return np.zeros(0, dtype=bool)
+    lo, hi = min(ts), max(ts)
+    _, fired, _ = theta_trace(NoUpdate(scheduler), 0.0, t0=lo, T=hi - lo + 1)
+    return np.array([bool(fired[t - lo, 0]) for t in ts])

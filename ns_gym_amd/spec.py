@@ -20,8 +20,7 @@ _INF = "inf"
 
 
 def compile_config(env, tunable_params: dict, *, change_notification=False, delta_change_notification=False,
-                   in_sim_change=False, scalar_reward=True, persistent_params=False, track_returns=False,
-                   compact_done=False, initial_prob_dist=None, modified_rewards=None):
+                   in_sim_change=False, scalar_reward=True, persistent_params=False, track_returns=False, initial_prob_dist=None, modified_rewards=None):
     """Returns (Config, tables_blob: bytes, BaseEnvSpec, param_names)."""
     spec: BaseEnvSpec = from_gym_env(env)
     et = spec.env_type
@@ -51,8 +50,6 @@ def compile_config(env, tunable_params: dict, *, change_notification=False, delt
         flags |= A.F_PERSISTENT_PARAMS
     if track_returns:
         flags |= A.F_TRACK_RETURNS
-    if compact_done:
-        flags |= A.F_COMPACT_DONE
     tables = TableBuilder()
     if is_fl:
         assert "P" in tunable_params, "NSFrozenLakeWrapper requires tunable_params['P']"

@@ -1,0 +1,274 @@
+"""VecNSEnv — N non-stationary env instances stepped by one fused HIP launch.
+
+Host-side mirror of the reference's wrapper interface for the hot path
+(NSWrapper / NSClassicControlWrapper / NSFrozenLakeWrapper: ns_gym/base.py:206-502,
+ns_gym/wrappers/classic_control.py:15-109, ns_gym/wrappers/toy_text.py:265-399), batched:
+env i behaves like one reference wrapper instance reset with `seed + i`.
+
+PyTorch owns every device buffer (the tensors below); the library (C-ABI, include/nsgym_hip.h)
+only enqueues kernels on the current stream.  No host synchronisation in `step`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+
+import numpy as np
+import torch
+
+from . import _abi as A
+from . import _lib
+from .spec import compile_config
+
+_TORCH_DT = {C.c_double: torch.float64, C.c_int32: torch.int32, C.c_uint8: torch.uint8,
+             C.c_uint64: torch.int64,  # bit pattern; torch has no first-class uint64 arithmetic
+             C.c_float: torch.float32}
+
+
+class ConstraintViolationWarning(Warning):
+    """Issued when updates were rejected by the physical-constraint checker
+    (ns_gym/wrappers/classic_control.py:9-12)."""
+
+
+class VecNSEnv:
+    """Vectorised non-stationary environment (duck-types gymnasium.vector.VectorEnv).
+
+    Args mirror NSWrapper.__init__ (ns_gym/base.py:222-232) plus `num_envs`; FrozenLake adds
+    `initial_prob_dist`, `modified_rewards` (ns_gym/wrappers/toy_text.py:282-294).
+    """
+
+    def __init__(self, env, tunable_params: dict, num_envs: int, change_notification: bool = False,
+                 delta_change_notification: bool = False, in_sim_change: bool = False, scalar_reward: bool = True,
+                 persistent_params: bool = False, track_returns: bool = False, device=None, **kwargs):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.NsgError("VecNSEnv needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.cfg, self.tables, self.spec, self.param_names = compile_config(
+            env, tunable_params, change_notification=change_notification,
+            delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
+            scalar_reward=scalar_reward, persistent_params=persistent_params, track_returns=track_returns, **kwargs)
+        self.tunable_params = tunable_params
+        self.change_notification = change_notification
+        self.delta_change_notification = delta_change_notification
+        self.in_sim_change = in_sim_change
+        self.scalar_reward = scalar_reward
+        self.persistent_params = persistent_params
+        self.frozen = False
+        self.is_sim_env = False
+        self.has_reset = False
+        self.num_envs = self.N = int(num_envs)
+        self.is_frozenlake = self.cfg.env_type == A.ENV_FROZENLAKE
+
+        lay = A.Layout()
+        _lib.check(self.lib.nsg_layout_query(C.byref(self.cfg), self.N, C.byref(lay)), "nsg_layout_query")
+        self.layout = lay
+        self.obs_dim = lay.obs_dim
+        self.action_is_float = bool(lay.action_is_float)
+        self.n_actions = lay.n_actions
+        with torch.cuda.device(self.device):
+            self.buf = {}
+            for name, ct in A.BUFFER_FIELDS:
+                n = getattr(lay, name)
+                self.buf[name] = torch.zeros(n, dtype=_TORCH_DT[ct], device=self.device) if n > 0 else None
+            self._bufs = A.Buffers(**{k: (v.data_ptr() if v is not None else None) for k, v in self.buf.items()})
+            h = C.c_void_p()
+            _lib.check(self.lib.nsg_create(C.byref(self.cfg), self.tables, len(self.tables), self.N, C.byref(h)),
+                       "nsg_create")
+            self._h = h
+            _lib.check(self.lib.nsg_bind(self._h, C.byref(self._bufs)), "nsg_bind")
+        self._make_views()
+        self._zero_flags = None
+        self._viol_seen = 0
+
+    # ------------------------------------------------------------------ tensor views
+    def _make_views(self):
+        N, P, b = self.N, max(self.cfg.n_params, 1), self.buf
+        self.t = b["t"]
+        self.reward = b["reward"]
+        self.terminated = b["terminated"].view(torch.bool)
+        self.truncated = b["truncated"].view(torch.bool)
+        self.gt_env_change = b["env_change"].view(P, N)
+        self.gt_delta_change = b["delta_change"].view(P, N)
+        rows = 3 if self.is_frozenlake else P
+        self.theta = b["theta"].view(rows, N)
+        if self.is_frozenlake:
+            self.state = b["cell"]
+            self.prob = b["prob"]
+            self.table_prob = b["table_prob"].view(3, N)
+        else:
+            self.state = b["obs"].view(N, self.obs_dim)
+            self.phys = b["phys"].view(self.layout.phys_dim, N)
+
+    @property
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ gym-like API
+    def reset(self, *, seed=None, options=None, mask=None):
+        """`reset(seed=s)`: env i is seeded exactly like the reference's `reset(seed=s+i)` (or
+        `seed[i]` for a sequence); `reset()` continues every stream (ns_gym/base.py:365-410)."""
+        seeds = None
+        if seed is not None:
+            if np.isscalar(seed):
+                s = np.arange(self.N, dtype=np.uint64) + np.uint64(int(seed))
+            else:
+                s = np.asarray(seed, dtype=np.uint64)
+                assert s.shape == (self.N,), "seed sequence must have one entry per env"
+            seeds = torch.from_numpy(s.view(np.int64)).to(self.device)
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nsg_reset(self._h, seeds.data_ptr() if seeds is not None else None,
+                                          m.data_ptr() if m is not None else None, self._stream), "nsg_reset")
+        self.has_reset = True
+        return self._obs(), self._info()
+
+    def step(self, actions):
+        """One fused wrapper step for all envs.  `actions`: int32[N] (discrete) or float32[N] /
+        float32[N,1] (continuous) device tensor."""
+        act = self._as_actions(actions)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nsg_step(self._h, act.data_ptr(), self._stream), "nsg_step")
+        return self._obs(), self.reward, self.terminated, self.truncated, self._info()
+
+    def rollout(self, actions, record=("obs", "reward", "terminated", "truncated")):
+        """K fused steps in one launch; `actions`: [K, N].  Returns a dict of [K, ...] trajectory
+        tensors for the fields named in `record`."""
+        K = int(actions.shape[0])
+        dt = torch.float32 if self.action_is_float else torch.int32
+        act = actions.to(device=self.device, dtype=dt).reshape(K, self.N).contiguous()
+        P, N = max(self.cfg.n_params, 1), self.N
+        shapes = {"obs": ((K, N) if self.is_frozenlake else (K, N, self.obs_dim),
+                          torch.int32 if self.is_frozenlake else torch.float32),
+                  "reward": ((K, N), torch.float32), "terminated": ((K, N), torch.uint8),
+                  "truncated": ((K, N), torch.uint8), "env_change": ((K, P, N), torch.uint8),
+                  "delta_change": ((K, P, N), torch.float32)}
+        out = {k: torch.empty(shapes[k][0], dtype=shapes[k][1], device=self.device) for k in record}
+        ro = A.RolloutOut(**{k: v.data_ptr() for k, v in out.items()})
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nsg_rollout(self._h, act.data_ptr(), K, C.byref(ro), self._stream), "nsg_rollout")
+        for k in ("terminated", "truncated"):
+            if k in out:
+                out[k] = out[k].view(torch.bool)
+        return out
+
+    def _as_actions(self, actions):
+        dt = torch.float32 if self.action_is_float else torch.int32
+        act = torch.as_tensor(actions, device=self.device)
+        if act.dtype != dt:
+            act = act.to(dt)
+        act = act.reshape(-1)
+        assert act.numel() == self.N, f"expected {self.N} actions, got {act.numel()}"
+        return act.contiguous()
+
+    # ------------------------------------------------------------------ observation / info
+    def _masked(self):
+        hide = self.frozen or (self.is_sim_env and not self.in_sim_change)
+        if self._zero_flags is None:
+            self._zero_flags = (torch.zeros_like(self.gt_env_change), torch.zeros_like(self.gt_delta_change))
+        ec = self.gt_env_change if (self.change_notification and not hide) else self._zero_flags[0]
+        dc = self.gt_delta_change if (self.delta_change_notification and not hide) else self._zero_flags[1]
+        return ec, dc
+
+    def _obs(self):
+        """NS observation dict (ns_gym/base.py:343-348), batched: values are [N]-tensors per param."""
+        ec, dc = self._masked()
+        return {
+            "state": self.state,
+            "env_change": {p: ec[j] for j, p in enumerate(self.param_names)},
+            "delta_change": {p: dc[j] for j, p in enumerate(self.param_names)},
+            "relative_time": self.t,
+        }
+
+    def _info(self):
+        info = {
+            "Ground Truth Env Change": {p: self.gt_env_change[j] for j, p in enumerate(self.param_names)},
+            "Ground Truth Delta Change": {p: self.gt_delta_change[j] for j, p in enumerate(self.param_names)},
+        }
+        if self.is_frozenlake:
+            info["prob"] = self.prob
+            info["transition_prob"] = self.theta
+        return info
+
+    # ------------------------------------------------------------------ reductions / bookkeeping
+    def counters(self) -> dict:
+        """Running totals produced by the kernels' wavefront ballots (synchronises)."""
+        c = self.buf["counters"].view(A.CNT_COUNT, A.CNT_SHARDS).sum(dim=1).tolist()
+        return {"episodes": int(c[A.CNT_DONE]), "updates_applied": int(c[A.CNT_FIRED]),
+                "constraint_violations": int(c[A.CNT_VIOLATION]), "env_steps": int(c[A.CNT_STEPS])}
+
+    def check_constraints(self) -> int:
+        """Aggregated ConstraintViolationWarning (the reference warns per violation,
+        classic_control.py:212-234); returns the number of new violations since the last call."""
+        v = self.counters()["constraint_violations"]
+        new = v - self._viol_seen
+        self._viol_seen = v
+        if new > 0:
+            warnings.warn(f"{new} parameter updates violated a physical constraint and were not applied",
+                          ConstraintViolationWarning)
+        return new
+
+    def done_indices(self):
+        """Dense int32 tensor of env indices whose episode ended in the last step (compaction of the
+        wavefront ballot words; order unspecified)."""
+        idx = torch.empty(self.N, dtype=torch.int32, device=self.device)
+        cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nsg_compact_done(self._h, idx.data_ptr(), cnt.data_ptr(), self._stream), "nsg_compact_done")
+        return idx[: int(cnt.item())]
+
+    def episode_returns(self):
+        if self.buf["last_return"] is None:
+            raise ValueError("construct with track_returns=True")
+        return self.buf["last_return"], self.buf["last_length"]
+
+    def time_steps(self, actions, iters: int) -> float:
+        """Average device milliseconds per `nsg_step` launch over `iters` back-to-back launches,
+        measured with hipEvents on the current stream."""
+        act = self._as_actions(actions)
+        ms = C.c_float()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nsg_time_steps(self._h, act.data_ptr(), int(iters), self._stream, C.byref(ms)),
+                       "nsg_time_steps")
+        return float(ms.value)
+
+    def freeze(self, mode: bool = True):
+        if not isinstance(mode, bool):
+            raise TypeError(f"Expected mode to be a boolean, got {type(mode)}")
+        self.frozen = mode
+        return self
+
+    def unfreeze(self):
+        return self.freeze(False)
+
+    def get_default_params(self):
+        from .envs import TUNABLE_PARAMS
+
+        return TUNABLE_PARAMS[self.spec.class_name]
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            torch.cuda.synchronize(self.device)
+            self.lib.nsg_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def step_group(envs, actions):
+    """One heterogeneous launch over several VecNSEnv of different env types (per-env-type
+    dispatch is uniform per workgroup)."""
+    lib = _lib.load()
+    n = len(envs)
+    acts = [e._as_actions(a) for e, a in zip(envs, actions)]
+    hs = (C.c_void_p * n)(*[e._h for e in envs])
+    ap = (C.c_void_p * n)(*[a.data_ptr() for a in acts])
+    with torch.cuda.device(envs[0].device):
+        _lib.check(lib.nsg_step_group(hs, n, ap, envs[0]._stream), "nsg_step_group")
+    return [(e._obs(), e.reward, e.terminated, e.truncated, e._info()) for e in envs]

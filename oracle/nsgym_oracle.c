@@ -618,10 +618,11 @@ static void frozenlake_move(const nsg_config* cfg, int row, int col, int a, int*
 }
 
 static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N, int64_t i,
-                     const void* actions, uint32_t* cnt) {
+                     const void* actions, uint64_t* cnt) {
   int env = cfg->env_type, P = cfg->n_params;
   if (b->status[i] & NSG_ST_NEEDS_RESET) { /* next-step autoreset == env.reset() with no seed */
     reset_one(cfg, tables, b, N, i, 0, 0);
+    if (b->done_bits) b->done_bits[i >> 6] &= ~(1ULL << (i & 63));
     return;
   }
   int t = b->t[i];
@@ -641,7 +642,7 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
     for (int k = 0; k < 3; k++) p[k] = b->table_prob[k * N + i];
     b->env_change[i] = (uint8_t)fired;
     b->delta_change[i] = (float)delta;
-    if (fired) cnt[NSG_CNT_FIRED]++;
+    if (fired) cnt[NSG_CNT_FIRED * NSG_CNT_SHARDS]++;
     /* gymnasium FrozenLakeEnv.step over the NS table (toy_text.py:426-444) */
     int a = ((const int32_t*)actions)[i];
     int s = b->cell[i];
@@ -698,7 +699,7 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
       int fired = (firedmask >> p) & 1;
       double delta = fired ? nv[k] - cur[k] : 0.0; /* base.py:182 */
       if ((viol >> k) & 1u) {
-        if (fired) cnt[NSG_CNT_VIOLATION]++;
+        if (fired) cnt[NSG_CNT_VIOLATION * NSG_CNT_SHARDS]++;
         fired = 0; delta = 0.0;
       } else {
         th[k] = nv[k];
@@ -706,7 +707,7 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
       b->theta[p * N + i] = th[k];
       b->env_change[p * N + i] = (uint8_t)fired;
       b->delta_change[p * N + i] = (float)delta;
-      if (fired) cnt[NSG_CNT_FIRED]++;
+      if (fired) cnt[NSG_CNT_FIRED * NSG_CNT_SHARDS]++;
     }
     double s[4];
     for (int k = 0; k < PHYS_DIM[env]; k++) s[k] = b->phys[k * N + i];
@@ -731,24 +732,42 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
     if (done) { b->last_return[i] = er; b->last_length[i] = el; er = 0.0f; el = 0; }
     b->ep_return[i] = er; b->ep_length[i] = el;
   }
-  if (done) {
-    if ((cfg->flags & NSG_F_COMPACT_DONE) && b->done_idx) b->done_idx[cnt[NSG_CNT_DONE]] = (int32_t)i;
-    cnt[NSG_CNT_DONE]++;
-    cnt[NSG_CNT_EPISODES]++;
+  cnt[NSG_CNT_STEPS * NSG_CNT_SHARDS]++;
+  if (b->done_bits) {
+    if (done) b->done_bits[i >> 6] |= 1ULL << (i & 63);
+    else b->done_bits[i >> 6] &= ~(1ULL << (i & 63));
   }
+  if (done) cnt[NSG_CNT_DONE * NSG_CNT_SHARDS]++;
 }
 
 int orc_step(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N, const void* actions) {
-  uint32_t* cnt = b->counters;
-  cnt[NSG_CNT_DONE] = cnt[NSG_CNT_FIRED] = cnt[NSG_CNT_VIOLATION] = 0;
+  uint64_t* cnt = b->counters; /* running totals, shard 0 */
   for (int64_t i = 0; i < N; i++) step_one(cfg, tables, b, N, i, actions, cnt);
   return 0;
 }
 
 /* range version for multi-threaded baselines (counters are per-call scratch of the caller) */
 int orc_step_range(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N, const void* actions,
-                   int64_t lo, int64_t hi, uint32_t* cnt) {
+                   int64_t lo, int64_t hi, uint64_t* cnt) {
   for (int64_t i = lo; i < hi; i++) step_one(cfg, tables, b, N, i, actions, cnt);
+  return 0;
+}
+
+/* multi-threaded variant for the CPU baseline leg of bench.py (OpenMP over env ranges) */
+int orc_step_mt(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N, const void* actions,
+                int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  uint64_t* total = b->counters;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (int th = 0; th < nthreads; th++) {
+    uint64_t cnt[NSG_CNT_COUNT * NSG_CNT_SHARDS];
+    memset(cnt, 0, sizeof(cnt));
+    int64_t per = ((N + nthreads - 1) / nthreads + 63) & ~63LL; /* 64-aligned: done_bits words stay thread-private */
+    int64_t lo = th * per, hi = lo + per < N ? lo + per : N;
+    for (int64_t i = lo; i < hi; i++) step_one(cfg, tables, b, N, i, actions, cnt);
+    for (int c = 0; c < NSG_CNT_COUNT; c++)
+      __atomic_fetch_add(&total[c * NSG_CNT_SHARDS], cnt[c * NSG_CNT_SHARDS], __ATOMIC_RELAXED);
+  }
   return 0;
 }
 

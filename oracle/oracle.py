@@ -76,7 +76,7 @@ class OracleVecEnv:
             "env_change": z((max(P, 1), N), np.uint8), "delta_change": z((max(P, 1), N), np.float32),
             "prob": z(N, np.float32), "ep_return": z(N, np.float32), "ep_length": z(N, np.int32),
             "last_return": z(N, np.float32), "last_length": z(N, np.int32),
-            "counters": z(A.CNT_COUNT, np.uint32), "done_idx": z(N, np.int32),
+            "counters": z((A.CNT_COUNT, A.CNT_SHARDS), np.uint64), "done_bits": z((N + 63) // 64, np.uint64),
         }
         self.bufs = A.Buffers(**{k: _ptr(v) for k, v in self.a.items()})
         lib().orc_init_streams(C.byref(self.cfg), C.byref(self.bufs), C.c_int64(N), None)
@@ -97,6 +97,12 @@ class OracleVecEnv:
         act = np.ascontiguousarray(actions, dtype=dt)
         assert act.shape == (self.N,)
         lib().orc_step(C.byref(self.cfg), _ptr(self.tab), C.byref(self.bufs), C.c_int64(self.N), _ptr(act))
+        return self.a
+
+    def step_mt(self, actions, nthreads):
+        dt = np.float32 if self.action_is_float else np.int32
+        act = np.ascontiguousarray(actions, dtype=dt)
+        lib().orc_step_mt(C.byref(self.cfg), _ptr(self.tab), C.byref(self.bufs), C.c_int64(self.N), _ptr(act), int(nthreads))
         return self.a
 
     # convenience views -----------------------------------------------------------------

@@ -88,3 +88,50 @@ class OracleView:
     def step(self, actions):
         self.env.step(actions)
         return self._out()
+
+
+class GpuView:
+    """Adapts ns_gym_amd.VecNSEnv (device tensors) to the dict-of-NumPy protocol above."""
+
+    def __init__(self, env):
+        self.env = env
+
+    def _out(self):
+        e = self.env
+        P = max(e.cfg.n_params, 1)
+        out = {
+            "state": e.state.cpu().numpy().copy(),
+            "reward": e.reward.cpu().numpy(), "terminated": e.terminated.cpu().numpy().astype(np.uint8),
+            "truncated": e.truncated.cpu().numpy().astype(np.uint8),
+            "env_change": e.gt_env_change.cpu().numpy()[:P], "delta_change": e.gt_delta_change.cpu().numpy()[:P],
+            "t": e.t.cpu().numpy(), "theta": e.theta.cpu().numpy(),
+        }
+        if e.is_frozenlake:
+            out["prob"] = e.prob.cpu().numpy()
+        return out
+
+    def reset(self, seeds):
+        self.env.reset(seed=seeds)
+        return self._out()
+
+    def step(self, actions):
+        import torch
+
+        self.env.step(torch.from_numpy(np.ascontiguousarray(actions)))
+        return self._out()
+
+
+def compare_views(a, b, is_fl, tag=""):
+    """Field-by-field comparison of two implementations' outputs (HIP vs oracle)."""
+    if is_fl:
+        np.testing.assert_array_equal(a["state"].reshape(-1), b["state"].reshape(-1), err_msg=tag)
+        np.testing.assert_array_equal(a["prob"], b["prob"], err_msg=tag)
+        np.testing.assert_array_equal(a["theta"], b["theta"], err_msg=tag)
+        np.testing.assert_array_equal(a["delta_change"], b["delta_change"], err_msg=tag)
+    else:
+        np.testing.assert_allclose(a["state"], b["state"], rtol=STATE_RTOL, atol=STATE_ATOL, err_msg=tag)
+        np.testing.assert_allclose(a["theta"], b["theta"], rtol=THETA_RTOL, atol=1e-12, err_msg=tag)
+        np.testing.assert_allclose(a["delta_change"], b["delta_change"], rtol=THETA_RTOL, atol=1e-7, err_msg=tag)
+    np.testing.assert_allclose(a["reward"], b["reward"], rtol=1e-5, atol=1e-5, err_msg=tag)
+    for k in ("terminated", "truncated", "env_change", "t"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=f"{tag} {k}")
