@@ -11,6 +11,7 @@
 // constants (slot order = ATTRIBUTE_MAP, ns_gym/base.py:611-635).
 #pragma once
 #include "../../include/nsgym_hip.h"
+#include "nsg_math.hip.h"
 #include "nsg_rng.hip.h"
 
 namespace nsg {
@@ -48,12 +49,12 @@ template <int ENV> __device__ __forceinline__ void env_obs(const double* s, floa
     for (int k = 0; k < 4; k++) o[k] = (float)s[k];
   } else if constexpr (ENV == NSG_ENV_PENDULUM) {
     double sn, cs;
-    sincos(s[0], &sn, &cs);
+    nsg_sincos(s[0], &sn, &cs);
     o[0] = (float)cs; o[1] = (float)sn; o[2] = (float)s[1];
   } else if constexpr (ENV == NSG_ENV_ACROBOT) {
     double s0, c0, s1, c1;
-    sincos(s[0], &s0, &c0);
-    sincos(s[1], &s1, &c1);
+    nsg_sincos(s[0], &s0, &c0);
+    nsg_sincos(s[1], &s1, &c1);
     o[0] = (float)c0; o[1] = (float)s0; o[2] = (float)c1; o[3] = (float)s1; o[4] = (float)s[2]; o[5] = (float)s[3];
   } else {
     o[0] = (float)s[0]; o[1] = (float)s[1];
@@ -108,12 +109,12 @@ __device__ __forceinline__ void acrobot_dsdt(const double* th, const double* y, 
   const double m1 = th[3], m2 = th[4], l1 = th[1], lc1 = th[5], lc2 = th[6], I1 = th[7], I2 = th[7], g = 9.8;
   const double theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
   double sin2, cos2;
-  sincos(theta2, &sin2, &cos2);
+  nsg_sincos(theta2, &sin2, &cos2);
   double d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * cos2) + I1 + I2;
   double d2 = m2 * (lc2 * lc2 + l1 * lc2 * cos2) + I2;
-  double phi2 = m2 * lc2 * g * cos(theta1 + theta2 - NSG_PI / 2.0);
+  double phi2 = m2 * lc2 * g * nsg_cos(theta1 + theta2 - NSG_PI / 2.0);
   double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * sin2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * sin2 +
-                (m1 * lc1 + m2 * l1) * g * cos(theta1 - NSG_PI / 2) + phi2;
+                (m1 * lc1 + m2 * l1) * g * nsg_cos(theta1 - NSG_PI / 2) + phi2;
   double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * sin2 - phi2) /
                     (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
   double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
@@ -130,7 +131,7 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
     double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
     double force = ai == 1 ? force_mag : -force_mag;
     double sintheta, costheta;
-    sincos(theta, &sintheta, &costheta);
+    nsg_sincos(theta, &sintheta, &costheta);
     double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
     double thetaacc = (gravity * sintheta - costheta * temp) /
                       (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
@@ -153,7 +154,7 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
     if (r != 0 && r < 0) r += 2 * NSG_PI;
     double an = r - NSG_PI;
     double costs = an * an + 0.1 * (thdot * thdot) + 0.001 * (u * u);
-    double newthdot = thdot + (3 * g / (2 * l) * sin(t0) + 3.0 / (m * (l * l)) * u) * dt;
+    double newthdot = thdot + (3 * g / (2 * l) * nsg_sin(t0) + 3.0 / (m * (l * l)) * u) * dt;
     if (newthdot < -8.0) newthdot = -8.0;
     if (newthdot > 8.0) newthdot = 8.0;
     double newth = t0 + newthdot * dt;
@@ -188,12 +189,12 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
     ns[3] = fmin(fmax(ns[3], -mv2), mv2);
 #pragma unroll
     for (int k = 0; k < 4; k++) s[k] = ns[k];
-    bool term = (-cos(s[0]) - cos(s[1] + s[0])) > 1.0;
+    bool term = (-nsg_cos(s[0]) - nsg_cos(s[1] + s[0])) > 1.0;
     reward = term ? 0.0 : -1.0;
     return term;
   } else if constexpr (ENV == NSG_ENV_MOUNTAINCAR) {
     double position = s[0], velocity = s[1];
-    velocity += (double)(ai - 1) * th[1] + cos(3 * position) * (-th[0]);
+    velocity += (double)(ai - 1) * th[1] + nsg_cos(3 * position) * (-th[0]);
     if (velocity < -0.07) velocity = -0.07;
     if (velocity > 0.07) velocity = 0.07;
     position += velocity;
@@ -207,7 +208,7 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
     double position = s[0], velocity = s[1];
     double a0 = (double)af;
     double force = fmin(fmax(a0, -1.0), 1.0);
-    velocity += force * th[0] - 0.0025 * cos(3 * position);
+    velocity += force * th[0] - 0.0025 * nsg_cos(3 * position);
     if (velocity > 0.07) velocity = 0.07;
     if (velocity < -0.07) velocity = -0.07;
     position += velocity;

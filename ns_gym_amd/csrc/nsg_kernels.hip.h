@@ -25,6 +25,9 @@ namespace nsg {
 constexpr int kBlock = 256;
 constexpr int kMaxTableBytes = 16384;
 constexpr int kCntShards = NSG_CNT_SHARDS;
+#ifndef NSG_MIN_WAVES
+#define NSG_MIN_WAVES 1
+#endif
 
 // Device-resident description of one homogeneous env segment (read through scalar loads).
 struct Segment {
@@ -35,6 +38,7 @@ struct Segment {
   const uint64_t* zig;     // ki[256] | wi[256] | fi[256] (global copy)
   int32_t table_bytes;
   int32_t uses_normal;     // some update fn draws normals -> stage the ziggurat tables
+  int32_t simple_theta;    // every update fn is plain arithmetic / table look-up (upd_kind_is_simple)
   int32_t block_begin;     // first block of this segment in a heterogeneous launch
   int32_t block_count;
 };
@@ -127,7 +131,7 @@ template <int ENV> __device__ __forceinline__ void store_obs(float* __restrict__
 // classic-control step for env i (one lane).  `active` = i < N; inactive lanes only take part
 // in the ballots.
 // ============================================================================================
-template <int ENV>
+template <int ENV, bool FULL>
 __device__ __forceinline__ void step_classic(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
                                              const StepOut& out, int64_t i, bool active, WaveCounts& wc) {
   using T = EnvTraits<ENV>;
@@ -167,10 +171,10 @@ __device__ __forceinline__ void step_classic(const Segment& sg, const Tables& tb
       Pcg r = {0, 0, 0, 0};
       int cursor = 0;
       const bool has_cur = upd_uses_cursor(pc.upd_kind);
-      if (pc.uses_rng) pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
+      if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
       if (has_cur) cursor = b.cursor[(int64_t)p * N + i];
-      n = upd_scalar(pc, tb, zg, c, t, r, cursor);
-      if (pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
+      n = upd_scalar<FULL>(pc, tb, zg, c, t, r, cursor);
+      if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
       if (has_cur) b.cursor[(int64_t)p * N + i] = cursor;
       firedmask |= 1u << p;
     }
@@ -389,16 +393,16 @@ __device__ __forceinline__ void step_frozenlake(const Segment& sg, const Tables&
   wc.fired += __popcll(__ballot(fired));
 }
 
-template <int ENV>
+template <int ENV, bool FULL>
 __device__ __forceinline__ void step_any(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
                                          const StepOut& out, int64_t i, bool active, WaveCounts& wc) {
   if constexpr (ENV == NSG_ENV_FROZENLAKE) step_frozenlake(sg, tb, actions, out, i, active, wc);
-  else step_classic<ENV>(sg, tb, zg, actions, out, i, active, wc);
+  else step_classic<ENV, FULL>(sg, tb, zg, actions, out, i, active, wc);
 }
 
 // Homogeneous launch: grid-stride over 256-env chunks.
-template <int ENV>
-__global__ __launch_bounds__(kBlock) void step_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions) {
+template <int ENV, bool FULL>
+__global__ __launch_bounds__(kBlock, NSG_MIN_WAVES) void step_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions) {
   __shared__ LdsTables lds;
   const Segment& sg = *seg;
   Tables tb;
@@ -409,13 +413,14 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const Segment* __restrict_
   const int64_t chunks = (sg.N + kBlock - 1) / kBlock;
   for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
     const int64_t i = c * kBlock + threadIdx.x;
-    step_any<ENV>(sg, tb, zg, actions, out, i, i < sg.N, wc);
+    step_any<ENV, FULL>(sg, tb, zg, actions, out, i, i < sg.N, wc);
   }
   flush_counts(sg, lds, wc);
 }
 
 // Heterogeneous launch: block ranges are assigned to env-type segments, so the env-type switch
 // is uniform per workgroup (no intra-wave divergence between Pendulum and Acrobot lanes).
+template <bool FULL>
 __global__ __launch_bounds__(kBlock) void step_group_kernel(const Segment* __restrict__ segs, int nseg, ActionPtrs acts) {
   __shared__ LdsTables lds;
   int sidx = 0;
@@ -433,12 +438,12 @@ __global__ __launch_bounds__(kBlock) void step_group_kernel(const Segment* __res
     const int64_t i = c * kBlock + threadIdx.x;
     const bool active = i < sg.N;
     switch (sg.cfg.env_type) {
-      case NSG_ENV_CARTPOLE: step_any<NSG_ENV_CARTPOLE>(sg, tb, zg, actions, out, i, active, wc); break;
-      case NSG_ENV_PENDULUM: step_any<NSG_ENV_PENDULUM>(sg, tb, zg, actions, out, i, active, wc); break;
-      case NSG_ENV_ACROBOT: step_any<NSG_ENV_ACROBOT>(sg, tb, zg, actions, out, i, active, wc); break;
-      case NSG_ENV_MOUNTAINCAR: step_any<NSG_ENV_MOUNTAINCAR>(sg, tb, zg, actions, out, i, active, wc); break;
-      case NSG_ENV_MOUNTAINCAR_CONT: step_any<NSG_ENV_MOUNTAINCAR_CONT>(sg, tb, zg, actions, out, i, active, wc); break;
-      default: step_any<NSG_ENV_FROZENLAKE>(sg, tb, zg, actions, out, i, active, wc); break;
+      case NSG_ENV_CARTPOLE: step_any<NSG_ENV_CARTPOLE, FULL>(sg, tb, zg, actions, out, i, active, wc); break;
+      case NSG_ENV_PENDULUM: step_any<NSG_ENV_PENDULUM, FULL>(sg, tb, zg, actions, out, i, active, wc); break;
+      case NSG_ENV_ACROBOT: step_any<NSG_ENV_ACROBOT, FULL>(sg, tb, zg, actions, out, i, active, wc); break;
+      case NSG_ENV_MOUNTAINCAR: step_any<NSG_ENV_MOUNTAINCAR, FULL>(sg, tb, zg, actions, out, i, active, wc); break;
+      case NSG_ENV_MOUNTAINCAR_CONT: step_any<NSG_ENV_MOUNTAINCAR_CONT, FULL>(sg, tb, zg, actions, out, i, active, wc); break;
+      default: step_any<NSG_ENV_FROZENLAKE, FULL>(sg, tb, zg, actions, out, i, active, wc); break;
     }
   }
   flush_counts(sg, lds, wc);
@@ -609,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void theta_trace_kernel(const Segment* __re
         delta = w1_3(th, q);
         th[0] = q[0]; th[1] = q[1]; th[2] = q[2];
       } else {
-        double nvv = upd_scalar(pc, tb, zg, th[0], t, r, cursor);
+        double nvv = upd_scalar<true>(pc, tb, zg, th[0], t, r, cursor);
         delta = nvv - th[0];
         th[0] = nvv;
       }

@@ -1,0 +1,68 @@
+// nsg_math.hip.h — float64 sin/cos for the integrators.
+//
+// The base MDPs call np.sin/np.cos (float64) on bounded arguments: CartPole's pole angle is
+// inside ±0.21 rad whenever a step is taken, Acrobot's joint angles are wrapped to [-π, π]
+// (RK4 stages stray a little beyond), MountainCar evaluates cos(3x) on x in [-1.2, 0.6],
+// Pendulum's angle drifts by at most 8 rad/s * dt per step.  The general-purpose ocml
+// sincos carries a Payne-Hanek path for |x| up to 1e308 whose register footprint caps the
+// kernel's occupancy; this version keeps fdlibm's kernels (|error| < 1 ulp) with a 3-stage
+// Cody-Waite reduction that is exact for |x| < 2^20 * π/2 (≈ 1.6e6 rad) — far beyond anything
+// an episode can reach.  Larger arguments still return values in [-1, 1] (reduced accuracy).
+#pragma once
+#if defined(__HIPCC__)
+#define NSG_HD __host__ __device__ __forceinline__
+#else
+#define NSG_HD inline
+#endif
+#include <math.h>
+
+namespace nsg {
+
+NSG_HD void nsg_sincos(double x, double* sn, double* cs) {
+  const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
+               pio2_1t = 6.07710050650619224932e-11, pio2_2 = 6.07710050630396597660e-11,
+               pio2_2t = 2.02226624879595063154e-21, pio2_3 = 2.02226624871116645580e-21,
+               pio2_3t = 8.47842766036889956997e-32;
+  // argument reduction: x = n*(π/2) + (y0 + y1), |y0| <= π/4.  π/2 = pio2_1 + pio2_2 + pio2_3 + pio2_3t
+  // in 33-bit pieces, so fn*pio2_k is exact for |fn| < 2^20; the two rounded subtractions are
+  // compensated with TwoSum error terms (branch-free equivalent of fdlibm's 3-iteration scheme).
+  const double fn = rint(x * invpio2);
+  const double r1 = x - fn * pio2_1;  // exact (Sterbenz)
+  const double c2 = -(fn * pio2_2);
+  const double r2 = r1 + c2;
+  const double b2 = r2 - r1;
+  const double e2 = (r1 - (r2 - b2)) + (c2 - b2);
+  const double c3 = -(fn * pio2_3);
+  const double r3 = r2 + c3;
+  const double b3 = r3 - r2;
+  const double e3 = (r2 - (r3 - b3)) + (c3 - b3);
+  const double tail = (e2 + e3) - fn * pio2_3t;
+  const double y0 = r3 + tail;
+  const double y1 = (r3 - y0) + tail;
+  (void)pio2_1t; (void)pio2_2t;
+  const int n = (int)fn;
+  // fdlibm __kernel_sin / __kernel_cos on (y0, y1)
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double z = y0 * y0;
+  const double v = z * y0;
+  const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  const double s = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+  const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const double hz = 0.5 * z;
+  const double wc = 1.0 - hz;
+  const double c = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+  switch (n & 3) {
+    case 0: *sn = s; *cs = c; break;
+    case 1: *sn = c; *cs = -s; break;
+    case 2: *sn = -s; *cs = -c; break;
+    default: *sn = -c; *cs = s; break;
+  }
+}
+
+NSG_HD double nsg_sin(double x) { double s, c; nsg_sincos(x, &s, &c); return s; }
+NSG_HD double nsg_cos(double x) { double s, c; nsg_sincos(x, &s, &c); return c; }
+
+}  // namespace nsg

@@ -9,7 +9,7 @@
 
 namespace nsg {
 
-template <int ENV>
+template <int ENV, bool FULL>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions,
                                                          int k_steps, nsg_rollout_out ro) {
   __shared__ LdsTables lds;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const Segment* __restri
       out.env_change = ro.env_change ? ro.env_change + (int64_t)k * P * N : dflt.env_change;
       out.delta_change = ro.delta_change ? ro.delta_change + (int64_t)k * P * N : dflt.delta_change;
       const void* act = FA ? (const void*)((const float*)actions + (int64_t)k * N) : (const void*)((const int32_t*)actions + (int64_t)k * N);
-      step_any<ENV>(sg, tb, zg, act, out, i, i < N, wc);
+      step_any<ENV, FULL>(sg, tb, zg, act, out, i, i < N, wc);
     }
   }
   flush_counts(sg, lds, wc);

@@ -41,7 +41,18 @@ __device__ __forceinline__ bool sched_fire(const nsg_param_cfg& pc, const Tables
   }
 }
 
+// Which update kinds need the "full" θ-engine build (float64 exp/sin/log1p from the device
+// library + the ziggurat sampler).  Batches whose update fns are all plain arithmetic /
+// table look-ups run a kernel instantiated without those paths: its register footprint is
+// much smaller, so more wavefronts stay resident to cover HBM latency.
+__host__ __device__ inline bool upd_kind_is_simple(int k) {
+  return k == NSG_UPD_INCREMENT || k == NSG_UPD_DECREMENT || k == NSG_UPD_TREND || k == NSG_UPD_POLY ||
+         k == NSG_UPD_GEOMETRIC || k == NSG_UPD_LERP || k == NSG_UPD_STEPWISE || k == NSG_UPD_CYCLIC ||
+         k == NSG_UPD_NOUPDATE || k >= NSG_UPD_D_INCREMENT;
+}
+
 // UpdateFn._update for the scalar classes.  `rng` is touched only by the stochastic kinds.
+template <bool FULL>
 __device__ inline double upd_scalar(const nsg_param_cfg& pc, const Tables& tb, const ZigLds& zg, double th, int t,
                                     Pcg& rng, int& cursor) {
   const double* u = pc.u;
@@ -60,11 +71,13 @@ __device__ inline double upd_scalar(const nsg_param_cfg& pc, const Tables& tb, c
       return th + trend;
     }
     case NSG_UPD_GEOMETRIC: return th * u[0];
-    case NSG_UPD_EXPDECAY: return th * exp(-u[0] * td);
-    case NSG_UPD_OSCILLATING: return th + u[0] * sin(td);
+    case NSG_UPD_EXPDECAY: if constexpr (FULL) return th * exp(-u[0] * td); else return th;
+    case NSG_UPD_OSCILLATING: if constexpr (FULL) return th + u[0] * sin(td); else return th;
     case NSG_UPD_SIGMOID: {
-      double sg = 1.0 / (1.0 + exp(-u[2] * (td - u[3])));
-      return u[0] + (u[1] - u[0]) * sg;
+      if constexpr (FULL) {
+        double sg = 1.0 / (1.0 + exp(-u[2] * (td - u[3])));
+        return u[0] + (u[1] - u[0]) * sg;
+      } else return th;
     }
     case NSG_UPD_LERP: {
       double frac = td / u[2];
@@ -81,27 +94,33 @@ __device__ inline double upd_scalar(const nsg_param_cfg& pc, const Tables& tb, c
       return v;
     }
     case NSG_UPD_NOUPDATE: return th;
-    case NSG_UPD_RANDOMWALK: return th + pcg_normal(rng, zg, u[0], u[1]);
-    case NSG_UPD_RW_DRIFT: {
-      double w = pcg_normal(rng, zg, u[1], u[2]);
-      return u[0] + th + w;
-    }
-    case NSG_UPD_RW_DRIFT_TREND: {
-      double w = pcg_normal(rng, zg, u[1], u[2]);
-      return u[0] + th + w + u[3] * td;
-    }
-    case NSG_UPD_OU: {
-      double noise = u[2] > 0 ? pcg_normal(rng, zg, 0.0, u[2]) : 0.0;
-      return th + u[0] * (u[1] - th) + noise;
-    }
-    case NSG_UPD_BOUNDED_RW: {
-      double v = th + pcg_normal(rng, zg, u[0], u[1]);
-      if (v < u[2]) v = u[2];
-      if (v > u[3]) v = u[3];
-      return v;
-    }
-    default: return th;
+    default: break;
   }
+  if constexpr (FULL) {
+    switch (pc.upd_kind) {
+      case NSG_UPD_RANDOMWALK: return th + pcg_normal(rng, zg, u[0], u[1]);
+      case NSG_UPD_RW_DRIFT: {
+        double w = pcg_normal(rng, zg, u[1], u[2]);
+        return u[0] + th + w;
+      }
+      case NSG_UPD_RW_DRIFT_TREND: {
+        double w = pcg_normal(rng, zg, u[1], u[2]);
+        return u[0] + th + w + u[3] * td;
+      }
+      case NSG_UPD_OU: {
+        double noise = u[2] > 0 ? pcg_normal(rng, zg, 0.0, u[2]) : 0.0;
+        return th + u[0] * (u[1] - th) + noise;
+      }
+      case NSG_UPD_BOUNDED_RW: {
+        double v = th + pcg_normal(rng, zg, u[0], u[1]);
+        if (v < u[2]) v = u[2];
+        if (v > u[3]) v = u[3];
+        return v;
+      }
+      default: break;
+    }
+  }
+  return th;
 }
 
 __device__ __forceinline__ bool upd_uses_cursor(int kind) {

@@ -189,7 +189,11 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
   h->host.zig = h->d_zig;
   h->host.table_bytes = (int32_t)table_bytes;
   h->host.uses_normal = 0;
-  for (int p = 0; p < cfg->n_params; p++) h->host.uses_normal |= cfg->params[p].uses_rng;
+  h->host.simple_theta = 1;
+  for (int p = 0; p < cfg->n_params; p++) {
+    h->host.uses_normal |= cfg->params[p].uses_rng;
+    if (!upd_kind_is_simple(cfg->params[p].upd_kind)) h->host.simple_theta = 0;
+  }
   h->host.block_begin = 0;
   h->host.block_count = 0;
   *out = h;
@@ -246,8 +250,13 @@ int nsg_step(nsg_handle* h, const void* actions_dev, void* stream) {
   if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
   if (!actions_dev) return fail(NSG_EINVAL, "actions_dev is NULL");
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_ENV(h->host.cfg.env_type,
-               hipLaunchKernelGGL(step_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, actions_dev));
+  if (h->host.simple_theta) {
+    DISPATCH_ENV(h->host.cfg.env_type,
+                 hipLaunchKernelGGL((step_kernel<E, false>), dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, actions_dev));
+  } else {
+    DISPATCH_ENV(h->host.cfg.env_type,
+                 hipLaunchKernelGGL((step_kernel<E, true>), dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, actions_dev));
+  }
   HIP_TRY(hipGetLastError());
   return NSG_OK;
 }
@@ -260,8 +269,13 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
   memset(&o, 0, sizeof(o));
   if (out) o = *out;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_ENV(h->host.cfg.env_type,
-               hipLaunchKernelGGL(rollout_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, actions_dev, k_steps, o));
+  if (h->host.simple_theta) {
+    DISPATCH_ENV(h->host.cfg.env_type,
+                 hipLaunchKernelGGL((rollout_kernel<E, false>), dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, actions_dev, k_steps, o));
+  } else {
+    DISPATCH_ENV(h->host.cfg.env_type,
+                 hipLaunchKernelGGL((rollout_kernel<E, true>), dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, actions_dev, k_steps, o));
+  }
   HIP_TRY(hipGetLastError());
   return NSG_OK;
 }
@@ -274,6 +288,7 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
   static thread_local nsg_handle* members[NSG_MAX_SEGMENTS];
   static thread_local int n_members = 0;
   static thread_local int total_blocks = 0;
+  static thread_local int all_simple = 0;
   bool same = n_members == n_handles;
   for (int k = 0; same && k < n_handles; k++) same = members[k] == hs[k];
   if (!same) {
@@ -291,6 +306,8 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
     for (int k = 0; k < n_handles; k++) members[k] = hs[k];
     n_members = n_handles;
     total_blocks = begin;
+    all_simple = 1;
+    for (int k = 0; k < n_handles; k++) all_simple &= hs[k]->host.simple_theta;
   }
   ActionPtrs ap;
   memset(&ap, 0, sizeof(ap));
@@ -298,7 +315,8 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
     if (!actions_dev[k]) return fail(NSG_EINVAL, "actions_dev[%d] is NULL", k);
     ap.p[k] = actions_dev[k];
   }
-  hipLaunchKernelGGL(step_group_kernel, dim3(total_blocks), dim3(kBlock), 0, (hipStream_t)stream, d_group, n_handles, ap);
+  if (all_simple) hipLaunchKernelGGL(step_group_kernel<false>, dim3(total_blocks), dim3(kBlock), 0, (hipStream_t)stream, d_group, n_handles, ap);
+  else hipLaunchKernelGGL(step_group_kernel<true>, dim3(total_blocks), dim3(kBlock), 0, (hipStream_t)stream, d_group, n_handles, ap);
   HIP_TRY(hipGetLastError());
   return NSG_OK;
 }

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Kernel timing harness (GPU box): average device time per nsg_step launch for the
+BASELINE.json configurations, measured with hipEvents over back-to-back launches."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from ns_gym_amd import make  # noqa: E402
+from ns_gym_amd.schedulers import ContinuousScheduler, DiscreteScheduler, PeriodicScheduler  # noqa: E402
+from ns_gym_amd.update_functions import DistributionStepWiseUpdate, IncrementUpdate, RandomWalk  # noqa: E402
+from ns_gym_amd.vec_env import VecNSEnv, step_group  # noqa: E402
+
+# algorithmic bytes per env-step, fp64-internal variants of SURVEY §8(d)
+WORK = {
+    "c1": ("CartPole-v1", lambda: {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)}, {}, 120),
+    "c2": ("CartPole-v1", lambda: {"gravity": RandomWalk(PeriodicScheduler(period=3))}, {}, 157),
+    "c3": ("FrozenLake-v1", lambda: {"P": DistributionStepWiseUpdate(DiscreteScheduler({50}), [[0.6, 0.2, 0.2]])},
+           {"map_name": "8x8"}, 96),
+    "pend": ("Pendulum-v1", lambda: {"m": IncrementUpdate(ContinuousScheduler(), k=0.01)}, {}, 83),
+    "acro": ("Acrobot-v1", lambda: {"LINK_MASS_2": IncrementUpdate(ContinuousScheduler(), k=0.1)}, {}, 127),
+}
+
+
+def mk(name, n, track=True):
+    env_id, tp, mkw, _ = WORK[name]
+    kw = dict(change_notification=True, delta_change_notification=True, track_returns=track)
+    if env_id == "FrozenLake-v1":
+        kw["initial_prob_dist"] = [1.0, 0.0, 0.0]
+    e = VecNSEnv(make(env_id, **mkw), tp(), n, **kw)
+    e.reset(seed=0)
+    return e
+
+
+def actions(e, n):
+    if e.action_is_float:
+        return (torch.rand(n, device="cuda") * 4 - 2).float()
+    return torch.randint(0, e.n_actions, (n,), dtype=torch.int32, device="cuda")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=1 << 20)
+    ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--work", default="c1,c2,c3,pend,acro")
+    ap.add_argument("--no-track", action="store_true")
+    args = ap.parse_args()
+    res = {}
+    for name in args.work.split(","):
+        n = args.n
+        e = mk(name, n, track=not args.no_track)
+        a = actions(e, n)
+        for _ in range(30):
+            e.step(a)
+        torch.cuda.synchronize()
+        ms = min(e.time_steps(a, args.iters) for _ in range(3))
+        gbs = WORK[name][3] * n / (ms * 1e-3) / 1e9
+        res[name] = {"us": ms * 1e3, "GB/s": gbs, "frac": gbs / 8000, "Gsteps/s": n / (ms * 1e-3) / 1e9}
+        print(name, json.dumps(res[name]), flush=True)
+        e.close()
+    if "pend" in args.work and "acro" in args.work:  # C4: heterogeneous launch, 2^18 each
+        n = 1 << 18
+        ep, ea = mk("pend", n), mk("acro", n)
+        ap_, aa = actions(ep, n), actions(ea, n)
+        for _ in range(20):
+            step_group([ep, ea], [ap_, aa])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            step_group([ep, ea], [ap_, aa])
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.iters
+        gbs = (83 + 127) * n / (ms * 1e-3) / 1e9
+        print("c4_group", json.dumps({"us": ms * 1e3, "GB/s": gbs, "frac": gbs / 8000, "Gsteps/s": 2 * n / (ms * 1e-3) / 1e9}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
