@@ -152,7 +152,8 @@ def main():
             },
         }
         if not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
+            # the GPU box exposes 256 logical CPUs but one GPU's share is 16 cores
+            threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
             cpu_baseline(1 << 14, 8, threads)  # warm the OpenMP pool / page in the oracle
             # bounded sample of the same workload: 2^18 envs x 40 steps (scaled down from 2^20 x K)
             v, secs = cpu_baseline(1 << 18, 40, threads)

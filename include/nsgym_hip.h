@@ -271,6 +271,11 @@ int nsg_compact_done(nsg_handle* h, int32_t* idx_out_dev, uint64_t* count_out_de
  * with hipEvents on `stream` (synchronises; not for use inside graph capture). */
 int nsg_time_steps(nsg_handle* h, const void* actions_dev, int32_t iters, void* stream, float* ms_avg);
 
+/* Counter calibration helper (MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE must be calibrated
+ * on a known byte count in the kernel's own access width): streams n float64 from src to dst
+ * with one 8-byte access per lane, the access shape of the step kernels' state rows. */
+int nsg_calib_copy_f64(const double* src_dev, double* dst_dev, int64_t n, void* stream);
+
 int nsg_destroy(nsg_handle* h);
 
 #ifdef __cplusplus

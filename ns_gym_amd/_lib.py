@@ -8,13 +8,13 @@ import os
 from . import _abi as A
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libnsgym_hip.so")
+LIB_PATH = os.environ.get("NSG_LIB", os.path.join(_PKG, "libnsgym_hip.so"))  # NSG_LIB: experiment builds (tools/kbench.py)
 _lib = None
 
 EXPORTS = [
     "nsg_abi_version", "nsg_last_error", "nsg_sizeof_config", "nsg_sizeof_buffers", "nsg_sizeof_layout",
     "nsg_layout_query", "nsg_create", "nsg_bind", "nsg_reset", "nsg_step", "nsg_rollout", "nsg_step_group",
-    "nsg_compact_done", "nsg_theta_trace", "nsg_rng_fill", "nsg_time_steps", "nsg_destroy",
+    "nsg_compact_done", "nsg_theta_trace", "nsg_rng_fill", "nsg_time_steps", "nsg_calib_copy_f64", "nsg_destroy",
 ]
 
 
@@ -66,6 +66,7 @@ def load():
     lib.nsg_theta_trace.argtypes = [vp, i32, i32, i32, i32, vp, u64p, vp, vp, vp, vp]
     lib.nsg_rng_fill.argtypes = [i32, vp, i32, i32, i32, vp, vp, vp]
     lib.nsg_time_steps.argtypes = [vp, vp, i32, vp, C.POINTER(C.c_float)]
+    lib.nsg_calib_copy_f64.argtypes = [vp, vp, i64, vp]
     lib.nsg_destroy.argtypes = [vp]
     for f in EXPORTS[5:]:
         getattr(lib, f).restype = C.c_int

@@ -227,13 +227,21 @@ __device__ __forceinline__ void step_classic(const Segment& sg, const Tables& tb
   double reward = 0.0;
   bool term = false, trunc = false;
   int tnew = 0;
+#ifdef NSG_EXP_NORESET  // timing experiment only: skip the divergent reset draw
+  if (false) {
+#else
   if (do_reset) {
+#endif
     Pcg g;
     pcg_load(b.rng_env, N, i, g);
     env_reset_draw<ENV>(g, s);
     pcg_store_state(b.rng_env, N, i, g);
   } else if (do_step) {
+#ifdef NSG_EXP_NOPHYS   // timing experiment only: no integrator arithmetic
+    s[0] += th[0] * 1e-9; reward = 1.0; term = s[0] > 1e30;
+#else
     term = env_step<ENV>(th, s, ai, af, reward);
+#endif
     tnew = t + 1;                                                      // base.py:314
     trunc = cfg.max_episode_steps > 0 && tnew >= cfg.max_episode_steps;  // TimeLimit [UPSTREAM]
   }
@@ -647,6 +655,10 @@ __global__ __launch_bounds__(kBlock) void rng_fill_kernel(int kind, const uint64
     else if (kind == 1) ((double*)out)[(int64_t)k * n + i] = pcg_double(r);
     else ((double*)out)[(int64_t)k * n + i] = pcg_std_normal(r, zg);
   }
+}
+
+__global__ __launch_bounds__(kBlock) void calib_copy_f64_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) dst[i] = src[i] + 1.0;
 }
 
 }  // namespace nsg

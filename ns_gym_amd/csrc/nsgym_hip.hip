@@ -384,6 +384,13 @@ int nsg_time_steps(nsg_handle* h, const void* actions_dev, int32_t iters, void* 
   return NSG_OK;
 }
 
+int nsg_calib_copy_f64(const double* src_dev, double* dst_dev, int64_t n, void* stream) {
+  if (!src_dev || !dst_dev || n <= 0) return fail(NSG_EINVAL, "bad calib arguments");
+  hipLaunchKernelGGL(calib_copy_f64_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, src_dev, dst_dev, n);
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
 int nsg_destroy(nsg_handle* h) {
   if (!h) return NSG_OK;
   if (h->d_tables) (void)hipFree(h->d_tables);

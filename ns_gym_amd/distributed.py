@@ -41,6 +41,10 @@ def all_gather_returns(env, group=None) -> torch.Tensor:
         out = torch.empty(world * sizes[0], dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
         return out
-    parts = [torch.empty(s, dtype=local.dtype, device=local.device) for s in sizes]
-    dist.all_gather(parts, local.contiguous(), group=group)
-    return torch.cat(parts)
+    # ragged shards (total_envs % world != 0): pad to the largest shard, gather, drop the padding
+    m = max(sizes)
+    padded = torch.zeros(m, dtype=local.dtype, device=local.device)
+    padded[: local.numel()] = local
+    out = torch.empty(world * m, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * m: r * m + sizes[r]] for r in range(world)])

@@ -1,0 +1,260 @@
+"""Single-env adaptors with the reference's class names and call signatures.
+
+`NSClassicControlWrapper` / `NSFrozenLakeWrapper` wrap a `VecNSEnv` with N = 1 and return
+exactly what the reference wrappers return for one env: the NS observation dict with Python /
+NumPy scalars, a float (or `Reward`) reward, Python bools, and the info dict
+(ns_gym/wrappers/classic_control.py:60-109, ns_gym/wrappers/toy_text.py:342-399,
+ns_gym/base.py:296-410).  They exist so that code written against the reference runs
+unchanged (BASELINE config C1); throughput comes from `VecNSEnv` with large N.
+
+Every value comes from the HIP kernels; reading it back synchronises the stream.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Any, Union
+
+import numpy as np
+import torch
+
+from . import _abi as A
+from .base import Reward
+from .envs import BaseEnvSpec, from_gym_env
+from .vec_env import ConstraintViolationWarning, VecNSEnv
+
+__all__ = ["NSClassicControlWrapper", "NSFrozenLakeWrapper", "ConstraintViolationWarning"]
+
+
+class _Space:
+    """Minimal stand-in for gymnasium.spaces (gymnasium is optional at run time)."""
+
+    def __init__(self, n=None, low=None, high=None, shape=(), dtype=np.float32, seed=None):
+        self.n, self.low, self.high, self.shape, self.dtype = n, low, high, shape, dtype
+        self._rng = np.random.default_rng(seed)
+
+    def sample(self):
+        if self.n is not None:
+            return int(self._rng.integers(self.n))
+        return self._rng.uniform(self.low, self.high, size=self.shape).astype(self.dtype)
+
+    def seed(self, seed=None):
+        self._rng = np.random.default_rng(seed)
+
+
+class _Unwrapped:
+    """`env.unwrapped.<attr>` of the reference: live view of the base env's attributes."""
+
+    def __init__(self, owner: "_NSSingle"):
+        object.__setattr__(self, "_o", owner)
+
+    def __getattr__(self, name):
+        o = self._o
+        et = o.spec.env_type
+        if name == "__class__":
+            return type(self)
+        if name in et.theta_names and not o._vec.is_frozenlake:
+            if name in o._vec.param_names:
+                return float(o._vec.theta[o._vec.param_names.index(name), 0].item())
+            return float(o._vec.cfg.base_theta[et.theta_names.index(name)])
+        if et.class_name == "CartPoleEnv" and name == "total_mass":
+            return self.masspole + self.masscart            # classic_control.py:426-435
+        if et.class_name == "CartPoleEnv" and name == "polemass_length":
+            return self.length * self.masspole              # classic_control.py:436-444
+        if name == "state" and not o._vec.is_frozenlake:
+            return o._vec.phys[:, 0].cpu().numpy().copy()
+        if name == "s" and o._vec.is_frozenlake:
+            return int(o._vec.state[0].item())
+        if name == "P" and o._vec.is_frozenlake:
+            return o._build_P()
+        if name in ("nrow", "ncol") and o._vec.is_frozenlake:
+            return int(getattr(o._vec.cfg, name))
+        if name == "desc" and o._vec.is_frozenlake:
+            return np.asarray(o.spec.desc, dtype="c")
+        raise AttributeError(name)
+
+    @property
+    def spec(self):
+        return self._o.spec
+
+
+class _NSSingle:
+    """Shared N = 1 plumbing (NSWrapper surface, ns_gym/base.py:206-502)."""
+
+    def __init__(self, env, tunable_params, change_notification=False, delta_change_notification=False,
+                 in_sim_change=False, **kwargs: Any):
+        self.spec: BaseEnvSpec = from_gym_env(env)
+        self._vec = VecNSEnv(self.spec, tunable_params, 1, change_notification=change_notification,
+                             delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
+                             **kwargs)
+        v = self._vec
+        self.tunable_params = tunable_params
+        self.change_notification = change_notification
+        self.delta_change_notification = delta_change_notification
+        self.in_sim_change = in_sim_change
+        self.scalar_reward = v.scalar_reward
+        self.persistent_params = v.persistent_params
+        self.unwrapped = _Unwrapped(self)
+        self.delta_t = 1
+        et = self.spec.env_type
+        if et.n_actions:
+            self.action_space = _Space(n=et.n_actions)
+        else:
+            self.action_space = _Space(low=et.action_low, high=et.action_high, shape=(1,))
+        self._done = False
+
+    # state mirrored from the vector env
+    t = property(lambda self: int(self._vec.t[0].item()))
+    has_reset = property(lambda self: self._vec.has_reset)
+    frozen = property(lambda self: self._vec.frozen)
+    is_sim_env = property(lambda self: self._vec.is_sim_env)
+
+    def _scalars(self, obs, info):
+        names = self._vec.param_names
+        state = obs["state"]
+        if self._vec.is_frozenlake:
+            st = int(state[0].item())
+        else:
+            st = state[0].cpu().numpy().copy()
+        out = {
+            "state": st,
+            "env_change": {p: int(obs["env_change"][p][0].item()) for p in names},
+            "delta_change": {p: float(obs["delta_change"][p][0].item()) for p in names},
+            "relative_time": int(obs["relative_time"][0].item()),
+        }
+        inf = {
+            "Ground Truth Env Change": {p: int(info["Ground Truth Env Change"][p][0].item()) for p in names},
+            "Ground Truth Delta Change": {p: float(info["Ground Truth Delta Change"][p][0].item()) for p in names},
+        }
+        return out, inf
+
+    def reset(self, *, seed: int | None = None, options: dict | None = None):
+        obs, info = self._vec.reset(seed=None if seed is None else [int(seed)], options=options)
+        self._done = False
+        o, inf = self._scalars(obs, info)
+        # the reference's reset info carries the zero dicts (base.py:397-408)
+        return o, inf
+
+    def _step(self, action):
+        if self._vec.action_is_float:
+            a = torch.tensor([float(np.asarray(action, dtype=np.float64).reshape(-1)[0])], dtype=torch.float32)
+        else:
+            a = torch.tensor([int(action)], dtype=torch.int32)
+        obs, rew, term, trunc, info = self._vec.step(a)
+        o, inf = self._scalars(obs, info)
+        r = float(rew[0].item())
+        terminated, truncated = bool(term[0].item()), bool(trunc[0].item())
+        if self.spec.class_name != "FrozenLakeEnv":
+            self._vec.check_constraints()  # aggregated ConstraintViolationWarning (classic_control.py:212-234)
+        if not self.scalar_reward:
+            r = Reward(reward=r, env_change=o["env_change"], delta_change=o["delta_change"],
+                       relative_time=o["relative_time"])
+        return o, r, terminated, truncated, inf
+
+    def freeze(self, mode: bool = True):
+        self._vec.freeze(mode)
+        return self
+
+    def unfreeze(self):
+        return self.freeze(False)
+
+    def get_default_params(self):
+        return self._vec.get_default_params()
+
+    def get_planning_env(self):
+        assert self.has_reset, "The environment must be reset before getting the planning environment."
+        raise NotImplementedError("planning-env snapshots are the next scope row (SURVEY §8(f) rank 1)")
+
+    def __deepcopy__(self, memo):
+        raise NotImplementedError("planning-env snapshots are the next scope row (SURVEY §8(f) rank 1)")
+
+    def close(self):
+        self._vec.close()
+
+
+class NSClassicControlWrapper(_NSSingle):
+    """Non-stationary wrapper for the classic-control envs
+    (ns_gym/wrappers/classic_control.py:15-109), N = 1 view of the fused HIP stepper."""
+
+    def __init__(self, env, tunable_params, change_notification: bool = False,
+                 delta_change_notification: bool = False, in_sim_change: bool = False, **kwargs: Any):
+        spec = from_gym_env(env)
+        from .envs import TUNABLE_PARAMS
+
+        assert spec.class_name in TUNABLE_PARAMS.keys() and spec.class_name != "FrozenLakeEnv", (
+            f"{spec.class_name} is not a supported environment"
+        )
+        for key in tunable_params.keys():
+            assert key in TUNABLE_PARAMS[spec.class_name].keys(), (
+                f"{key} is not a tunable parameter for {spec.class_name}"
+            )
+        super().__init__(spec, tunable_params, change_notification, delta_change_notification, in_sim_change, **kwargs)
+        self.initial_params = {k: getattr(self.unwrapped, k) for k in tunable_params.keys()}
+
+    def step(self, action: Union[float, int]):
+        obs, reward, terminated, truncated, info = self._step(action)
+        info["prob"] = 1.0  # classic_control.py:98
+        return obs, reward, terminated, truncated, info
+
+
+class NSFrozenLakeWrapper(_NSSingle):
+    """Non-stationary FrozenLake wrapper (ns_gym/wrappers/toy_text.py:265-399), N = 1 view."""
+
+    def __init__(self, env, tunable_params, change_notification: bool = False,
+                 delta_change_notification: bool = False, in_sim_change: bool = False,
+                 initial_prob_dist=[1, 0, 0], modified_rewards: Union[dict, None] = None, **kwargs: Any):
+        spec = from_gym_env(env)
+        assert spec.class_name == "FrozenLakeEnv", f"{spec.class_name} is not a FrozenLake environment"
+        super().__init__(spec, tunable_params, change_notification, delta_change_notification, in_sim_change,
+                         initial_prob_dist=initial_prob_dist, modified_rewards=modified_rewards, **kwargs)
+        self.initial_prob_dist = initial_prob_dist
+        self.modified_rewards = modified_rewards
+        self.ncol, self.nrow = int(self._vec.cfg.ncol), int(self._vec.cfg.nrow)
+        self.nA, self.nS = 4, self.ncol * self.nrow
+        self.LEFT, self.DOWN, self.RIGHT, self.UP = 0, 1, 2, 3
+
+    @property
+    def transition_prob(self):
+        return [float(x) for x in self._vec.theta[:, 0].tolist()]
+
+    def step(self, action: int):
+        obs, reward, terminated, truncated, info = self._step(action)
+        info["prob"] = float(self._vec.prob[0].item())
+        info["transition_prob"] = self.transition_prob  # toy_text.py:379
+        return obs, reward, terminated, truncated, info
+
+    def reset(self, *, seed: int | None = None, options: dict | None = None):
+        obs, info = super().reset(seed=seed, options=options)
+        info["prob"] = 1
+        return obs, info
+
+    def _build_P(self):
+        """The transition table the wrapper installs on the base env (toy_text.py:426-469),
+        rebuilt on demand from the device-side table probabilities."""
+        tp = [float(x) for x in self._vec.table_prob[:, 0].tolist()]
+        desc = self.spec.desc
+        P = {s: {a: [] for a in range(4)} for s in range(self.nS)}
+
+        def inc(row, col, a):
+            if a == 0:
+                col = max(col - 1, 0)
+            elif a == 1:
+                row = min(row + 1, self.nrow - 1)
+            elif a == 2:
+                col = min(col + 1, self.ncol - 1)
+            elif a == 3:
+                row = max(row - 1, 0)
+            return row, col
+
+        for row in range(self.nrow):
+            for col in range(self.ncol):
+                s = row * self.ncol + col
+                for a in range(4):
+                    if desc[row][col] in "GH":
+                        P[s][a].append((1.0, s, 0, True))
+                        continue
+                    for ind, b in enumerate([a, (a + 1) % 4, (a - 1) % 4]):
+                        nr, nc = inc(row, col, b)
+                        letter = desc[nr][nc]
+                        rew = float(self.modified_rewards[letter]) if self.modified_rewards else float(letter == "G")
+                        P[s][a].append((tp[ind], nr * self.ncol + nc, rew, letter in "GH"))
+        return P

@@ -1,0 +1,166 @@
+"""Host-side mirror of the reference interface: constructor validation and error behaviour
+(AssertionError / TypeError types of ns_gym/base.py:252-261, schedulers.py:66-71,
+wrappers/toy_text.py:329-334), config compilation, table building.  No GPU, no oracle."""
+import numpy as np
+import pytest
+
+from ns_gym_amd import TUNABLE_PARAMS, make
+from ns_gym_amd import _abi as A
+from ns_gym_amd.base import Scheduler, TableBuilder
+from ns_gym_amd.schedulers import (BurstScheduler, ContinuousScheduler, CustomScheduler, DiscreteScheduler,
+                                   PeriodicScheduler, RandomScheduler, WindowScheduler)
+from ns_gym_amd.spec import compile_config
+from ns_gym_amd.update_functions import (CyclicUpdate, DistributionStepWiseUpdate, IncrementUpdate, RandomWalk,
+                                         StepWiseUpdate)
+
+
+def test_tunable_params_match_reference_defaults():
+    # docs/source/env_pages/classic_control/*.md of the reference; SURVEY §8(a) a18
+    assert TUNABLE_PARAMS["CartPoleEnv"] == {"gravity": 9.8, "masscart": 1.0, "masspole": 0.1, "force_mag": 10.0,
+                                             "tau": 0.02, "length": 0.5}
+    assert TUNABLE_PARAMS["PendulumEnv"] == {"m": 1.0, "l": 1.0, "dt": 0.05, "g": 10.0}
+    assert list(TUNABLE_PARAMS["AcrobotEnv"]) == ["dt", "LINK_LENGTH_1", "LINK_LENGTH_2", "LINK_MASS_1", "LINK_MASS_2",
+                                                  "LINK_COM_POS_1", "LINK_COM_POS_2", "LINK_MOI"]
+    assert TUNABLE_PARAMS["MountainCarEnv"] == {"gravity": 0.0025, "force": 0.001}
+    assert TUNABLE_PARAMS["Continuous_MountainCarEnv"] == {"power": 0.0015}
+    assert list(TUNABLE_PARAMS["FrozenLakeEnv"]) == ["P"]
+
+
+def test_update_fn_requires_scheduler_instance():
+    with pytest.raises(AssertionError):
+        IncrementUpdate("not a scheduler", k=1)
+
+
+def test_delta_notification_requires_change_notification():
+    with pytest.raises(AssertionError):
+        compile_config(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), 0.1)},
+                       change_notification=False, delta_change_notification=True)
+
+
+def test_unknown_parameter_name_rejected():
+    with pytest.raises(AssertionError):
+        compile_config(make("CartPole-v1"), {"not_a_param": IncrementUpdate(ContinuousScheduler(), 0.1)})
+    with pytest.raises(AssertionError):
+        compile_config(make("Pendulum-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), 0.1)})
+    with pytest.raises(KeyError):
+        make("Ant-v5")
+
+
+def test_frozenlake_distribution_asserts():
+    fn = lambda: DistributionStepWiseUpdate(ContinuousScheduler(), [[0.6, 0.2, 0.2]])  # noqa: E731
+    with pytest.raises(AssertionError):
+        compile_config(make("FrozenLake-v1"), {"P": fn()}, initial_prob_dist=[0.5, 0.2, 0.2])
+    with pytest.raises(AssertionError):
+        compile_config(make("FrozenLake-v1"), {"P": fn()}, initial_prob_dist=[0.5, 0.5])
+    with pytest.raises(AssertionError):
+        compile_config(make("FrozenLake-v1"), {"P": IncrementUpdate(ContinuousScheduler(), 0.1)})
+    with pytest.raises(ValueError):
+        compile_config(make("FrozenLake-v1"), {"P": DistributionStepWiseUpdate(ContinuousScheduler(), [[0.5, 0.5]])})
+
+
+def test_discrete_scheduler_ctor_asserts():
+    with pytest.raises(AssertionError):
+        DiscreteScheduler({1, 5}, start=3)
+    with pytest.raises(AssertionError):
+        DiscreteScheduler({1, 50}, end=10)
+    with pytest.raises(ValueError):  # min() of empty set, like the reference (schedulers.py:66)
+        DiscreteScheduler(set())
+
+
+def test_config_compilation_cartpole():
+    tp = {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1), "gravity": RandomWalk(PeriodicScheduler(3), seed=5)}
+    cfg, blob, spec, names = compile_config(make("CartPole-v1"), tp, change_notification=True,
+                                            delta_change_notification=True, persistent_params=True)
+    assert names == ["masspole", "gravity"]
+    assert cfg.env_type == A.ENV_CARTPOLE and cfg.n_params == 2 and cfg.max_episode_steps == 500
+    assert cfg.flags == A.F_CHANGE_NOTIFICATION | A.F_DELTA_NOTIFICATION | A.F_PERSISTENT_PARAMS
+    assert list(cfg.base_theta)[:6] == [9.8, 1.0, 0.1, 10.0, 0.02, 0.5]
+    p0, p1 = cfg.params[0], cfg.params[1]
+    assert (p0.theta_slot, p0.sched_kind, p0.upd_kind, p0.rng_child, p0.uses_rng) == (2, A.SCHED_CONTINUOUS, A.UPD_INCREMENT, 0, 0)
+    assert p0.u[0] == 0.1 and p0.sched_start == 0.0 and p0.sched_end == float("inf")
+    assert (p1.theta_slot, p1.sched_kind, p1.upd_kind, p1.rng_child, p1.uses_rng) == (0, A.SCHED_PERIODIC, A.UPD_RANDOMWALK, 1, 1)
+    assert p1.sched_i0 == 3 and (p1.u[0], p1.u[1]) == (0.0, 1.0) and p1.has_fn_seed == 1 and p1.fn_seed == 5
+
+
+def test_bit_and_value_tables():
+    tb = TableBuilder()
+    off, ln = tb.add_bits([0, 1, 0, 0, 1] + [0] * 40 + [1])
+    words = np.frombuffer(tb.blob(), dtype=np.uint32)
+    assert ln == 46 and words[off] == 0b10010 and words[off + 1] == 1 << (45 - 32)
+    voff, vlen = tb.add_values([1.5, 2.5, -3.0])
+    vals = np.frombuffer(tb.blob(), dtype=np.float64)
+    assert vlen == 3 and list(vals[voff:voff + 3]) == [1.5, 2.5, -3.0]
+    assert len(tb.blob()) % 8 == 0
+
+
+def _table_bits(cfg, blob, p=0):
+    pc = cfg.params[p]
+    words = np.frombuffer(blob, dtype=np.uint32)[pc.sched_tab_off:]
+    return [(int(words[t >> 5]) >> (t & 31)) & 1 for t in range(pc.sched_tab_len)], pc
+
+
+def test_table_schedulers_compile_to_reference_fire_patterns():
+    mk = lambda s: compile_config(make("CartPole-v1"), {"gravity": IncrementUpdate(s, 1.0)})  # noqa: E731
+    cfg, blob, _, _ = mk(DiscreteScheduler({1, 7, 8, 50}))
+    bits, pc = _table_bits(cfg, blob)
+    assert pc.sched_kind == A.SCHED_TABLE and [t for t, b in enumerate(bits) if b] == [1, 7, 8, 50] and pc.sched_i0 == 0
+    cfg, blob, _, _ = mk(WindowScheduler([(2, 4), (10, 10), (30, np.inf)], start=3, end=50))
+    bits, pc = _table_bits(cfg, blob)
+    assert [t for t, b in enumerate(bits) if b][:5] == [2, 3, 4, 10, 30] and pc.sched_i0 == 1
+    assert (pc.sched_start, pc.sched_end) == (3.0, 50.0)
+    cfg, blob, _, _ = mk(CustomScheduler(lambda t: t % 7 == 3))
+    bits, pc = _table_bits(cfg, blob)
+    assert pc.sched_tab_len == 501 and [t for t, b in enumerate(bits) if b][:3] == [3, 10, 17]  # horizon = TimeLimit 500
+    cfg, _, _, _ = mk(BurstScheduler(3, 2, start=1))
+    assert (cfg.params[0].sched_kind, cfg.params[0].sched_i0, cfg.params[0].sched_i1) == (A.SCHED_BURST, 3, 2)
+
+
+def test_value_list_update_fns_and_unsupported_kinds():
+    cfg, blob, _, _ = compile_config(make("CartPole-v1"), {"length": StepWiseUpdate(ContinuousScheduler(), [1.5, 0.7]),
+                                                           "tau": CyclicUpdate(ContinuousScheduler(), [0.01, 0.03])})
+    vals = np.frombuffer(blob, dtype=np.float64)
+    p0, p1 = cfg.params[0], cfg.params[1]
+    assert list(vals[p0.val_tab_off:p0.val_tab_off + p0.val_tab_len]) == [1.5, 0.7]
+    assert list(vals[p1.val_tab_off:p1.val_tab_off + p1.val_tab_len]) == [0.01, 0.03]
+    with pytest.raises(NotImplementedError):
+        compile_config(make("CartPole-v1"), {"gravity": IncrementUpdate(RandomScheduler(0.5), 1.0)})
+    assert isinstance(ContinuousScheduler(), Scheduler)
+
+
+def test_frozenlake_config():
+    cfg, blob, spec, _ = compile_config(make("FrozenLake-v1", map_name="8x8", is_slippery=False),
+                                        {"P": DistributionStepWiseUpdate(DiscreteScheduler({50}), [[0.6, 0.2, 0.2]])},
+                                        initial_prob_dist=[1.0, 0.0, 0.0], modified_rewards={"H": -1, "G": 1, "F": 0, "S": 0})
+    assert (cfg.nrow, cfg.ncol, cfg.max_episode_steps) == (8, 8, 100)
+    desc = blob[cfg.desc_tab_off:cfg.desc_tab_off + 64]
+    assert desc[:8] == b"SFFFFFFF" and desc[-1:] == b"G" and desc.count(b"H") == 10
+    assert cfg.flags & A.F_MODIFIED_REWARDS and list(cfg.letter_reward) == [0.0, 0.0, -1.0, 1.0]
+    assert list(cfg.initial_prob) == [1.0, 0.0, 0.0]
+
+
+def test_product_has_no_cpu_fallback():
+    """The product path fails loudly without a GPU (never routes through the oracle)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ns_gym_amd._lib import NsgError
+    from ns_gym_amd.vec_env import VecNSEnv
+
+    with pytest.raises(NsgError):
+        VecNSEnv(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), 0.1)}, 4)
+    with pytest.raises(NsgError):
+        ContinuousScheduler()(3)   # Scheduler.__call__ evaluates on the device only
+    import glob
+    import os
+
+    import ns_gym_amd
+
+    pkg = os.path.dirname(ns_gym_amd.__file__)
+    files = glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True) + glob.glob(os.path.join(pkg, "csrc", "*"))
+    assert len(files) > 10
+    for f in files:
+        if os.path.isfile(f) and not f.endswith((".so", ".s", ".txt")):
+            src = open(f, errors="replace").read()
+            assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src.replace(
+                "never routes through the oracle", ""), f"{f} must not touch oracle/"
