@@ -21,7 +21,7 @@ def lib():
 def _declared_functions():
     src = open(os.path.join(ROOT, "include", "nsgym_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(nsg_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(nsg_[a-z_0-9]+)\s*\(", src)))
 
 
 def test_exports_every_declared_symbol(lib):
