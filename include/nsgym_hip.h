@@ -167,8 +167,9 @@ typedef struct nsg_buffers {
                             episode's slip probabilities stay in force until the next fire.   */
   int32_t* t;            /* [N]    wrapper time t == obs["relative_time"] (base.py:314,347) */
   uint8_t* status;       /* [N]    NSG_ST_* bits                                          */
-  uint64_t* rng_env;     /* [4][N] env np_random PCG64: state_hi,state_lo,inc_hi,inc_lo   */
-  uint64_t* rng_upd;     /* [P][4][N] update-fn PCG64 streams (only rows with uses_rng)   */
+  uint64_t* rng_env;     /* [N][4] env np_random PCG64 records: state_hi,state_lo,inc_hi,inc_lo
+                            (32-byte record per env: streams are touched by few scattered lanes) */
+  uint64_t* rng_upd;     /* [P][N][4] update-fn PCG64 streams (only rows with uses_rng)   */
   int32_t* cursor;       /* [P][N] StepWise/Cyclic list cursor                            */
   float* obs;            /* [N][D] obs["state"] float32 (classic control)                 */
   float* reward;         /* [N]                                                           */
@@ -251,7 +252,7 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
 /* θ-schedule engine alone (Scheduler.__call__ + UpdateFn.__call__, base.py:67-81,124-149)
  * on param slot `p` of the handle's config: n lanes, each starting from theta0[i] (3 doubles
  * per lane for distributions) and its stream, iterated over t = t0 .. t0+T-1, θ fed back.
- * Outputs [T][n] (theta: [T][n] or [T][3][n]).  rng_state: [4][n] or NULL. */
+ * Outputs [T][n] (theta: [T][n] or [T][3][n]).  rng_state: [n][4] records or NULL. */
 int nsg_theta_trace(nsg_handle* h, int32_t p, int32_t n, int32_t t0, int32_t T, const double* theta0,
                     uint64_t* rng_state, double* theta_out, uint8_t* fired_out, double* delta_out,
                     void* stream);
@@ -259,7 +260,7 @@ int nsg_theta_trace(nsg_handle* h, int32_t p, int32_t n, int32_t t0, int32_t T, 
 /* NumPy-compatible bit streams on device (SeedSequence -> PCG64; numpy Generator.random /
  * normal).  kind 0: raw uint64, 1: random() double, 2: standard_normal double.
  * seeds[n], spawn_key < 0 = root stream, else SeedSequence(seed).spawn(..)[spawn_key].
- * out [count][n].  state_out [4][n] may be NULL. */
+ * out [count][n].  state_out [n][4] records, may be NULL. */
 int nsg_rng_fill(int32_t kind, const uint64_t* seeds_dev, int32_t n, int32_t spawn_key, int32_t count,
                  void* out_dev, uint64_t* state_out_dev, void* stream);
 

@@ -47,14 +47,34 @@ struct ActionPtrs {
   const void* p[NSG_MAX_SEGMENTS];
 };
 
+// Dynamic LDS layout (sized per handle at launch: a batch with tiny tables must not pay 22 KB of
+// LDS per workgroup, which would cap residency at 6-7 workgroups per CU):
+//   [ cnt[4] | reset_n[2] | pad | reset_list[kBlock] (short) | reset_state[kBlock][4] (f64) |
+//     table blob | ziggurat ki/wi/fi ]
 struct LdsTables {
-  uint64_t zig[768];
-  uint64_t blob[kMaxTableBytes / 8];
-  unsigned cnt[NSG_CNT_COUNT];
+  unsigned* cnt;        // NSG_CNT_COUNT block-level counters
+  int* reset_n;         // [2] workgroup-level compaction of the autoreset lanes (double-buffered)
+  short* reset_list;    // [kBlock] lanes whose env resets in this chunk
+  double* reset_state;  // [kBlock][4] initial states drawn by the helper lanes, read back by the owners
+  uint64_t* blob;       // constant-table blob
+  uint64_t* zig;        // 768 words, only when some update fn draws normals
 };
+constexpr int kLdsHeaderBytes = 32 + kBlock * 2 + kBlock * 4 * 8;
+
+__host__ __device__ inline int lds_bytes_for(int table_bytes, int uses_normal) {
+  return kLdsHeaderBytes + ((table_bytes + 7) & ~7) + (uses_normal ? 768 * 8 : 0);
+}
 
 // Cooperative staging of the constant tables into LDS (once per workgroup).
 __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, Tables& tb, ZigLds& zg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char nsg_dyn_lds[];
+  unsigned char* base = nsg_dyn_lds;
+  lds.cnt = (unsigned*)base;
+  lds.reset_n = (int*)(base + 16);
+  lds.reset_list = (short*)(base + 32);
+  lds.reset_state = (double*)(base + 32 + kBlock * 2);
+  lds.blob = (uint64_t*)(base + kLdsHeaderBytes);
+  lds.zig = (uint64_t*)(base + kLdsHeaderBytes + ((sg.table_bytes + 7) & ~7));
   const int tid = threadIdx.x;
   if (sg.uses_normal) {
     for (int k = tid; k < 768; k += kBlock) lds.zig[k] = sg.zig[k];
@@ -63,6 +83,7 @@ __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, 
   const uint64_t* src = (const uint64_t*)sg.tables;
   for (int k = tid; k < words; k += kBlock) lds.blob[k] = src[k];
   if (tid < NSG_CNT_COUNT) lds.cnt[tid] = 0;
+  if (tid == 0) lds.reset_n[0] = lds.reset_n[1] = 0;
   __syncthreads();
   tb.base = (const uint8_t*)lds.blob;
   zg.ki = lds.zig;
@@ -114,171 +135,249 @@ template <> struct Unroll<0> {
   template <typename F> static __device__ __forceinline__ void run(F&&) {}
 };
 
-template <int ENV> __device__ __forceinline__ void store_obs(float* __restrict__ obs, int64_t i, const float* o) {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int ENV> __device__ __forceinline__ void store_obs(float* obs, int64_t i, const float* o) {
+  const uint32_t u = (uint32_t)i;
   if constexpr (ENV == NSG_ENV_CARTPOLE) {
-    reinterpret_cast<float4*>(obs)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    stg(reinterpret_cast<f32x4*>(obs), u * 16u, f32x4{o[0], o[1], o[2], o[3]});
   } else if constexpr (ENV == NSG_ENV_PENDULUM) {
-    obs[3 * i + 0] = o[0]; obs[3 * i + 1] = o[1]; obs[3 * i + 2] = o[2];
+    stg(obs, u * 12u, o[0]); stg(obs, u * 12u + 4u, o[1]); stg(obs, u * 12u + 8u, o[2]);
   } else if constexpr (ENV == NSG_ENV_ACROBOT) {
-    float2* q = reinterpret_cast<float2*>(obs) + 3 * i;
-    q[0] = make_float2(o[0], o[1]); q[1] = make_float2(o[2], o[3]); q[2] = make_float2(o[4], o[5]);
+    f32x2* q = reinterpret_cast<f32x2*>(obs);
+    stg(q, u * 24u, f32x2{o[0], o[1]}); stg(q, u * 24u + 8u, f32x2{o[2], o[3]});
+    stg(q, u * 24u + 16u, f32x2{o[4], o[5]});
   } else {
-    reinterpret_cast<float2*>(obs)[i] = make_float2(o[0], o[1]);
+    stg(reinterpret_cast<f32x2*>(obs), u * 8u, f32x2{o[0], o[1]});
+  }
+}
+
+// Envs whose constraint checker looks at one proposal at a time (everything but Acrobot, whose
+// link-length / centre-of-mass checks cross-reference other proposals, classic_control.py:241-357).
+template <int ENV> __device__ __forceinline__ bool own_constraint_violated(int slot, double n) {
+  if constexpr (ENV == NSG_ENV_CARTPOLE) {  // :208-235  gravity masscart masspole force_mag tau length
+    return slot == 0 ? n < 0 : (slot == 1 || slot == 2 || slot == 5) ? n <= 0 : false;
+  } else if constexpr (ENV == NSG_ENV_PENDULUM) {  // :389-420  m l dt g
+    return slot == 3 ? n < 0 : n <= 0;
+  } else {  // MountainCar :359-376 gravity force;  MountainCarContinuous :378-387 power
+    return n <= 0;
   }
 }
 
 // ============================================================================================
-// classic-control step for env i (one lane).  `active` = i < N; inactive lanes only take part
-// in the ballots.
+// classic-control step for one chunk of kBlock envs (the whole workgroup; one env per lane).
+//   phase 1: every lane steps its env (θ-engine, constraints, integrator, outputs); an env that
+//            ended an episode on the previous call takes no transition and is queued in LDS
+//   phase 2: the first `reset_n` lanes of the workgroup perform the queued resets (PCG64 draws of
+//            the initial state).  ~5 % of the envs reset per step but they sit in ~96 % of the
+//            wavefronts; compacting them per workgroup lets ONE wavefront execute the draw path
+//            instead of all of them.
 // ============================================================================================
 template <int ENV, bool FULL>
-__device__ __forceinline__ void step_classic(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
-                                             const StepOut& out, int64_t i, bool active, WaveCounts& wc) {
+__device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
+                                           const StepOut& out, int64_t base, int parity, LdsTables& lds, WaveCounts& wc) {
   using T = EnvTraits<ENV>;
   const nsg_config& cfg = sg.cfg;
   const nsg_buffers& b = sg.buf;
   const int64_t N = sg.N;
   const int P = cfg.n_params;
   const bool persistent = (cfg.flags & NSG_F_PERSISTENT_PARAMS) != 0;
+  const int tid = threadIdx.x;
+  const int64_t i = base + tid;
+  const bool active = i < N;
 
-  const unsigned st = active ? b.status[i] : 0u;
-  const int t = active ? b.t[i] : 0;
+  const uint32_t o1 = (uint32_t)i, o4 = o1 * 4u, o8 = o1 * 8u;  // per-lane byte offsets (N <= 2^27)
+  const unsigned st = active ? ldg(b.status, o1) : 0u;
+  const int t = active ? ldg(b.t, o4) : 0;
   const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);  // next-step autoreset == reset(seed=None)
   const bool do_step = active && !do_reset;
 
   double s[T::PHYS];
 #pragma unroll
-  for (int k = 0; k < T::PHYS; k++) s[k] = do_step ? b.phys[(int64_t)k * N + i] : 0.0;
+  for (int k = 0; k < T::PHYS; k++) s[k] = do_step ? ldg(b.phys + (int64_t)k * N, o8) : 0.0;
   int ai = 0;
   float af = 0.f;
   if (do_step) {
-    if constexpr (T::FLOAT_ACT) af = ((const float*)actions)[i];
-    else ai = ((const int32_t*)actions)[i];
+    if constexpr (T::FLOAT_ACT) af = ldg((const float*)actions, o4);
+    else ai = ldg((const int32_t*)actions, o4);
   }
+  float er = 0.f;
+  const bool track = (cfg.flags & NSG_F_TRACK_RETURNS) != 0;
+  if (track && do_step) er = ldg(b.ep_return, o4);
 
-  // ---- pass 1: every update fn proposes a value (classic_control.py:80-85) -----------------
-  double cur[T::NTHETA], nv[T::NTHETA];
-#pragma unroll
-  for (int k = 0; k < T::NTHETA; k++) cur[k] = nv[k] = cfg.base_theta[k];
-  unsigned tuned = 0, firedmask = 0;
-  for (int p = 0; p < P; p++) {
-    const nsg_param_cfg& pc = cfg.params[p];
-    const int slot = pc.theta_slot;
-    double c = active ? b.theta[(int64_t)p * N + i] : cfg.base_theta[slot];
-    double n = c;
-    const bool fire = do_step && sched_fire(pc, tb, t);
-    if (fire) {
-      Pcg r = {0, 0, 0, 0};
-      int cursor = 0;
-      const bool has_cur = upd_uses_cursor(pc.upd_kind);
-      if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
-      if (has_cur) cursor = b.cursor[(int64_t)p * N + i];
-      n = upd_scalar<FULL>(pc, tb, zg, c, t, r, cursor);
-      if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
-      if (has_cur) b.cursor[(int64_t)p * N + i] = cursor;
-      firedmask |= 1u << p;
-    }
-    Unroll<T::NTHETA>::run([&](int k) {
-      if (k == slot) { cur[k] = c; nv[k] = n; }
-    });
-    tuned |= 1u << slot;
-  }
-
-  // ---- constraint checker on all proposals at once (classic_control.py:87, 193-422) --------
-  const unsigned viol = constraint_mask<ENV>(nv, cur, tuned);
-
-  // ---- pass 2: commit / reject, notification ground truth (classic_control.py:87-92) -------
   double th[T::NTHETA];
 #pragma unroll
-  for (int k = 0; k < T::NTHETA; k++) th[k] = cur[k];
+  for (int k = 0; k < T::NTHETA; k++) th[k] = cfg.base_theta[k];
   unsigned n_fired = 0, n_viol = 0;
-  for (int p = 0; p < P; p++) {
-    const nsg_param_cfg& pc = cfg.params[p];
-    const int slot = pc.theta_slot;
-    double c = 0.0, n = 0.0;
-    Unroll<T::NTHETA>::run([&](int k) {
-      if (k == slot) { c = cur[k]; n = nv[k]; }
-    });
-    bool fired = (firedmask >> p) & 1u;
-    const bool rejected = (viol >> slot) & 1u;
-    double delta = fired ? n - c : 0.0;  // UpdateFn._get_delta_change, base.py:182
-    double fin = rejected ? c : n;
-    if (rejected) {
-      n_viol += fired ? 1u : 0u;
-      fired = false;
-      delta = 0.0;
+
+  if constexpr (ENV != NSG_ENV_ACROBOT) {
+    // ---- single pass: propose, check, commit (classic_control.py:80-92) ----------------------
+    for (int p = 0; p < P; p++) {
+      const nsg_param_cfg& pc = cfg.params[p];
+      const int slot = pc.theta_slot;
+      const double c = active ? ldg(b.theta + (int64_t)p * N, o8) : cfg.base_theta[slot];
+      double n = c;
+      bool fired = do_step && sched_fire(pc, tb, t);
+      if (fired) {
+        Pcg r = {0, 0, 0, 0};
+        int cursor = 0;
+        const bool has_cur = upd_uses_cursor(pc.upd_kind);
+        if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
+        if (has_cur) cursor = ldg(b.cursor + (int64_t)p * N, o4);
+        n = upd_scalar<FULL>(pc, tb, zg, c, t, r, cursor);
+        if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
+        if (has_cur) stg(b.cursor + (int64_t)p * N, o4, cursor);
+      }
+      const bool rejected = own_constraint_violated<ENV>(slot, n);
+      double delta = fired ? n - c : 0.0;  // UpdateFn._get_delta_change, base.py:182
+      double fin = rejected ? c : n;
+      if (rejected) {
+        n_viol += fired ? 1u : 0u;
+        fired = false;
+        delta = 0.0;
+      }
+      if (do_reset) {  // base.py:381-384 + classic_control.py:105-107; streams continue (base.py:389-391)
+        fin = persistent ? c : cfg.base_theta[slot];
+        if (!persistent && upd_uses_cursor(pc.upd_kind)) stg(b.cursor + (int64_t)p * N, o4, 0);
+      }
+      Unroll<T::NTHETA>::run([&](int k) {
+        if (k == slot) th[k] = fin;
+      });
+      if (active) {
+        if (fin != c) stg(b.theta + (int64_t)p * N, o8, fin);
+        stg(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
+        stg(out.delta_change + (int64_t)p * N, o4, (float)delta);
+      }
+      n_fired += fired ? 1u : 0u;
     }
-    if (do_reset) {  // base.py:381-384 + classic_control.py:105-107; streams continue (base.py:389-391)
-      fin = persistent ? c : cfg.base_theta[slot];
-      if (!persistent && upd_uses_cursor(pc.upd_kind)) b.cursor[(int64_t)p * N + i] = 0;
+  } else {
+    // ---- Acrobot: all proposals first, then the cross-referencing checker --------------------
+    double cur[T::NTHETA], nv[T::NTHETA];
+#pragma unroll
+    for (int k = 0; k < T::NTHETA; k++) cur[k] = nv[k] = cfg.base_theta[k];
+    unsigned tuned = 0, firedmask = 0;
+    for (int p = 0; p < P; p++) {
+      const nsg_param_cfg& pc = cfg.params[p];
+      const int slot = pc.theta_slot;
+      const double c = active ? ldg(b.theta + (int64_t)p * N, o8) : cfg.base_theta[slot];
+      double n = c;
+      if (do_step && sched_fire(pc, tb, t)) {
+        Pcg r = {0, 0, 0, 0};
+        int cursor = 0;
+        const bool has_cur = upd_uses_cursor(pc.upd_kind);
+        if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
+        if (has_cur) cursor = ldg(b.cursor + (int64_t)p * N, o4);
+        n = upd_scalar<FULL>(pc, tb, zg, c, t, r, cursor);
+        if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
+        if (has_cur) stg(b.cursor + (int64_t)p * N, o4, cursor);
+        firedmask |= 1u << p;
+      }
+      Unroll<T::NTHETA>::run([&](int k) {
+        if (k == slot) { cur[k] = c; nv[k] = n; }
+      });
+      tuned |= 1u << slot;
     }
-    Unroll<T::NTHETA>::run([&](int k) {
-      if (k == slot) th[k] = fin;
-    });
-    if (active) {
-      if (fin != c) b.theta[(int64_t)p * N + i] = fin;
-      out.env_change[(int64_t)p * N + i] = fired ? 1 : 0;
-      out.delta_change[(int64_t)p * N + i] = (float)delta;
+    const unsigned viol = constraint_mask<ENV>(nv, cur, tuned);
+#pragma unroll
+    for (int k = 0; k < T::NTHETA; k++) th[k] = cur[k];
+    for (int p = 0; p < P; p++) {
+      const nsg_param_cfg& pc = cfg.params[p];
+      const int slot = pc.theta_slot;
+      double c = 0.0, n = 0.0;
+      Unroll<T::NTHETA>::run([&](int k) {
+        if (k == slot) { c = cur[k]; n = nv[k]; }
+      });
+      bool fired = (firedmask >> p) & 1u;
+      const bool rejected = (viol >> slot) & 1u;
+      double delta = fired ? n - c : 0.0;
+      double fin = rejected ? c : n;
+      if (rejected) {
+        n_viol += fired ? 1u : 0u;
+        fired = false;
+        delta = 0.0;
+      }
+      if (do_reset) {
+        fin = persistent ? c : cfg.base_theta[slot];
+        if (!persistent && upd_uses_cursor(pc.upd_kind)) stg(b.cursor + (int64_t)p * N, o4, 0);
+      }
+      Unroll<T::NTHETA>::run([&](int k) {
+        if (k == slot) th[k] = fin;
+      });
+      if (active) {
+        if (fin != c) stg(b.theta + (int64_t)p * N, o8, fin);
+        stg(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
+        stg(out.delta_change + (int64_t)p * N, o4, (float)delta);
+      }
+      n_fired += fired ? 1u : 0u;
     }
-    n_fired += fired ? 1u : 0u;
   }
 
-  // ---- base MDP transition with the updated θ (base.py:313) or the reset draw (base.py:377) --
+  // ---- base MDP transition with the updated θ (base.py:313) ----------------------------------
   double reward = 0.0;
   bool term = false, trunc = false;
   int tnew = 0;
-#ifdef NSG_EXP_NORESET  // timing experiment only: skip the divergent reset draw
-  if (false) {
-#else
-  if (do_reset) {
-#endif
-    Pcg g;
-    pcg_load(b.rng_env, N, i, g);
-    env_reset_draw<ENV>(g, s);
-    pcg_store_state(b.rng_env, N, i, g);
-  } else if (do_step) {
-#ifdef NSG_EXP_NOPHYS   // timing experiment only: no integrator arithmetic
-    s[0] += th[0] * 1e-9; reward = 1.0; term = s[0] > 1e30;
-#else
+  if (do_step) {
     term = env_step<ENV>(th, s, ai, af, reward);
-#endif
-    tnew = t + 1;                                                      // base.py:314
+    tnew = t + 1;                                                        // base.py:314
     trunc = cfg.max_episode_steps > 0 && tnew >= cfg.max_episode_steps;  // TimeLimit [UPSTREAM]
   }
   const bool done = term || trunc;
 
-  if (active) {
+  // ---- compacted resets: queue -> helper lanes draw -> owners read back ----------------------
+  int* rn = lds.reset_n + (parity & 1);
+  if (do_reset) {
+    const int q = atomicAdd(rn, 1);
+    lds.reset_list[q] = (short)tid;
+  }
+  __syncthreads();
+  const int n_reset = *rn;
+  if (tid == 0) lds.reset_n[(parity + 1) & 1] = 0;  // the other buffer is idle until the next chunk
+  if (tid < n_reset) {  // gymnasium reset(): np_random draws of the initial state [UPSTREAM]
+    const int owner = lds.reset_list[tid];
+    const int64_t j = base + owner;
+    Pcg g;
+    pcg_load(b.rng_env, N, j, g);
+    double r0[T::PHYS];
+    env_reset_draw<ENV>(g, r0);
+    pcg_store_state(b.rng_env, N, j, g);
 #pragma unroll
-    for (int k = 0; k < T::PHYS; k++) b.phys[(int64_t)k * N + i] = s[k];
+    for (int k = 0; k < T::PHYS; k++) lds.reset_state[owner * 4 + k] = r0[k];
+  }
+  __syncthreads();
+  if (do_reset) {
+#pragma unroll
+    for (int k = 0; k < T::PHYS; k++) s[k] = lds.reset_state[tid * 4 + k];
+  }
+
+  if (active) {  // every row is written by its owner lane: fully coalesced stores
+#pragma unroll
+    for (int k = 0; k < T::PHYS; k++) stg(b.phys + (int64_t)k * N, o8, s[k]);
     float o[T::OBS];
     env_obs<ENV>(s, o);
     store_obs<ENV>(out.obs, i, o);
-    b.t[i] = tnew;
-    out.reward[i] = (float)reward;
-    out.terminated[i] = term ? 1 : 0;
-    out.truncated[i] = trunc ? 1 : 0;
-    b.status[i] = done ? NSG_ST_NEEDS_RESET : 0;
-    if (cfg.flags & NSG_F_TRACK_RETURNS) {
-      float er = do_reset ? 0.f : b.ep_return[i] + (float)reward;
-      int el = do_reset ? 0 : b.ep_length[i] + 1;
+    stg(b.t, o4, tnew);
+    stg(out.reward, o4, (float)reward);
+    stg(out.terminated, o1, (uint8_t)(term ? 1 : 0));
+    stg(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
+    stg(b.status, o1, (uint8_t)(done ? NSG_ST_NEEDS_RESET : 0));
+    if (track) {  // the episode length is the wrapper time t: only the return needs a running row
+      er += (float)reward;
       if (done) {
-        b.last_return[i] = er;
-        b.last_length[i] = el;
+        stg(b.last_return, o4, er);
+        stg(b.last_length, o4, tnew);
         er = 0.f;
-        el = 0;
       }
-      b.ep_return[i] = er;
-      b.ep_length[i] = el;
+      stg(b.ep_return, o4, er);
     }
   }
 
-  // ---- wavefront ballot: done mask word + counters -----------------------------------------
+  // ---- wavefront ballots: done-mask word + counters ------------------------------------------
   const unsigned long long done_mask = __ballot(done);
-  if (b.done_bits && (threadIdx.x & 63) == 0 && i < N) b.done_bits[i >> 6] = done_mask;
+  if (b.done_bits && (tid & 63) == 0 && i < N) b.done_bits[i >> 6] = done_mask;
   wc.done += __popcll(done_mask);
   wc.steps += __popcll(__ballot(do_step));
-  // per-lane small integers: sum across the wave with a ballot per bit
-  for (unsigned bit = 0; bit < 4; bit++) {
+  for (unsigned bit = 0; bit < 4; bit++) {  // per-lane small integers summed with one ballot per bit
     wc.fired += __popcll(__ballot((n_fired >> bit) & 1u)) << bit;
     wc.viol += __popcll(__ballot((n_viol >> bit) & 1u)) << bit;
   }
@@ -296,8 +395,9 @@ __device__ __forceinline__ void step_frozenlake(const Segment& sg, const Tables&
   const bool persistent = (cfg.flags & NSG_F_PERSISTENT_PARAMS) != 0;
   const uint8_t* desc = tb.base + cfg.desc_tab_off;
 
-  const unsigned st = active ? b.status[i] : 0u;
-  const int t = active ? b.t[i] : 0;
+  const uint32_t o1 = (uint32_t)i, o4 = o1 * 4u, o8 = o1 * 8u;  // per-lane byte offsets (N <= 2^27)
+  const unsigned st = active ? ldg(b.status, o1) : 0u;
+  const int t = active ? ldg(b.t, o4) : 0;
   const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);
   const bool do_step = active && !do_reset;
 
@@ -373,11 +473,11 @@ __device__ __forceinline__ void step_frozenlake(const Segment& sg, const Tables&
   if (active) {
     b.cell[i] = cell;
     if (out.obs) ((int32_t*)out.obs)[i] = cell;  // trajectory slice (rollout); NULL for nsg_step: cell[] is the obs
-    b.t[i] = tnew;
-    out.reward[i] = (float)reward;
-    out.terminated[i] = term ? 1 : 0;
-    out.truncated[i] = trunc ? 1 : 0;
-    b.status[i] = done ? NSG_ST_NEEDS_RESET : 0;
+    stg(b.t, o4, tnew);
+    stg(out.reward, o4, (float)reward);
+    stg(out.terminated, o1, (uint8_t)(term ? 1 : 0));
+    stg(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
+    stg(b.status, o1, (uint8_t)(done ? NSG_ST_NEEDS_RESET : 0));
     out.env_change[i] = fired ? 1 : 0;
     out.delta_change[i] = (float)delta;
     if (b.prob) b.prob[i] = (float)prob;
@@ -390,7 +490,7 @@ __device__ __forceinline__ void step_frozenlake(const Segment& sg, const Tables&
         er = 0.f;
         el = 0;
       }
-      b.ep_return[i] = er;
+      stg(b.ep_return, o4, er);
       b.ep_length[i] = el;
     }
   }
@@ -401,17 +501,23 @@ __device__ __forceinline__ void step_frozenlake(const Segment& sg, const Tables&
   wc.fired += __popcll(__ballot(fired));
 }
 
+
+// One chunk of kBlock envs of any env type (block-level call: contains workgroup barriers).
 template <int ENV, bool FULL>
-__device__ __forceinline__ void step_any(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
-                                         const StepOut& out, int64_t i, bool active, WaveCounts& wc) {
-  if constexpr (ENV == NSG_ENV_FROZENLAKE) step_frozenlake(sg, tb, actions, out, i, active, wc);
-  else step_classic<ENV, FULL>(sg, tb, zg, actions, out, i, active, wc);
+__device__ __forceinline__ void step_block(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
+                                           const StepOut& out, int64_t base, int parity, LdsTables& lds, WaveCounts& wc) {
+  if constexpr (ENV == NSG_ENV_FROZENLAKE) {
+    const int64_t i = base + threadIdx.x;
+    step_frozenlake(sg, tb, actions, out, i, i < sg.N, wc);
+  } else {
+    step_chunk<ENV, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc);
+  }
 }
 
 // Homogeneous launch: grid-stride over 256-env chunks.
 template <int ENV, bool FULL>
 __global__ __launch_bounds__(kBlock, NSG_MIN_WAVES) void step_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions) {
-  __shared__ LdsTables lds;
+  LdsTables lds;
   const Segment& sg = *seg;
   Tables tb;
   ZigLds zg;
@@ -419,10 +525,9 @@ __global__ __launch_bounds__(kBlock, NSG_MIN_WAVES) void step_kernel(const Segme
   WaveCounts wc;
   const StepOut out = default_out(sg.buf);
   const int64_t chunks = (sg.N + kBlock - 1) / kBlock;
-  for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-    const int64_t i = c * kBlock + threadIdx.x;
-    step_any<ENV, FULL>(sg, tb, zg, actions, out, i, i < sg.N, wc);
-  }
+  int parity = 0;
+  for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x, parity ^= 1)
+    step_block<ENV, FULL>(sg, tb, zg, actions, out, c * kBlock, parity, lds, wc);
   flush_counts(sg, lds, wc);
 }
 
@@ -430,7 +535,7 @@ __global__ __launch_bounds__(kBlock, NSG_MIN_WAVES) void step_kernel(const Segme
 // is uniform per workgroup (no intra-wave divergence between Pendulum and Acrobot lanes).
 template <bool FULL>
 __global__ __launch_bounds__(kBlock) void step_group_kernel(const Segment* __restrict__ segs, int nseg, ActionPtrs acts) {
-  __shared__ LdsTables lds;
+  LdsTables lds;
   int sidx = 0;
   for (int k = 1; k < nseg; k++)
     if ((int)blockIdx.x >= segs[k].block_begin) sidx = k;
@@ -442,16 +547,16 @@ __global__ __launch_bounds__(kBlock) void step_group_kernel(const Segment* __res
   const int64_t chunks = (sg.N + kBlock - 1) / kBlock;
   const void* actions = acts.p[sidx];
   const StepOut out = default_out(sg.buf);
-  for (int64_t c = (int)blockIdx.x - sg.block_begin; c < chunks; c += sg.block_count) {
-    const int64_t i = c * kBlock + threadIdx.x;
-    const bool active = i < sg.N;
+  int parity = 0;
+  for (int64_t c = (int)blockIdx.x - sg.block_begin; c < chunks; c += sg.block_count, parity ^= 1) {
+    const int64_t base = c * kBlock;
     switch (sg.cfg.env_type) {
-      case NSG_ENV_CARTPOLE: step_any<NSG_ENV_CARTPOLE, FULL>(sg, tb, zg, actions, out, i, active, wc); break;
-      case NSG_ENV_PENDULUM: step_any<NSG_ENV_PENDULUM, FULL>(sg, tb, zg, actions, out, i, active, wc); break;
-      case NSG_ENV_ACROBOT: step_any<NSG_ENV_ACROBOT, FULL>(sg, tb, zg, actions, out, i, active, wc); break;
-      case NSG_ENV_MOUNTAINCAR: step_any<NSG_ENV_MOUNTAINCAR, FULL>(sg, tb, zg, actions, out, i, active, wc); break;
-      case NSG_ENV_MOUNTAINCAR_CONT: step_any<NSG_ENV_MOUNTAINCAR_CONT, FULL>(sg, tb, zg, actions, out, i, active, wc); break;
-      default: step_any<NSG_ENV_FROZENLAKE, FULL>(sg, tb, zg, actions, out, i, active, wc); break;
+      case NSG_ENV_CARTPOLE: step_block<NSG_ENV_CARTPOLE, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
+      case NSG_ENV_PENDULUM: step_block<NSG_ENV_PENDULUM, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
+      case NSG_ENV_ACROBOT: step_block<NSG_ENV_ACROBOT, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
+      case NSG_ENV_MOUNTAINCAR: step_block<NSG_ENV_MOUNTAINCAR, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
+      case NSG_ENV_MOUNTAINCAR_CONT: step_block<NSG_ENV_MOUNTAINCAR_CONT, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
+      default: step_block<NSG_ENV_FROZENLAKE, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
     }
   }
   flush_counts(sg, lds, wc);
@@ -598,7 +703,7 @@ __global__ __launch_bounds__(kBlock) void theta_trace_kernel(const Segment* __re
                                                              const double* __restrict__ theta0, uint64_t* rng_state,
                                                              double* __restrict__ theta_out, uint8_t* __restrict__ fired_out,
                                                              double* __restrict__ delta_out) {
-  __shared__ LdsTables lds;
+  LdsTables lds;
   const Segment& sg = *seg;
   Tables tb;
   ZigLds zg;

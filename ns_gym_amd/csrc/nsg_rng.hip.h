@@ -8,8 +8,7 @@
 // uv.lock:1868-1869]: SeedSequence hash-mix -> PCG64 (128-bit LCG, XSL-RR output) ->
 // next_double = (u64 >> 11) * 2^-53 -> 256-layer ziggurat normal.
 //
-// Layout: a stream is 4 x u64 per env, struct-of-arrays [4][N]:
-//   row 0 state_hi, row 1 state_lo, row 2 inc_hi, row 3 inc_lo   (coalesced 8-byte lanes).
+// Layout: a stream is one 32-byte record per env ([N][4] u64: state_hi, state_lo, inc_hi, inc_lo).
 // The ziggurat tables (6 KiB) are staged in LDS once per workgroup: lookups are per-lane
 // random indices, which LDS serves at full rate and HBM/L2 would not.
 #pragma once
@@ -17,6 +16,27 @@
 #include <stdint.h>
 
 namespace nsg {
+
+// Global-memory accessors: base pointer wave-uniform (SGPR pair), per-lane 32-bit BYTE offset.
+// The buffers reach the kernels through a struct in memory, so without the explicit address
+// space the compiler must emit flat_* instructions and 64-bit per-lane address arithmetic;
+// with it, every access is `global_load/store vdata, voffset32, s[base:base+1]`.
+#define NSG_GLOBAL __attribute__((address_space(1)))
+// readfirstlane declares the row base wave-uniform (it is: every lane computes it from the same
+// kernel-uniform values), which keeps it in an SGPR pair instead of 64-bit per-lane arithmetic.
+__device__ __forceinline__ uint64_t pin_sgpr(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+template <typename T> __device__ __forceinline__ T ldg(const T* base, uint32_t byte_off) {
+  const NSG_GLOBAL char* p = (const NSG_GLOBAL char*)pin_sgpr((uint64_t)base);
+  return *(const NSG_GLOBAL T*)(p + byte_off);
+}
+template <typename T> __device__ __forceinline__ void stg(T* base, uint32_t byte_off, T v) {
+  NSG_GLOBAL char* p = (NSG_GLOBAL char*)pin_sgpr((uint64_t)base);
+  *(NSG_GLOBAL T*)(p + byte_off) = v;
+}
 
 struct Pcg {
   uint64_t sh, sl, ih, il;
@@ -104,21 +124,28 @@ __device__ inline void pcg_seed(Pcg& r, uint64_t seed, int child) {
   pcg_step(r);
 }
 
-__device__ __forceinline__ void pcg_load(const uint64_t* __restrict__ base, int64_t N, int64_t i, Pcg& r) {
-  r.sh = base[0 * N + i];
-  r.sl = base[1 * N + i];
-  r.ih = base[2 * N + i];
-  r.il = base[3 * N + i];
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+
+// A stream is one 32-byte record per env, array-of-records [N][4]: state_hi, state_lo, inc_hi,
+// inc_lo.  Streams are touched by few, scattered lanes (the ~5 % of envs that reset, the lanes
+// whose scheduler fired), so one 32-byte record = one memory sector per touch; four SoA rows
+// would cost four sectors.  Two 16-byte accesses per lane; only the state half is written back.
+__device__ __forceinline__ void pcg_load(const uint64_t* base, int64_t N, int64_t i, Pcg& r) {
+  (void)N;
+  const uint32_t o = (uint32_t)i * 32u;
+  const u64x2 a = ldg(reinterpret_cast<const u64x2*>(base), o);
+  const u64x2 c = ldg(reinterpret_cast<const u64x2*>(base), o + 16u);
+  r.sh = a.x; r.sl = a.y; r.ih = c.x; r.il = c.y;
 }
-__device__ __forceinline__ void pcg_store_state(uint64_t* __restrict__ base, int64_t N, int64_t i, const Pcg& r) {
-  base[0 * N + i] = r.sh;  // the increment never changes after seeding
-  base[1 * N + i] = r.sl;
+__device__ __forceinline__ void pcg_store_state(uint64_t* base, int64_t N, int64_t i, const Pcg& r) {
+  (void)N;
+  stg(reinterpret_cast<u64x2*>(base), (uint32_t)i * 32u, u64x2{r.sh, r.sl});  // the increment never changes
 }
-__device__ __forceinline__ void pcg_store_all(uint64_t* __restrict__ base, int64_t N, int64_t i, const Pcg& r) {
-  base[0 * N + i] = r.sh;
-  base[1 * N + i] = r.sl;
-  base[2 * N + i] = r.ih;
-  base[3 * N + i] = r.il;
+__device__ __forceinline__ void pcg_store_all(uint64_t* base, int64_t N, int64_t i, const Pcg& r) {
+  (void)N;
+  const uint32_t o = (uint32_t)i * 32u;
+  stg(reinterpret_cast<u64x2*>(base), o, u64x2{r.sh, r.sl});
+  stg(reinterpret_cast<u64x2*>(base), o + 16u, u64x2{r.ih, r.il});
 }
 
 // ---- ziggurat normal (numpy random_standard_normal), tables in LDS --------------------

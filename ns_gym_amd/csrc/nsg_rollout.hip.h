@@ -12,7 +12,7 @@ namespace nsg {
 template <int ENV, bool FULL>
 __global__ __launch_bounds__(kBlock) void rollout_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions,
                                                          int k_steps, nsg_rollout_out ro) {
-  __shared__ LdsTables lds;
+  LdsTables lds;
   const Segment& sg = *seg;
   Tables tb;
   ZigLds zg;
@@ -24,8 +24,8 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const Segment* __restri
   constexpr int D = ENV == NSG_ENV_FROZENLAKE ? 1 : EnvTraits<ENV == NSG_ENV_FROZENLAKE ? NSG_ENV_CARTPOLE : ENV>::OBS;
   constexpr bool FA = ENV == NSG_ENV_PENDULUM || ENV == NSG_ENV_MOUNTAINCAR_CONT;
   const int64_t chunks = (N + kBlock - 1) / kBlock;
+  int parity = 0;
   for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
-    const int64_t i = c * kBlock + threadIdx.x;
     for (int k = 0; k < k_steps; k++) {
       StepOut out;
       out.obs = ro.obs ? ro.obs + (int64_t)k * N * D : (ENV == NSG_ENV_FROZENLAKE ? nullptr : dflt.obs);
@@ -35,7 +35,8 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const Segment* __restri
       out.env_change = ro.env_change ? ro.env_change + (int64_t)k * P * N : dflt.env_change;
       out.delta_change = ro.delta_change ? ro.delta_change + (int64_t)k * P * N : dflt.delta_change;
       const void* act = FA ? (const void*)((const float*)actions + (int64_t)k * N) : (const void*)((const int32_t*)actions + (int64_t)k * N);
-      step_any<ENV, FULL>(sg, tb, zg, act, out, i, i < N, wc);
+      step_block<ENV, FULL>(sg, tb, zg, act, out, c * kBlock, parity, lds, wc);
+      parity ^= 1;
     }
   }
   flush_counts(sg, lds, wc);

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -14,6 +15,7 @@
 #include "nsg_rollout.hip.h"
 
 using namespace nsg;
+
 
 namespace {
 
@@ -200,9 +202,18 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
   return NSG_OK;
 }
 
+static int grid_cap() {  // tuning knob (tools/kbench.py sweeps it); default from measurements
+  static int cap = 0;
+  if (!cap) {
+    const char* e = getenv("NSG_GRID_CAP");
+    cap = e ? atoi(e) : 4096;
+    if (cap < 1) cap = 4096;
+  }
+  return cap;
+}
 static int grid_for(int64_t n) {
   int64_t chunks = (n + kBlock - 1) / kBlock;
-  return (int)(chunks < 4096 ? chunks : 4096);
+  return (int)(chunks < grid_cap() ? chunks : grid_cap());
 }
 
 int nsg_bind(nsg_handle* h, const nsg_buffers* bufs) {
@@ -250,12 +261,14 @@ int nsg_step(nsg_handle* h, const void* actions_dev, void* stream) {
   if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
   if (!actions_dev) return fail(NSG_EINVAL, "actions_dev is NULL");
   hipStream_t s = (hipStream_t)stream;
+  const int grid = grid_for(h->n);
+  const size_t lds = (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal);
   if (h->host.simple_theta) {
     DISPATCH_ENV(h->host.cfg.env_type,
-                 hipLaunchKernelGGL((step_kernel<E, false>), dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, actions_dev));
+                 hipLaunchKernelGGL((step_kernel<E, false>), dim3(grid), dim3(kBlock), lds, s, h->dev, actions_dev));
   } else {
     DISPATCH_ENV(h->host.cfg.env_type,
-                 hipLaunchKernelGGL((step_kernel<E, true>), dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, actions_dev));
+                 hipLaunchKernelGGL((step_kernel<E, true>), dim3(grid), dim3(kBlock), lds, s, h->dev, actions_dev));
   }
   HIP_TRY(hipGetLastError());
   return NSG_OK;
@@ -271,10 +284,10 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
   hipStream_t s = (hipStream_t)stream;
   if (h->host.simple_theta) {
     DISPATCH_ENV(h->host.cfg.env_type,
-                 hipLaunchKernelGGL((rollout_kernel<E, false>), dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, actions_dev, k_steps, o));
+                 hipLaunchKernelGGL((rollout_kernel<E, false>), dim3(grid_for(h->n)), dim3(kBlock), (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal), s, h->dev, actions_dev, k_steps, o));
   } else {
     DISPATCH_ENV(h->host.cfg.env_type,
-                 hipLaunchKernelGGL((rollout_kernel<E, true>), dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, actions_dev, k_steps, o));
+                 hipLaunchKernelGGL((rollout_kernel<E, true>), dim3(grid_for(h->n)), dim3(kBlock), (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal), s, h->dev, actions_dev, k_steps, o));
   }
   HIP_TRY(hipGetLastError());
   return NSG_OK;
@@ -289,6 +302,7 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
   static thread_local int n_members = 0;
   static thread_local int total_blocks = 0;
   static thread_local int all_simple = 0;
+  static thread_local int group_lds = 0;
   bool same = n_members == n_handles;
   for (int k = 0; same && k < n_handles; k++) same = members[k] == hs[k];
   if (!same) {
@@ -307,7 +321,12 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
     n_members = n_handles;
     total_blocks = begin;
     all_simple = 1;
-    for (int k = 0; k < n_handles; k++) all_simple &= hs[k]->host.simple_theta;
+    group_lds = 0;
+    for (int k = 0; k < n_handles; k++) {
+      all_simple &= hs[k]->host.simple_theta;
+      const int l = lds_bytes_for(hs[k]->host.table_bytes, hs[k]->host.uses_normal);
+      if (l > group_lds) group_lds = l;
+    }
   }
   ActionPtrs ap;
   memset(&ap, 0, sizeof(ap));
@@ -315,8 +334,8 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
     if (!actions_dev[k]) return fail(NSG_EINVAL, "actions_dev[%d] is NULL", k);
     ap.p[k] = actions_dev[k];
   }
-  if (all_simple) hipLaunchKernelGGL(step_group_kernel<false>, dim3(total_blocks), dim3(kBlock), 0, (hipStream_t)stream, d_group, n_handles, ap);
-  else hipLaunchKernelGGL(step_group_kernel<true>, dim3(total_blocks), dim3(kBlock), 0, (hipStream_t)stream, d_group, n_handles, ap);
+  if (all_simple) hipLaunchKernelGGL(step_group_kernel<false>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, d_group, n_handles, ap);
+  else hipLaunchKernelGGL(step_group_kernel<true>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, d_group, n_handles, ap);
   HIP_TRY(hipGetLastError());
   return NSG_OK;
 }
@@ -339,7 +358,8 @@ int nsg_theta_trace(nsg_handle* h, int32_t p, int32_t n, int32_t t0, int32_t T, 
   if (!theta0 || !theta_out || !fired_out || !delta_out) return fail(NSG_EINVAL, "NULL buffer");
   if (h->host.cfg.params[p].uses_rng && !rng_state) return fail(NSG_EINVAL, "rng_state required for a stochastic update fn");
   if (!h->bound) HIP_TRY(hipMemcpy(h->dev, &h->host, sizeof(Segment), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(theta_trace_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, h->dev, p, n, t0, T,
+  hipLaunchKernelGGL(theta_trace_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock),
+                     (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal), (hipStream_t)stream, h->dev, p, n, t0, T,
                      theta0, rng_state, theta_out, fired_out, delta_out);
   HIP_TRY(hipGetLastError());
   return NSG_OK;

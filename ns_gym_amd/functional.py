@@ -29,12 +29,12 @@ def rng_fill(kind: int, seeds, count: int, spawn_key: int = -1):
     n = s.size
     sd = torch.from_numpy(s.view(np.int64)).to(dev)
     out = torch.zeros((max(count, 1), n), dtype=torch.int64 if kind == 0 else torch.float64, device=dev)
-    st = torch.zeros((4, n), dtype=torch.int64, device=dev)
+    st = torch.zeros((n, 4), dtype=torch.int64, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(lib.nsg_rng_fill(kind, sd.data_ptr(), n, spawn_key, count, out.data_ptr(), st.data_ptr(), stream), "nsg_rng_fill")
     torch.cuda.synchronize(dev)
     o = out[:count].cpu().numpy()
-    return (o.view(np.uint64) if kind == 0 else o), st.cpu().numpy().view(np.uint64)
+    return (o.view(np.uint64) if kind == 0 else o), st.cpu().numpy().view(np.uint64).T.copy()  # [4, n]
 
 
 def theta_trace(fn: UpdateFn, theta0, t0: int = 0, T: int = 1, n: int = 1, seeds=None):
@@ -53,7 +53,7 @@ def theta_trace(fn: UpdateFn, theta0, t0: int = 0, T: int = 1, n: int = 1, seeds
         if cfg.params[0].uses_rng:
             sd = np.asarray(seeds if seeds is not None else [cfg.params[0].fn_seed] * n, dtype=np.uint64)
             _, st = rng_fill(0, sd, 0)
-            rng = torch.from_numpy(st.view(np.int64)).to(dev)
+            rng = torch.from_numpy(np.ascontiguousarray(st.T).view(np.int64)).to(dev)  # [n, 4] records
         th = torch.zeros((T, 3, n) if dist else (T, n), dtype=torch.float64, device=dev)
         fired = torch.zeros((T, n), dtype=torch.uint8, device=dev)
         delta = torch.zeros((T, n), dtype=torch.float64, device=dev)

@@ -137,15 +137,18 @@ static double pcg_std_normal(pcg64* g) {
 }
 static double pcg_normal(pcg64* g, double loc, double scale) { return loc + scale * pcg_std_normal(g); }
 
+/* streams are stored as 32-byte records [N][4]: state_hi, state_lo, inc_hi, inc_lo */
 static void rng_load(const uint64_t* base, int64_t N, int64_t i, pcg64* r) {
-  r->state = ((u128)base[0 * N + i] << 64) | base[1 * N + i];
-  r->inc = ((u128)base[2 * N + i] << 64) | base[3 * N + i];
+  (void)N;
+  r->state = ((u128)base[4 * i + 0] << 64) | base[4 * i + 1];
+  r->inc = ((u128)base[4 * i + 2] << 64) | base[4 * i + 3];
 }
 static void rng_store(uint64_t* base, int64_t N, int64_t i, const pcg64* r) {
-  base[0 * N + i] = (uint64_t)(r->state >> 64);
-  base[1 * N + i] = (uint64_t)r->state;
-  base[2 * N + i] = (uint64_t)(r->inc >> 64);
-  base[3 * N + i] = (uint64_t)r->inc;
+  (void)N;
+  base[4 * i + 0] = (uint64_t)(r->state >> 64);
+  base[4 * i + 1] = (uint64_t)r->state;
+  base[4 * i + 2] = (uint64_t)(r->inc >> 64);
+  base[4 * i + 3] = (uint64_t)r->inc;
 }
 
 /* ------------------------------------------------------------------ schedulers */

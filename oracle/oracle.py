@@ -70,7 +70,7 @@ class OracleVecEnv:
         self.a = {
             "phys": z((max(PHYS_DIM[et], 1), N), np.float64), "cell": z(N, np.int32),
             "theta": z((max(rows, 1), N), np.float64), "table_prob": z((3, N), np.float64), "t": z(N, np.int32), "status": z(N, np.uint8),
-            "rng_env": z((4, N), np.uint64), "rng_upd": z((max(P, 1), 4, N), np.uint64),
+            "rng_env": z((N, 4), np.uint64), "rng_upd": z((max(P, 1), N, 4), np.uint64),
             "cursor": z((max(P, 1), N), np.int32), "obs": z((N, OBS_DIM[et]), np.float32),
             "reward": z(N, np.float32), "terminated": z(N, np.uint8), "truncated": z(N, np.uint8),
             "env_change": z((max(P, 1), N), np.uint8), "delta_change": z((max(P, 1), N), np.float32),
@@ -127,7 +127,7 @@ def theta_trace(fn, theta0, t0=0, T=1, n=1, seeds=None):
     rng = None
     if cfg.params[0].uses_rng:
         sd = np.asarray(seeds if seeds is not None else [cfg.params[0].fn_seed] * n, dtype=np.uint64)
-        rng = np.zeros((4, n), dtype=np.uint64)
+        rng = np.zeros((n, 4), dtype=np.uint64)
         scratch = np.zeros((1, n), dtype=np.uint64)
         lib().orc_rng_fill(0, _ptr(sd), n, -1, 0, _ptr(scratch), _ptr(rng))
     th = np.zeros((T, 3, n) if dist else (T, n), dtype=np.float64)
@@ -142,6 +142,6 @@ def rng_fill(kind, seeds, count, spawn_key=-1):
     seeds = np.asarray(seeds, dtype=np.uint64)
     n = seeds.size
     out = np.zeros((count, n), dtype=np.uint64 if kind == 0 else np.float64)
-    st = np.zeros((4, n), dtype=np.uint64)
+    st = np.zeros((n, 4), dtype=np.uint64)
     lib().orc_rng_fill(int(kind), _ptr(seeds), n, int(spawn_key), int(count), _ptr(out), _ptr(st))
-    return out, st
+    return out, st.T.copy()   # [4, n]: state_hi, state_lo, inc_hi, inc_lo
