@@ -66,3 +66,89 @@ NSG_HD double nsg_sin(double x) { double s, c; nsg_sincos(x, &s, &c); return s; 
 NSG_HD double nsg_cos(double x) { double s, c; nsg_sincos(x, &s, &c); return c; }
 
 }  // namespace nsg
+
+namespace nsg {
+
+// ---- float64 exp / log1p with a small register footprint (fdlibm algorithms, < 1 ulp) -------
+// Used by the "full" θ-engine: ExponentialDecay / SigmoidTransition (np.exp, single_param.py:286,
+// 384) and the ziggurat wedge / tail tests of NumPy's normal sampler (exp, log1p).  The device
+// library's versions cost ~60 VGPRs more, which costs the RandomWalk kernels a wave of occupancy.
+NSG_HD double nsg_ldexp_norm(double y, int k) {  // y * 2^k for the k range exp() produces
+  // two-step scaling keeps subnormal results correctly rounded once
+  union { double d; unsigned long long u; } a;
+  if (k > 1023) {
+    a.u = 0x7fe0000000000000ULL;  // 2^1023
+    y *= a.d;
+    k -= 1023;
+    if (k > 1023) k = 1023;
+  } else if (k < -1022) {
+    a.u = 0x0360000000000000ULL;  // 2^-969
+    y *= a.d;
+    k += 969;
+    if (k < -1022) k = -1022;
+  }
+  a.u = (unsigned long long)(k + 1023) << 52;
+  return y * a.d;
+}
+
+NSG_HD double nsg_exp(double x) {
+  const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+               invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+               P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+               P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  if (x != x) return x;
+  if (x > 7.09782712893383973096e+02) return INFINITY;
+  if (x < -7.45133219101941108420e+02) return 0.0;
+  const double kf = rint(x * invln2);
+  const int k = (int)kf;
+  const double hi = x - kf * ln2HI;
+  const double lo = kf * ln2LO;
+  const double r = hi - lo;
+  const double t = r * r;
+  const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+  return k == 0 ? y : nsg_ldexp_norm(y, k);
+}
+
+NSG_HD double nsg_log1p(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+               Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
+               Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
+               Lp7 = 1.479819860511658591e-01;
+  if (x != x) return x;
+  if (x < -1.0) return NAN;
+  if (x == -1.0) return -INFINITY;
+  if (x == INFINITY) return x;
+  const double ax = fabs(x);
+  if (ax < 5.55111512312578270212e-17) return x;  // |x| < 2^-54
+  int k = 1;
+  double f = x, c = 0.0;
+  if (x > -0.2928932188134524 && x < 0.41421356237309515) {
+    k = 0;  // sqrt(2)/2 - 1 < x < sqrt(2) - 1: no reduction
+  } else {
+    union { double d; unsigned long long u; } uu;
+    const double u1 = 1.0 + x;
+    uu.d = u1;
+    k = (int)((uu.u >> 52) & 0x7ff) - 1023;
+    // correction term for the rounding of 1 + x
+    c = (k > 0) ? 1.0 - (u1 - x) : x - (u1 - 1.0);
+    c /= u1;
+    unsigned long long m = uu.u & 0x000fffffffffffffULL;
+    if (m < 0x6a09e667f3bcdULL) {
+      uu.u = m | 0x3ff0000000000000ULL;  // normalise u
+    } else {
+      k += 1;
+      uu.u = m | 0x3fe0000000000000ULL;  // normalise u/2
+    }
+    f = uu.d - 1.0;
+  }
+  const double hfsq = 0.5 * f * f;
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  const double R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+  if (k == 0) return f - (hfsq - s * (hfsq + R));
+  const double kd = (double)k;
+  return kd * ln2_hi - ((hfsq - (s * (hfsq + R) + (kd * ln2_lo + c))) - f);
+}
+
+}  // namespace nsg

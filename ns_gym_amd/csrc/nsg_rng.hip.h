@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "nsg_math.hip.h"
+
 namespace nsg {
 
 // Global-memory accessors: base pointer wave-uniform (SGPR pair), per-lane 32-bit BYTE offset.
@@ -168,13 +170,13 @@ __device__ inline double pcg_std_normal(Pcg& g, const ZigLds& z) {
     if (rabs < z.ki[idx]) return x;  // 99.3 % of draws
     if (idx == 0) {
       for (;;) {
-        double xx = -ZINV * log1p(-pcg_double(g));
-        double yy = -log1p(-pcg_double(g));
+        double xx = -ZINV * nsg_log1p(-pcg_double(g));
+        double yy = -nsg_log1p(-pcg_double(g));
         if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? -(ZR + xx) : ZR + xx;
       }
     } else {
       double f1 = z.fi[idx - 1], f0 = z.fi[idx];
-      if ((f1 - f0) * pcg_double(g) + f0 < exp(-0.5 * x * x)) return x;
+      if ((f1 - f0) * pcg_double(g) + f0 < nsg_exp(-0.5 * x * x)) return x;
     }
   }
 }

@@ -71,11 +71,11 @@ __device__ inline double upd_scalar(const nsg_param_cfg& pc, const Tables& tb, c
       return th + trend;
     }
     case NSG_UPD_GEOMETRIC: return th * u[0];
-    case NSG_UPD_EXPDECAY: if constexpr (FULL) return th * exp(-u[0] * td); else return th;
-    case NSG_UPD_OSCILLATING: if constexpr (FULL) return th + u[0] * sin(td); else return th;
+    case NSG_UPD_EXPDECAY: if constexpr (FULL) return th * nsg_exp(-u[0] * td); else return th;
+    case NSG_UPD_OSCILLATING: if constexpr (FULL) return th + u[0] * nsg_sin(td); else return th;
     case NSG_UPD_SIGMOID: {
       if constexpr (FULL) {
-        double sg = 1.0 / (1.0 + exp(-u[2] * (td - u[3])));
+        double sg = 1.0 / (1.0 + nsg_exp(-u[2] * (td - u[3])));
         return u[0] + (u[1] - u[0]) * sg;
       } else return th;
     }

@@ -1,0 +1,74 @@
+"""Accuracy of the kernels' own float64 sincos / exp / log1p (ns_gym_amd/csrc/nsg_math.hip.h).
+The header is plain C++ under NSG_HD, so the very same source is compiled for the host here and
+compared with long-double libm: <= 1 ulp everywhere the integrators / θ-engine evaluate it."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SRC = r'''
+#include "%s/ns_gym_amd/csrc/nsg_math.hip.h"
+extern "C" {
+void t_sincos(const double* x, double* s, double* c, long n) { for (long i = 0; i < n; i++) nsg::nsg_sincos(x[i], s + i, c + i); }
+void t_exp(const double* x, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_exp(x[i]); }
+void t_log1p(const double* x, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_log1p(x[i]); }
+}
+''' % ROOT
+
+
+@pytest.fixture(scope="module")
+def m():
+    d = tempfile.mkdtemp()
+    src, so = os.path.join(d, "m.cpp"), os.path.join(d, "m.so")
+    open(src, "w").write(SRC)
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src])
+    return C.CDLL(so)
+
+
+def _ulps(got, want_ld):
+    want = want_ld.astype(np.float64)
+    ulp = np.spacing(np.abs(want))
+    return np.max(np.abs(got.astype(np.longdouble) - want_ld) / ulp)
+
+
+def _call(fn, x, nout=1):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    outs = [np.empty_like(x) for _ in range(nout)]
+    fn(x.ctypes.data_as(C.c_void_p), *[o.ctypes.data_as(C.c_void_p) for o in outs], C.c_long(x.size))
+    return outs
+
+
+def test_sincos_within_one_ulp(m):
+    rng = np.random.default_rng(0)
+    xs = [rng.uniform(-r, r, 400_000) for r in (0.3, 4.0, 30.0, 1e3, 1e6)]
+    k = np.arange(-2000, 2001)[:, None] * (np.pi / 2)
+    near = np.concatenate([np.nextafter(k, np.inf), k, np.nextafter(k, -np.inf)]).ravel()
+    for x in xs + [near]:
+        s, c = _call(m.t_sincos, x, 2)
+        xl = x.astype(np.longdouble)
+        assert _ulps(s, np.sin(xl)) <= 1.0 and _ulps(c, np.cos(xl)) <= 1.0
+
+
+def test_exp_and_log1p_within_one_ulp(m):
+    rng = np.random.default_rng(1)
+    for r in (1e-3, 1.0, 8.0, 50.0, 700.0):
+        x = rng.uniform(-r, r, 300_000)
+        (y,) = _call(m.t_exp, x)
+        assert _ulps(y, np.exp(x.astype(np.longdouble))) <= 1.0
+    x = -rng.uniform(0.0, 1.0, 500_000)
+    x = x[x > -1.0]
+    (y,) = _call(m.t_log1p, x)
+    assert _ulps(y, np.log1p(x.astype(np.longdouble))) <= 1.0
+    for r in (1e-10, 0.5, 10.0, 1e6):
+        x = rng.uniform(-min(r, 0.999), r, 200_000)
+        (y,) = _call(m.t_log1p, x)
+        assert _ulps(y, np.log1p(x.astype(np.longdouble))) <= 1.0
+    (y,) = _call(m.t_exp, np.array([710.0, -800.0, np.nan, 0.0]))
+    assert np.isinf(y[0]) and y[1] == 0.0 and np.isnan(y[2]) and y[3] == 1.0
+    (y,) = _call(m.t_log1p, np.array([-1.0, -2.0, 0.0, np.inf]))
+    assert y[0] == -np.inf and np.isnan(y[1]) and y[2] == 0.0 and np.isinf(y[3])
