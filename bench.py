@@ -155,14 +155,16 @@ def main():
             # the GPU box exposes 256 logical CPUs but one GPU's share is 16 cores
             threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
             cpu_baseline(1 << 14, 8, threads)  # warm the OpenMP pool / page in the oracle
-            # bounded sample of the same workload: 2^18 envs x 40 steps (scaled down from 2^20 x K)
-            v, secs = cpu_baseline(1 << 18, 40, threads)
-            if secs < 5.0:  # fast host: lengthen the sample towards ~10 s of CPU work
-                reps = min(int(10.0 / max(secs, 1e-3)), 20)
-                v, secs = cpu_baseline(1 << 18, 40 * max(reps, 1), threads)
+            # bounded sample of the same workload: 2^18 envs, step count sized from a short probe so the
+            # timed sample is ~10 s of wall time on the host share (never more than 20 s)
+            n_cpu = 1 << 18
+            rate, _ = cpu_baseline(n_cpu, 40, threads)
+            steps_cpu = int(min(max(10.0 * rate / n_cpu, 40), 20.0 * rate / n_cpu, 200000))
+            v, secs = cpu_baseline(n_cpu, steps_cpu, threads)
             out["cpu_baseline"] = {
                 "value": v, "unit": "env-steps/s", "cores": threads, "kind": "port",
-                "sample": f"oracle C port (OpenMP), 262144 envs, same config, {secs:.1f} s wall",
+                "sample": f"oracle C port (OpenMP, {threads} threads), {n_cpu} envs x {steps_cpu} steps of the same config, "
+                          f"{secs:.1f} s wall",
             }
         print(json.dumps(out), flush=True)
     if dist is not None:
