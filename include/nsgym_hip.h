@@ -100,6 +100,8 @@ enum {
 #define NSG_F_PERSISTENT_PARAMS 0x4u
 #define NSG_F_TRACK_RETURNS 0x8u   /* keep per-env episode return / length accumulators   */
 #define NSG_F_MODIFIED_REWARDS 0x10u /* FrozenLake modified_rewards (toy_text.py:465-468)  */
+#define NSG_F_SIM_ENV 0x40u        /* planning copy: is_sim_env (base.py:270, classic_control.py:184)   */
+#define NSG_F_IN_SIM_CHANGE 0x80u  /* in_sim_change: θ keeps evolving inside planning copies            */
 
 /* per-env status byte (buffers.status) */
 #define NSG_ST_NEEDS_RESET 0x1u
@@ -165,7 +167,14 @@ typedef struct nsg_buffers {
                             transition_prob (toy_text.py:396) but its next step re-installs the
                             wrapper's un-reset self.P (toy_text.py:365-367), so the previous
                             episode's slip probabilities stay in force until the next fire.   */
+  double* derived;       /* [2][N] CartPole planning copies only: total_mass, polemass_length as resolved
+                            at fork time.  get_planning_env() re-installs the initial θ AFTER the
+                            copy's _dependency_resolver() ran and a frozen copy never resolves again
+                            (classic_control.py:70-75,133-136,183), so these can be stale w.r.t. θ  */
   int32_t* t;            /* [N]    wrapper time t == obs["relative_time"] (base.py:314,347) */
+  int32_t* t_fork;       /* [N]    planning copies only: t at fork time.  __deepcopy__ builds a fresh
+                            gym.make() env, so TimeLimit's elapsed count restarts at 0 while the
+                            wrapper's t is preserved (classic_control.py:168-180)              */
   uint8_t* status;       /* [N]    NSG_ST_* bits                                          */
   uint64_t* rng_env;     /* [N][4] env np_random PCG64 records: state_hi,state_lo,inc_hi,inc_lo
                             (32-byte record per env: streams are touched by few scattered lanes) */
@@ -192,7 +201,7 @@ typedef struct nsg_layout {
   int64_t n;
   int32_t phys_dim, obs_dim, n_params, n_theta_rows, action_is_float;
   int32_t n_actions;           /* discrete action count, 0 for continuous                  */
-  int64_t phys, cell, theta, table_prob, t, status, rng_env, rng_upd, cursor, obs, reward, terminated,
+  int64_t phys, cell, theta, table_prob, derived, t, t_fork, status, rng_env, rng_upd, cursor, obs, reward, terminated,
       truncated, env_change, delta_change, prob, ep_return, ep_length, last_return, last_length,
       counters, done_bits;
 } nsg_layout;
@@ -230,6 +239,20 @@ int nsg_reset(nsg_handle* h, const uint64_t* seeds_dev, const uint8_t* mask_dev,
  * Envs whose previous step ended an episode are reset (seed=None) instead of stepped
  * (gymnasium next-step autoreset): reward 0, terminated/truncated 0, relative_time 0. */
 int nsg_step(nsg_handle* h, const void* actions_dev, void* stream);
+
+/* Batched planning-env snapshot: get_planning_env() / __deepcopy__ of the reference wrappers
+ * (classic_control.py:120-186, toy_text.py:471-511, base.py:433-441) for all N envs at once.
+ * `dst` must have been created from the same config plus NSG_F_SIM_ENV and bound to its own
+ * buffers.  Copies state, t (t_fork = t), list cursors and the last outputs; θ per theta_mode:
+ *   0 = current θ          (deepcopy; get_planning_env when delta_change_notification or sim env)
+ *   1 = construction-time θ (get_planning_env without delta_change_notification)
+ * and re-seeds every stream from `entropy` (the reference uses fresh OS entropy:
+ * _reseed_planning_env_rngs, base.py:433-441; env np_random of the new gym.make() env). */
+int nsg_fork(nsg_handle* src, nsg_handle* dst, uint64_t entropy, int32_t theta_mode, void* stream);
+
+/* Re-seed streams without touching env state: which = 0 env np_random (env.np_random =
+ * default_rng(seed)), 1 = update-fn streams (SeedSequence(seed).spawn children, base.py:412-421). */
+int nsg_seed_streams(nsg_handle* h, const uint64_t* seeds_dev, int32_t which, void* stream);
 
 /* K fused steps with state held in registers between steps; actions [K][N]; per-step
  * outputs are written to the caller's [K][...] trajectory buffers (any may be NULL). */

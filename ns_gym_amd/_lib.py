@@ -14,6 +14,7 @@ _lib = None
 EXPORTS = [
     "nsg_abi_version", "nsg_last_error", "nsg_sizeof_config", "nsg_sizeof_buffers", "nsg_sizeof_layout",
     "nsg_layout_query", "nsg_create", "nsg_bind", "nsg_reset", "nsg_step", "nsg_rollout", "nsg_step_group",
+    "nsg_fork", "nsg_seed_streams",
     "nsg_compact_done", "nsg_theta_trace", "nsg_rng_fill", "nsg_time_steps", "nsg_calib_copy_f64", "nsg_destroy",
 ]
 
@@ -62,6 +63,8 @@ def load():
     lib.nsg_step.argtypes = [vp, vp, vp]
     lib.nsg_rollout.argtypes = [vp, vp, i32, C.POINTER(A.RolloutOut), vp]
     lib.nsg_step_group.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), vp]
+    lib.nsg_fork.argtypes = [vp, vp, C.c_uint64, i32, vp]
+    lib.nsg_seed_streams.argtypes = [vp, vp, i32, vp]
     lib.nsg_compact_done.argtypes = [vp, vp, vp, vp]
     lib.nsg_theta_trace.argtypes = [vp, i32, i32, i32, i32, vp, u64p, vp, vp, vp, vp]
     lib.nsg_rng_fill.argtypes = [i32, vp, i32, i32, i32, vp, vp, vp]

@@ -19,11 +19,11 @@ namespace nsg {
 #define NSG_PI 3.141592653589793238462643383279502884
 
 template <int ENV> struct EnvTraits;
-template <> struct EnvTraits<NSG_ENV_CARTPOLE> { static constexpr int PHYS = 4, OBS = 4, NTHETA = 6; static constexpr bool FLOAT_ACT = false; };
-template <> struct EnvTraits<NSG_ENV_PENDULUM> { static constexpr int PHYS = 2, OBS = 3, NTHETA = 4; static constexpr bool FLOAT_ACT = true; };
-template <> struct EnvTraits<NSG_ENV_ACROBOT> { static constexpr int PHYS = 4, OBS = 6, NTHETA = 8; static constexpr bool FLOAT_ACT = false; };
-template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR> { static constexpr int PHYS = 2, OBS = 2, NTHETA = 2; static constexpr bool FLOAT_ACT = false; };
-template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR_CONT> { static constexpr int PHYS = 2, OBS = 2, NTHETA = 1; static constexpr bool FLOAT_ACT = true; };
+template <> struct EnvTraits<NSG_ENV_CARTPOLE> { static constexpr int PHYS = 4, OBS = 4, NTHETA = 6, NDERIVED = 2; static constexpr bool FLOAT_ACT = false; };
+template <> struct EnvTraits<NSG_ENV_PENDULUM> { static constexpr int NDERIVED = 0, PHYS = 2, OBS = 3, NTHETA = 4; static constexpr bool FLOAT_ACT = true; };
+template <> struct EnvTraits<NSG_ENV_ACROBOT> { static constexpr int NDERIVED = 0, PHYS = 4, OBS = 6, NTHETA = 8; static constexpr bool FLOAT_ACT = false; };
+template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR> { static constexpr int NDERIVED = 0, PHYS = 2, OBS = 2, NTHETA = 2; static constexpr bool FLOAT_ACT = false; };
+template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR_CONT> { static constexpr int NDERIVED = 0, PHYS = 2, OBS = 2, NTHETA = 1; static constexpr bool FLOAT_ACT = true; };
 
 // ---- reset draws: np_random.uniform(low, high) = low + (high - low) * next_double ----------
 template <int ENV> __device__ __forceinline__ void env_reset_draw(Pcg& g, double* s) {
@@ -125,9 +125,10 @@ __device__ __forceinline__ void acrobot_dsdt(const double* th, const double* y, 
 template <int ENV>
 __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, float af, double& reward) {
   if constexpr (ENV == NSG_ENV_CARTPOLE) {
-    const double gravity = th[0], masscart = th[1], masspole = th[2], force_mag = th[3], tau = th[4], length = th[5];
-    const double total_mass = masspole + masscart;     // _dependency_resolver, classic_control.py:426-435
-    const double polemass_length = length * masspole;  // :436-444
+    const double gravity = th[0], masspole = th[2], force_mag = th[3], tau = th[4], length = th[5];
+    // th[6] = total_mass, th[7] = polemass_length: resolved by the caller (_dependency_resolver,
+    // classic_control.py:424-444); a frozen planning copy carries the values resolved at fork time
+    const double total_mass = th[6], polemass_length = th[7];
     double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
     double force = ai == 1 ? force_mag : -force_mag;
     double sintheta, costheta;

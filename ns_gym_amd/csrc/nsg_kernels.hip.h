@@ -183,6 +183,10 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
   const int64_t N = sg.N;
   const int P = cfg.n_params;
   const bool persistent = (cfg.flags & NSG_F_PERSISTENT_PARAMS) != 0;
+  // planning copies (get_planning_env / __deepcopy__): θ frozen unless in_sim_change
+  // (classic_control.py:70-75); TimeLimit counts from the fork (t_fork)
+  const bool sim = (cfg.flags & NSG_F_SIM_ENV) != 0;
+  const bool theta_live = !(sim && !(cfg.flags & NSG_F_IN_SIM_CHANGE));
   const int tid = threadIdx.x;
   const int64_t i = base + tid;
   const bool active = i < N;
@@ -206,7 +210,7 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
   const bool track = (cfg.flags & NSG_F_TRACK_RETURNS) != 0;
   if (track && do_step) er = ldg(b.ep_return, o4);
 
-  double th[T::NTHETA];
+  double th[T::NTHETA + T::NDERIVED];
 #pragma unroll
   for (int k = 0; k < T::NTHETA; k++) th[k] = cfg.base_theta[k];
   unsigned n_fired = 0, n_viol = 0;
@@ -218,7 +222,7 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
       const int slot = pc.theta_slot;
       const double c = active ? ldg(b.theta + (int64_t)p * N, o8) : cfg.base_theta[slot];
       double n = c;
-      bool fired = do_step && sched_fire(pc, tb, t);
+      bool fired = do_step && theta_live && sched_fire(pc, tb, t);
       if (fired) {
         Pcg r = {0, 0, 0, 0};
         int cursor = 0;
@@ -262,7 +266,7 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
       const int slot = pc.theta_slot;
       const double c = active ? ldg(b.theta + (int64_t)p * N, o8) : cfg.base_theta[slot];
       double n = c;
-      if (do_step && sched_fire(pc, tb, t)) {
+      if (do_step && theta_live && sched_fire(pc, tb, t)) {
         Pcg r = {0, 0, 0, 0};
         int cursor = 0;
         const bool has_cur = upd_uses_cursor(pc.upd_kind);
@@ -317,11 +321,23 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
   double reward = 0.0;
   bool term = false, trunc = false;
   int tnew = 0;
+  if constexpr (ENV == NSG_ENV_CARTPOLE) {
+    if (sim && !theta_live && b.derived) {  // frozen planning copy: the resolver never runs again
+      th[6] = do_step ? ldg(b.derived, o8) : 0.0;
+      th[7] = do_step ? ldg(b.derived + N, o8) : 0.0;
+    } else {  // _dependency_resolver, classic_control.py:426-444
+      th[6] = th[2] + th[1];
+      th[7] = th[5] * th[2];
+    }
+  }
   if (do_step) {
     term = env_step<ENV>(th, s, ai, af, reward);
-    tnew = t + 1;                                                        // base.py:314
-    trunc = cfg.max_episode_steps > 0 && tnew >= cfg.max_episode_steps;  // TimeLimit [UPSTREAM]
+    tnew = t + 1;  // base.py:314
+    // TimeLimit [UPSTREAM] counts the steps of ITS env: a planning copy restarts at the fork
+    const int elapsed = tnew - (sim ? ldg(b.t_fork, o4) : 0);
+    trunc = cfg.max_episode_steps > 0 && elapsed >= cfg.max_episode_steps;
   }
+  if (sim && do_reset) stg(b.t_fork, o4, 0);
   const bool done = term || trunc;
 
   // ---- compacted resets: queue -> helper lanes draw -> owners read back ----------------------
@@ -393,6 +409,8 @@ __device__ __forceinline__ void step_frozenlake(const Segment& sg, const Tables&
   const int64_t N = sg.N;
   const nsg_param_cfg& pc = cfg.params[0];
   const bool persistent = (cfg.flags & NSG_F_PERSISTENT_PARAMS) != 0;
+  const bool sim = (cfg.flags & NSG_F_SIM_ENV) != 0;
+  const bool theta_live = !(sim && !(cfg.flags & NSG_F_IN_SIM_CHANGE));  // toy_text.py:354-360
   const uint8_t* desc = tb.base + cfg.desc_tab_off;
 
   const uint32_t o1 = (uint32_t)i, o4 = o1 * 4u, o8 = o1 * 8u;  // per-lane byte offsets (N <= 2^27)
@@ -415,7 +433,7 @@ __device__ __forceinline__ void step_frozenlake(const Segment& sg, const Tables&
   bool term = false, trunc = false;
   int tnew = 0;
   if (do_step) {
-    fired = sched_fire(pc, tb, t);
+    fired = theta_live && sched_fire(pc, tb, t);
     double p0, p1, p2;
     if (fired) {  // toy_text.py:362-366
       double p[3] = {b.theta[0 * N + i], b.theta[1 * N + i], b.theta[2 * N + i]}, q[3];
@@ -455,8 +473,9 @@ __device__ __forceinline__ void step_frozenlake(const Segment& sg, const Tables&
       prob = idx == 0 ? p0 : idx == 1 ? p1 : p2;
     }
     tnew = t + 1;
-    trunc = cfg.max_episode_steps > 0 && tnew >= cfg.max_episode_steps;
+    trunc = cfg.max_episode_steps > 0 && (tnew - (sim ? b.t_fork[i] : 0)) >= cfg.max_episode_steps;
   } else if (do_reset) {
+    if (sim) b.t_fork[i] = 0;
     // start cell: argmax(cumsum(one-hot S) > r)
     const int nS = cfg.nrow * cfg.ncol;
     int s0 = 0;
@@ -600,6 +619,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
     }
     pcg_store_all(b.rng_env, N, i, g);
     b.t[i] = 0;
+    if (b.t_fork) b.t_fork[i] = 0;
     for (int p = 0; p < P; p++) {
       const nsg_param_cfg& pc = cfg.params[p];
       if (!persistent) {
@@ -759,6 +779,99 @@ __global__ __launch_bounds__(kBlock) void rng_fill_kernel(int kind, const uint64
     if (kind == 0) ((uint64_t*)out)[(int64_t)k * n + i] = pcg_next64(r);
     else if (kind == 1) ((double*)out)[(int64_t)k * n + i] = pcg_double(r);
     else ((double*)out)[(int64_t)k * n + i] = pcg_std_normal(r, zg);
+  }
+}
+
+// ============================================================================================
+// Batched planning-env snapshot (get_planning_env / __deepcopy__, classic_control.py:120-186,
+// toy_text.py:471-511, base.py:433-441): dst := copy of src with is_sim_env semantics.
+// ============================================================================================
+__global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict__ sseg, const Segment* __restrict__ dseg,
+                                                      uint64_t entropy, int theta_mode) {
+  const Segment& ss = *sseg;
+  const Segment& ds = *dseg;
+  const nsg_config& cfg = ss.cfg;
+  const nsg_buffers& sb = ss.buf;
+  const nsg_buffers& db = ds.buf;
+  const int64_t N = ss.N;
+  const int env = cfg.env_type, P = cfg.n_params;
+  const bool fl = env == NSG_ENV_FROZENLAKE;
+  const bool in_sim_change = (ds.cfg.flags & NSG_F_IN_SIM_CHANGE) != 0;
+  const int phys = fl ? 0 : (env == NSG_ENV_CARTPOLE || env == NSG_ENV_ACROBOT ? 4 : 2);
+  const int obs = fl ? 0 : (env == NSG_ENV_CARTPOLE ? 4 : env == NSG_ENV_PENDULUM ? 3 : env == NSG_ENV_ACROBOT ? 6 : 2);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
+    for (int k = 0; k < phys; k++) db.phys[(int64_t)k * N + i] = sb.phys[(int64_t)k * N + i];
+    if (fl) db.cell[i] = sb.cell[i];
+    const int t = sb.t[i];
+    db.t[i] = t;
+    db.t_fork[i] = t;
+    db.status[i] = sb.status[i];
+    for (int r = 0; r < (fl ? 3 : P); r++) {
+      const double cur = sb.theta[(int64_t)r * N + i];
+      const double init = fl ? cfg.initial_prob[r] : cfg.base_theta[cfg.params[r].theta_slot];
+      db.theta[(int64_t)r * N + i] = theta_mode == 1 ? init : cur;
+    }
+    if (env == NSG_ENV_CARTPOLE && db.derived) {  // sim_env._dependency_resolver() at copy time (:183)
+      double c[6];
+      for (int k = 0; k < 6; k++) c[k] = cfg.base_theta[k];
+      for (int p = 0; p < P; p++) {
+        const int slot = cfg.params[p].theta_slot;
+        const double v = sb.theta[(int64_t)p * N + i];
+        for (int k = 0; k < 6; k++)
+          if (k == slot) c[k] = v;
+      }
+      db.derived[i] = c[2] + c[1];
+      db.derived[N + i] = c[5] * c[2];
+    }
+    if (fl) {  // which P the copy steps with: toy_text.py:479-480 (planning), :505-508 (deepcopy), :365-367
+      for (int k = 0; k < 3; k++)
+        db.table_prob[(int64_t)k * N + i] = (in_sim_change || theta_mode == 1) ? cfg.initial_prob[k] : sb.table_prob[(int64_t)k * N + i];
+      if (db.prob && sb.prob) db.prob[i] = sb.prob[i];
+    }
+    for (int p = 0; p < P; p++) {
+      if (db.cursor && sb.cursor) db.cursor[(int64_t)p * N + i] = sb.cursor[(int64_t)p * N + i];  // deepcopy(tunable_params)
+      db.env_change[(int64_t)p * N + i] = sb.env_change[(int64_t)p * N + i];
+      db.delta_change[(int64_t)p * N + i] = sb.delta_change[(int64_t)p * N + i];
+      if (cfg.params[p].uses_rng) {  // _reseed_planning_env_rngs (base.py:433-441): fresh entropy
+        Pcg r;
+        pcg_seed(r, entropy + (uint64_t)i, 7100 + p);
+        pcg_store_all(db.rng_upd + (int64_t)p * 4 * N, N, i, r);
+      }
+    }
+    Pcg g;  // the copy's base env is a new gym.make(): its np_random is unseeded
+    pcg_seed(g, entropy + (uint64_t)i, 7001);
+    pcg_store_all(db.rng_env, N, i, g);
+    for (int k = 0; k < obs; k++) db.obs[i * obs + k] = sb.obs[i * obs + k];
+    db.reward[i] = sb.reward[i];
+    db.terminated[i] = sb.terminated[i];
+    db.truncated[i] = sb.truncated[i];
+    if (ds.cfg.flags & NSG_F_TRACK_RETURNS) {
+      db.ep_return[i] = (cfg.flags & NSG_F_TRACK_RETURNS) ? sb.ep_return[i] : 0.f;
+      db.last_return[i] = 0.f;
+      db.last_length[i] = 0;
+    }
+    if (db.done_bits && (i & 63) == 0) db.done_bits[i >> 6] = sb.done_bits ? sb.done_bits[i >> 6] : 0;
+  }
+}
+
+// env.np_random = default_rng(seed) / fn.seed(child) without touching env state
+__global__ __launch_bounds__(kBlock) void seed_streams_kernel(const Segment* __restrict__ seg, const uint64_t* __restrict__ seeds,
+                                                              int which) {
+  const Segment& sg = *seg;
+  const int64_t N = sg.N;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
+    if (which == 0) {
+      Pcg g;
+      pcg_seed(g, seeds[i], -1);
+      pcg_store_all(sg.buf.rng_env, N, i, g);
+    } else {
+      for (int p = 0; p < sg.cfg.n_params; p++)
+        if (sg.cfg.params[p].uses_rng) {
+          Pcg r;
+          pcg_seed(r, seeds[i], sg.cfg.params[p].rng_child);
+          pcg_store_all(sg.buf.rng_upd + (int64_t)p * 4 * N, N, i, r);
+        }
+    }
   }
 }
 

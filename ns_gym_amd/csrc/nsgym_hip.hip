@@ -141,6 +141,9 @@ int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
   out->theta = (int64_t)out->n_theta_rows * n;
   out->table_prob = fl ? 3 * n : 0;
   out->t = n;
+  const bool simenv = (cfg->flags & NSG_F_SIM_ENV) != 0;
+  out->t_fork = simenv ? n : 0;
+  out->derived = (simenv && e == NSG_ENV_CARTPOLE) ? 2 * n : 0;
   out->status = n;
   out->rng_env = 4 * n;
   out->rng_upd = any_rng ? (int64_t)P * 4 * n : 0;
@@ -223,7 +226,7 @@ int nsg_bind(nsg_handle* h, const nsg_buffers* bufs) {
   if (rc) return rc;
 #define NEED(field) \
   if (lay.field > 0 && !bufs->field) return fail(NSG_EINVAL, "buffer '%s' is required (%lld elements)", #field, (long long)lay.field)
-  NEED(phys); NEED(cell); NEED(theta); NEED(table_prob); NEED(t); NEED(status); NEED(rng_env); NEED(rng_upd); NEED(cursor);
+  NEED(phys); NEED(cell); NEED(theta); NEED(table_prob); NEED(derived); NEED(t); NEED(t_fork); NEED(status); NEED(rng_env); NEED(rng_upd); NEED(cursor);
   NEED(obs); NEED(reward); NEED(terminated); NEED(truncated); NEED(env_change); NEED(delta_change);
   NEED(ep_return); NEED(ep_length); NEED(last_return); NEED(last_length);
 #undef NEED
@@ -336,6 +339,30 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
   }
   if (all_simple) hipLaunchKernelGGL(step_group_kernel<false>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, d_group, n_handles, ap);
   else hipLaunchKernelGGL(step_group_kernel<true>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, d_group, n_handles, ap);
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
+int nsg_fork(nsg_handle* src, nsg_handle* dst, uint64_t entropy, int32_t theta_mode, void* stream) {
+  if (!src || !dst) return fail(NSG_EINVAL, "NULL handle");
+  if (!src->bound || !dst->bound) return fail(NSG_ENOTBOUND, "both handles must be bound");
+  if (src->n != dst->n) return fail(NSG_EINVAL, "fork: env counts differ (%lld vs %lld)", (long long)src->n, (long long)dst->n);
+  if (!(dst->host.cfg.flags & NSG_F_SIM_ENV)) return fail(NSG_EINVAL, "fork: dst must be created with NSG_F_SIM_ENV");
+  if (theta_mode != 0 && theta_mode != 1) return fail(NSG_EINVAL, "fork: theta_mode must be 0 or 1");
+  nsg_config a = src->host.cfg, b = dst->host.cfg;
+  a.flags = b.flags = 0;
+  if (memcmp(&a, &b, sizeof(a)) != 0 || src->host.table_bytes != dst->host.table_bytes)
+    return fail(NSG_EINVAL, "fork: dst was not created from the same configuration");
+  hipLaunchKernelGGL(fork_kernel, dim3(grid_for(src->n)), dim3(kBlock), 0, (hipStream_t)stream, src->dev, dst->dev, entropy, theta_mode);
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
+int nsg_seed_streams(nsg_handle* h, const uint64_t* seeds_dev, int32_t which, void* stream) {
+  if (!h || !seeds_dev) return fail(NSG_EINVAL, "NULL argument");
+  if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
+  if (which != 0 && which != 1) return fail(NSG_EINVAL, "which must be 0 (env) or 1 (update fns)");
+  hipLaunchKernelGGL(seed_streams_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, (hipStream_t)stream, h->dev, seeds_dev, which);
   HIP_TRY(hipGetLastError());
   return NSG_OK;
 }

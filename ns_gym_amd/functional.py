@@ -47,7 +47,7 @@ def theta_trace(fn: UpdateFn, theta0, t0: int = 0, T: int = 1, n: int = 1, seeds
     h = C.c_void_p()
     _lib.check(lib.nsg_create(C.byref(cfg), tables, len(tables), max(n, 1), C.byref(h)), "nsg_create")
     try:
-        th0 = np.ascontiguousarray(np.broadcast_to(np.asarray(theta0, dtype=np.float64), (n, 3) if dist else (n,)))
+        th0 = np.array(np.broadcast_to(np.asarray(theta0, dtype=np.float64), (n, 3) if dist else (n,)))  # writable copy
         d_th0 = torch.from_numpy(th0).to(dev)
         rng = None
         if cfg.params[0].uses_rng:

@@ -20,7 +20,7 @@ _INF = "inf"
 
 
 def compile_config(env, tunable_params: dict, *, change_notification=False, delta_change_notification=False,
-                   in_sim_change=False, scalar_reward=True, persistent_params=False, track_returns=False, initial_prob_dist=None, modified_rewards=None):
+                   in_sim_change=False, scalar_reward=True, persistent_params=False, track_returns=False, initial_prob_dist=None, modified_rewards=None, is_sim_env=False):
     """Returns (Config, tables_blob: bytes, BaseEnvSpec, param_names)."""
     spec: BaseEnvSpec = from_gym_env(env)
     et = spec.env_type
@@ -50,6 +50,10 @@ def compile_config(env, tunable_params: dict, *, change_notification=False, delt
         flags |= A.F_PERSISTENT_PARAMS
     if track_returns:
         flags |= A.F_TRACK_RETURNS
+    if in_sim_change:
+        flags |= A.F_IN_SIM_CHANGE
+    if is_sim_env:
+        flags |= A.F_SIM_ENV
     tables = TableBuilder()
     if is_fl:
         assert "P" in tunable_params, "NSFrozenLakeWrapper requires tunable_params['P']"

@@ -39,7 +39,8 @@ class VecNSEnv:
 
     def __init__(self, env, tunable_params: dict, num_envs: int, change_notification: bool = False,
                  delta_change_notification: bool = False, in_sim_change: bool = False, scalar_reward: bool = True,
-                 persistent_params: bool = False, track_returns: bool = False, device=None, **kwargs):
+                 persistent_params: bool = False, track_returns: bool = False, device=None, is_sim_env: bool = False,
+                 **kwargs):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.NsgError("VecNSEnv needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
@@ -47,7 +48,12 @@ class VecNSEnv:
         self.cfg, self.tables, self.spec, self.param_names = compile_config(
             env, tunable_params, change_notification=change_notification,
             delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
-            scalar_reward=scalar_reward, persistent_params=persistent_params, track_returns=track_returns, **kwargs)
+            scalar_reward=scalar_reward, persistent_params=persistent_params, track_returns=track_returns,
+            is_sim_env=is_sim_env, **kwargs)
+        self._ctor = dict(env=env, tunable_params=tunable_params, num_envs=num_envs, change_notification=change_notification,
+                          delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
+                          scalar_reward=scalar_reward, persistent_params=persistent_params, track_returns=track_returns,
+                          device=device, **kwargs)
         self.tunable_params = tunable_params
         self.change_notification = change_notification
         self.delta_change_notification = delta_change_notification
@@ -55,7 +61,7 @@ class VecNSEnv:
         self.scalar_reward = scalar_reward
         self.persistent_params = persistent_params
         self.frozen = False
-        self.is_sim_env = False
+        self.is_sim_env = bool(is_sim_env)
         self.has_reset = False
         self.num_envs = self.N = int(num_envs)
         self.is_frozenlake = self.cfg.env_type == A.ENV_FROZENLAKE
@@ -233,6 +239,49 @@ class VecNSEnv:
             _lib.check(self.lib.nsg_time_steps(self._h, act.data_ptr(), int(iters), self._stream, C.byref(ms)),
                        "nsg_time_steps")
         return float(ms.value)
+
+    # ------------------------------------------------------------------ planning copies
+    def fork(self, theta_mode: int = 0, entropy: int | None = None) -> "VecNSEnv":
+        """Batched planning-env snapshot: a new `VecNSEnv` (is_sim_env=True) holding a copy of every
+        env's state, t and update-fn state, with every stream re-seeded from `entropy` (fresh OS
+        entropy by default, like the reference's `_reseed_planning_env_rngs`, ns_gym/base.py:433-441).
+        theta_mode 0 keeps the current θ, 1 installs the construction-time θ."""
+        import os
+
+        if entropy is None:
+            entropy = int.from_bytes(os.urandom(8), "little")
+        kw = dict(self._ctor)
+        kw["is_sim_env"] = True
+        kw["device"] = self.device
+        dst = VecNSEnv(**kw)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nsg_fork(self._h, dst._h, C.c_uint64(entropy & (2**64 - 1)), int(theta_mode), self._stream),
+                       "nsg_fork")
+        dst.has_reset = self.has_reset
+        dst.frozen = self.frozen
+        return dst
+
+    def get_planning_env(self) -> "VecNSEnv":
+        """`get_planning_env()` of the reference wrappers for all envs at once
+        (classic_control.py:120-136, toy_text.py:471-481): current θ if the agent is told the
+        deltas (or this already is a planning copy), otherwise the initial θ; frozen unless
+        in_sim_change."""
+        assert self.has_reset, "The environment must be reset before getting the planning environment."
+        keep = self.is_sim_env or self.delta_change_notification
+        return self.fork(theta_mode=0 if keep else 1)
+
+    def __deepcopy__(self, memo):
+        """`copy.deepcopy(env)` -> planning copy with the current θ (classic_control.py:138-186)."""
+        return self.fork(theta_mode=0)
+
+    def seed_streams(self, seed, which: str = "env"):
+        """Re-seed streams without touching env state: "env" = env.np_random, "update" = update fns."""
+        s = (np.arange(self.N, dtype=np.uint64) + np.uint64(int(seed))) if np.isscalar(seed) else np.asarray(seed, dtype=np.uint64)
+        assert s.shape == (self.N,)
+        d = torch.from_numpy(s.view(np.int64)).to(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nsg_seed_streams(self._h, d.data_ptr(), 0 if which == "env" else 1, self._stream),
+                       "nsg_seed_streams")
 
     def freeze(self, mode: bool = True):
         if not isinstance(mode, bool):

@@ -81,11 +81,11 @@ class _NSSingle:
     """Shared N = 1 plumbing (NSWrapper surface, ns_gym/base.py:206-502)."""
 
     def __init__(self, env, tunable_params, change_notification=False, delta_change_notification=False,
-                 in_sim_change=False, **kwargs: Any):
+                 in_sim_change=False, _vec=None, **kwargs: Any):
         self.spec: BaseEnvSpec = from_gym_env(env)
-        self._vec = VecNSEnv(self.spec, tunable_params, 1, change_notification=change_notification,
-                             delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
-                             **kwargs)
+        self._vec = _vec if _vec is not None else VecNSEnv(
+            self.spec, tunable_params, 1, change_notification=change_notification,
+            delta_change_notification=delta_change_notification, in_sim_change=in_sim_change, **kwargs)
         v = self._vec
         self.tunable_params = tunable_params
         self.change_notification = change_notification
@@ -160,12 +160,22 @@ class _NSSingle:
     def get_default_params(self):
         return self._vec.get_default_params()
 
+    def _wrap(self, vec):
+        import copy as _copy
+
+        new = _copy.copy(self)            # shallow: shares the descriptor objects, not device state
+        new._vec = vec
+        new.unwrapped = _Unwrapped(new)
+        return new
+
     def get_planning_env(self):
+        """Planning copy (classic_control.py:120-136 / toy_text.py:471-481)."""
         assert self.has_reset, "The environment must be reset before getting the planning environment."
-        raise NotImplementedError("planning-env snapshots are the next scope row (SURVEY §8(f) rank 1)")
+        return self._wrap(self._vec.get_planning_env())
 
     def __deepcopy__(self, memo):
-        raise NotImplementedError("planning-env snapshots are the next scope row (SURVEY §8(f) rank 1)")
+        """`deepcopy(env)` sets is_sim_env on the copy (classic_control.py:138-186)."""
+        return self._wrap(self._vec.fork(theta_mode=0))
 
     def close(self):
         self._vec.close()

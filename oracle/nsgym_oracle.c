@@ -424,9 +424,8 @@ static void acrobot_dsdt(const double* th, const double* y, double a, double* d)
 static int env_step(int env, const double* th, double* s, int ai, float af, double* reward) {
   switch (env) {
     case NSG_ENV_CARTPOLE: { /* th: gravity masscart masspole force_mag tau length */
-      double gravity = th[0], masscart = th[1], masspole = th[2], force_mag = th[3], tau = th[4], length = th[5];
-      double total_mass = masspole + masscart;     /* _dependency_resolver classic_control.py:426-435 */
-      double polemass_length = length * masspole;  /* :436-444 */
+      double gravity = th[0], masspole = th[2], force_mag = th[3], tau = th[4], length = th[5];
+      double total_mass = th[6], polemass_length = th[7]; /* resolved by the caller (classic_control.py:424-444) */
       double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
       double force = ai == 1 ? force_mag : -force_mag;
       double costheta = cos(theta), sintheta = sin(theta);
@@ -551,6 +550,7 @@ static void reset_one(const nsg_config* cfg, const uint8_t* tables, const nsg_bu
   }
   rng_store(b->rng_env, N, i, &g);
   b->t[i] = 0; /* base.py:379 */
+  if (b->t_fork) b->t_fork[i] = 0; /* a reset planning copy: TimeLimit.reset() zeroes its elapsed count too */
   int persistent = (cfg->flags & NSG_F_PERSISTENT_PARAMS) != 0;
   for (int p = 0; p < P; p++) {
     const nsg_param_cfg* pc = &cfg->params[p];
@@ -631,11 +631,13 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
   int t = b->t[i];
   double reward = 0;
   int term = 0;
+  const int sim = (cfg->flags & NSG_F_SIM_ENV) != 0;
+  const int theta_live = !(sim && !(cfg->flags & NSG_F_IN_SIM_CHANGE));
   if (env == NSG_ENV_FROZENLAKE) {
     /* toy_text.py:362-377 */
     const nsg_param_cfg* pc = &cfg->params[0];
     double p[3] = {b->theta[0 * N + i], b->theta[1 * N + i], b->theta[2 * N + i]}, q[3];
-    int fired = sched_fire(pc, tables, t);
+    int fired = theta_live && sched_fire(pc, tables, t); /* frozen planning copy: toy_text.py:354-360 */
     double delta = 0.0;
     if (fired) {
       upd_dist(pc, tables, p, t, b->cursor ? &b->cursor[i] : NULL, q);
@@ -686,7 +688,7 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
       const nsg_param_cfg* pc = &cfg->params[p];
       int k = pc->theta_slot;
       tuned |= 1u << k;
-      if (sched_fire(pc, tables, t)) {
+      if (theta_live && sched_fire(pc, tables, t)) { /* frozen planning copy: classic_control.py:70-75 */
         pcg64 r;
         if (pc->uses_rng) rng_load(b->rng_upd + (int64_t)p * 4 * N, N, i, &r);
         nv[k] = upd_scalar(pc, tables, cur[k], t, pc->uses_rng ? &r : NULL, b->cursor ? &b->cursor[p * N + i] : NULL);
@@ -695,7 +697,7 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
       }
     }
     unsigned viol = constraint_mask(env, nv, cur, tuned); /* :87 */
-    double th[NSG_MAX_THETA];
+    double th[NSG_MAX_THETA + 2];
     for (int k = 0; k < K; k++) th[k] = cur[k];
     for (int p = 0; p < P; p++) { /* :87-92 */
       int k = cfg->params[p].theta_slot;
@@ -712,6 +714,15 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
       b->delta_change[p * N + i] = (float)delta;
       if (fired) cnt[NSG_CNT_FIRED * NSG_CNT_SHARDS]++;
     }
+    if (env == NSG_ENV_CARTPOLE) {
+      if (sim && !theta_live && b->derived) { /* frozen planning copy: resolver never runs again */
+        th[6] = b->derived[0 * N + i];
+        th[7] = b->derived[1 * N + i];
+      } else { /* _dependency_resolver, classic_control.py:426-444 */
+        th[6] = th[2] + th[1];
+        th[7] = th[5] * th[2];
+      }
+    }
     double s[4];
     for (int k = 0; k < PHYS_DIM[env]; k++) s[k] = b->phys[k * N + i];
     int ai = 0; float af = 0;
@@ -723,7 +734,9 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
   }
   t += 1; /* base.py:314 */
   b->t[i] = t;
-  int trunc = cfg->max_episode_steps > 0 && t >= cfg->max_episode_steps; /* TimeLimit [UPSTREAM] */
+  /* TimeLimit [UPSTREAM] counts steps of ITS env: a planning copy restarts at the fork */
+  int elapsed = t - ((sim && b->t_fork) ? b->t_fork[i] : 0);
+  int trunc = cfg->max_episode_steps > 0 && elapsed >= cfg->max_episode_steps;
   b->reward[i] = (float)reward;
   b->terminated[i] = (uint8_t)term;
   b->truncated[i] = (uint8_t)trunc;
@@ -753,6 +766,77 @@ int orc_step(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b,
 int orc_step_range(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N, const void* actions,
                    int64_t lo, int64_t hi, uint64_t* cnt) {
   for (int64_t i = lo; i < hi; i++) step_one(cfg, tables, b, N, i, actions, cnt);
+  return 0;
+}
+
+/* get_planning_env() / __deepcopy__ for all envs (classic_control.py:120-186, toy_text.py:471-511) */
+int orc_fork(const nsg_config* scfg, const nsg_buffers* sb, const nsg_config* dcfg, const nsg_buffers* db, int64_t N,
+             uint64_t entropy, int theta_mode) {
+  int env = scfg->env_type, P = scfg->n_params;
+  const int fl = env == NSG_ENV_FROZENLAKE;
+  const int in_sim_change = (dcfg->flags & NSG_F_IN_SIM_CHANGE) != 0;
+  for (int64_t i = 0; i < N; i++) {
+    for (int k = 0; k < PHYS_DIM[env]; k++) db->phys[k * N + i] = sb->phys[k * N + i];
+    if (fl) db->cell[i] = sb->cell[i];
+    db->t[i] = sb->t[i];
+    db->t_fork[i] = sb->t[i];
+    db->status[i] = sb->status[i];
+    for (int r = 0; r < (fl ? 3 : P); r++) {
+      double cur = sb->theta[r * N + i];
+      double init = fl ? scfg->initial_prob[r] : scfg->base_theta[scfg->params[r].theta_slot];
+      db->theta[r * N + i] = theta_mode == 1 ? init : cur;
+    }
+    if (env == NSG_ENV_CARTPOLE && db->derived) { /* sim_env._dependency_resolver() at copy time, :183 */
+      double cur[NSG_MAX_THETA];
+      for (int k = 0; k < 6; k++) cur[k] = scfg->base_theta[k];
+      for (int p = 0; p < P; p++) cur[scfg->params[p].theta_slot] = sb->theta[p * N + i];
+      db->derived[0 * N + i] = cur[2] + cur[1];
+      db->derived[1 * N + i] = cur[5] * cur[2];
+    }
+    if (fl) /* which P the copy steps with: see include/nsgym_hip.h nsg_fork and toy_text.py:479-480,505-508 */
+      for (int k = 0; k < 3; k++)
+        db->table_prob[k * N + i] = (in_sim_change || theta_mode == 1) ? scfg->initial_prob[k] : sb->table_prob[k * N + i];
+    for (int p = 0; p < P; p++) {
+      if (db->cursor && sb->cursor) db->cursor[p * N + i] = sb->cursor[p * N + i]; /* deepcopy(tunable_params) */
+      db->env_change[p * N + i] = sb->env_change[p * N + i];
+      db->delta_change[p * N + i] = sb->delta_change[p * N + i];
+      if (scfg->params[p].uses_rng) { /* _reseed_planning_env_rngs: fresh entropy */
+        pcg64 r;
+        pcg_seed(&r, entropy + (uint64_t)i, 7100 + p);
+        rng_store(db->rng_upd + (int64_t)p * 4 * N, N, i, &r);
+      }
+    }
+    pcg64 g; /* the copy's base env is a new gym.make(): unseeded np_random */
+    pcg_seed(&g, entropy + (uint64_t)i, 7001);
+    rng_store(db->rng_env, N, i, &g);
+    if (!fl) for (int k = 0; k < OBS_DIM[env]; k++) db->obs[i * OBS_DIM[env] + k] = sb->obs[i * OBS_DIM[env] + k];
+    db->reward[i] = sb->reward[i];
+    db->terminated[i] = sb->terminated[i];
+    db->truncated[i] = sb->truncated[i];
+    if (db->prob && sb->prob) db->prob[i] = sb->prob[i];
+    if (dcfg->flags & NSG_F_TRACK_RETURNS) {
+      db->ep_return[i] = (scfg->flags & NSG_F_TRACK_RETURNS) ? sb->ep_return[i] : 0.0f;
+      db->ep_length[i] = 0; db->last_return[i] = 0.0f; db->last_length[i] = 0;
+    }
+  }
+  return 0;
+}
+
+int orc_seed_streams(const nsg_config* cfg, const nsg_buffers* b, int64_t N, const uint64_t* seeds, int which) {
+  for (int64_t i = 0; i < N; i++) {
+    if (which == 0) {
+      pcg64 g;
+      pcg_seed(&g, seeds[i], -1);
+      rng_store(b->rng_env, N, i, &g);
+    } else {
+      for (int p = 0; p < cfg->n_params; p++)
+        if (cfg->params[p].uses_rng) {
+          pcg64 r;
+          pcg_seed(&r, seeds[i], cfg->params[p].rng_child);
+          rng_store(b->rng_upd + (int64_t)p * 4 * N, N, i, &r);
+        }
+    }
+  }
   return 0;
 }
 

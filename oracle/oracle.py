@@ -59,6 +59,7 @@ def _ptr(a):
 
 class OracleVecEnv:
     def __init__(self, env, tunable_params, num_envs, **kwargs):
+        self._tp, self._kwargs = tunable_params, dict(kwargs)
         self.cfg, self.tables, self.spec, self.param_names = compile_config(env, tunable_params, **kwargs)
         self.tab = np.frombuffer(self.tables, dtype=np.uint8).copy()
         self.N = N = int(num_envs)
@@ -69,7 +70,7 @@ class OracleVecEnv:
         z = lambda shape, dt: np.zeros(shape, dtype=dt)  # noqa: E731
         self.a = {
             "phys": z((max(PHYS_DIM[et], 1), N), np.float64), "cell": z(N, np.int32),
-            "theta": z((max(rows, 1), N), np.float64), "table_prob": z((3, N), np.float64), "t": z(N, np.int32), "status": z(N, np.uint8),
+            "theta": z((max(rows, 1), N), np.float64), "table_prob": z((3, N), np.float64), "derived": z((2, N), np.float64), "t": z(N, np.int32), "t_fork": z(N, np.int32), "status": z(N, np.uint8),
             "rng_env": z((N, 4), np.uint64), "rng_upd": z((max(P, 1), N, 4), np.uint64),
             "cursor": z((max(P, 1), N), np.int32), "obs": z((N, OBS_DIM[et]), np.float32),
             "reward": z(N, np.float32), "terminated": z(N, np.uint8), "truncated": z(N, np.uint8),
@@ -98,6 +99,19 @@ class OracleVecEnv:
         assert act.shape == (self.N,)
         lib().orc_step(C.byref(self.cfg), _ptr(self.tab), C.byref(self.bufs), C.c_int64(self.N), _ptr(act))
         return self.a
+
+    def fork(self, theta_mode=0, entropy=0):
+        """get_planning_env()/__deepcopy__ twin of VecNSEnv.fork."""
+        kw = dict(self._kwargs)
+        kw["is_sim_env"] = True
+        dst = OracleVecEnv(self.spec, self._tp, self.N, **kw)
+        lib().orc_fork(C.byref(self.cfg), C.byref(self.bufs), C.byref(dst.cfg), C.byref(dst.bufs), C.c_int64(self.N),
+                       C.c_uint64(entropy), int(theta_mode))
+        return dst
+
+    def seed_streams(self, seeds, which=0):
+        s = np.ascontiguousarray(seeds, dtype=np.uint64)
+        lib().orc_seed_streams(C.byref(self.cfg), C.byref(self.bufs), C.c_int64(self.N), _ptr(s), int(which))
 
     def step_mt(self, actions, nthreads):
         dt = np.float32 if self.action_is_float else np.int32

@@ -450,6 +450,115 @@ def gen_reset_semantics(gym, S, U, CC):
     return out
 
 
+# --------------------------------------------------------------------------- planning envs
+
+PLANNING_SPECS = {
+    # (env, params, flags, fork kind): reference get_planning_env / __deepcopy__ semantics
+    # (classic_control.py:120-186, toy_text.py:471-511, base.py:433-441)
+    "cartpole_planning_theta0": {   # no delta notification -> planning env carries the INITIAL θ, frozen
+        "env_id": "CartPole-v1", "seed": 3, "pre": 12, "post": 60, "kind": "planning",
+        "params": {"masspole": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["IncrementUpdate", {"k": 0.05}]},
+                   "length": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["IncrementUpdate", {"k": 0.02}]}},
+        "flags": {"change_notification": True, "delta_change_notification": False},
+    },
+    "cartpole_planning_current": {  # delta notification -> current θ, frozen (is_sim_env and not in_sim_change)
+        "env_id": "CartPole-v1", "seed": 4, "pre": 12, "post": 60, "kind": "planning",
+        "params": {"masspole": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["IncrementUpdate", {"k": 0.05}]},
+                   "length": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["IncrementUpdate", {"k": 0.02}]}},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "cartpole_deepcopy_in_sim_change": {  # in_sim_change -> θ keeps evolving in the copy (fn state copied)
+        "env_id": "CartPole-v1", "seed": 5, "pre": 10, "post": 60, "kind": "deepcopy",
+        "params": {"masspole": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["IncrementUpdate", {"k": 0.05}]},
+                   "force_mag": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["StepWiseUpdate", {"param_list": [11.0, 12.0, 13.0, 9.0, 8.0, 7.5, 7.0, 6.5, 6.0, 5.5, 5.0, 4.5, 4.0, 3.5]}]}},
+        "flags": {"change_notification": True, "delta_change_notification": True, "in_sim_change": True},
+    },
+    "pendulum_deepcopy_frozen": {
+        "env_id": "Pendulum-v1", "seed": 6, "pre": 150, "post": 120, "kind": "deepcopy",
+        "params": {"g": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["IncrementUpdate", {"k": 0.01}]}},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "frozenlake_planning_theta0": {
+        "env_id": "FrozenLake-v1", "make_kwargs": {"is_slippery": False}, "seed": 7, "pre": 6, "post": 40, "kind": "planning",
+        "params": {"P": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["DistributionDecrementUpdate", {"k": 0.05}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [1.0, 0.0, 0.0]},
+        "flags": {"change_notification": True, "delta_change_notification": False},
+    },
+    "frozenlake_deepcopy_frozen": {
+        "env_id": "FrozenLake-v1", "make_kwargs": {"is_slippery": False}, "seed": 8, "pre": 6, "post": 40, "kind": "deepcopy",
+        "params": {"P": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["DistributionDecrementUpdate", {"k": 0.05}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [1.0, 0.0, 0.0]},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "frozenlake_deepcopy_in_sim_change": {
+        "env_id": "FrozenLake-v1", "make_kwargs": {"is_slippery": False}, "seed": 9, "pre": 6, "post": 40, "kind": "deepcopy",
+        "params": {"P": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["DistributionDecrementUpdate", {"k": 0.05}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [1.0, 0.0, 0.0]},
+        "flags": {"change_notification": True, "delta_change_notification": True, "in_sim_change": True},
+    },
+}
+
+
+def gen_planning(gym, S, U, CC, FL, spec):
+    """Run the real env `pre` steps, fork it the reference's way, then step the FORK `post` times
+    (stopping at its first done).  FrozenLake forks draw slip outcomes from a fresh-entropy
+    np_random, so their fixtures record the uniform draws the fork consumed (captured from the
+    fork's own generator state) instead of relying on a seed."""
+    import copy as _copy
+
+    env_id = spec["env_id"]
+    is_fl = env_id == "FrozenLake-v1"
+    cont = env_id in ("Pendulum-v1",)
+    tp = {p: build_fn(S, U, fs) for p, fs in spec["params"].items()}
+    Wr = FL if is_fl else CC
+    env = Wr(gym.make(env_id, **spec.get("make_kwargs", {})), tp, **spec["flags"], **spec.get("wrapper_kwargs", {}))
+    pnames = list(spec["params"].keys())
+    T = spec["pre"] + spec["post"]
+    actions = make_actions(env_id, T, 1)[:, 0]
+    env.reset(seed=spec["seed"])
+    k = 0
+    while k < spec["pre"]:
+        a = actions[k]
+        obs, r, term, trunc, info = env.step(np.array([a], dtype=np.float32) if cont else int(a))
+        assert not (term or trunc), "pick a seed whose first episode outlives `pre`"
+        k += 1
+    sim = env.get_planning_env() if spec["kind"] == "planning" else _copy.deepcopy(env)
+    assert sim.is_sim_env
+    out = {"actions": actions, "pre": np.int32(spec["pre"]), "fork_t": np.int32(sim.t)}
+    if is_fl:
+        # make the fork's slip draws reproducible: re-seed its base env stream with a recorded seed
+        sim.unwrapped.np_random = np.random.default_rng(4242)
+        out["fork_env_seed"] = np.uint64(4242)
+        out["fork_state"] = np.int32(sim.unwrapped.s)
+        out["fork_theta"] = np.array(sim.transition_prob, dtype=np.float64)
+    else:
+        out["fork_state"] = np.array(sim.unwrapped.state, dtype=np.float64)
+        out["fork_theta"] = np.array([getattr(sim.unwrapped, p) for p in pnames], dtype=np.float64)
+    st, rw, te, tr, ec, dc, th, rt, pr = [], [], [], [], [], [], [], [], []
+    for j in range(spec["post"]):
+        a = actions[spec["pre"] + j]
+        obs, r, term, trunc, info = sim.step(np.array([a], dtype=np.float32) if cont else int(a))
+        st.append(np.atleast_1d(obs["state"])); rw.append(r); te.append(term); tr.append(trunc)
+        ec.append([info["Ground Truth Env Change"][p] for p in pnames])
+        dc.append([info["Ground Truth Delta Change"][p] for p in pnames])
+        th.append(list(sim.transition_prob) if is_fl else [getattr(sim.unwrapped, p) for p in pnames])
+        rt.append(obs["relative_time"])
+        if is_fl:
+            pr.append(info["prob"])
+        if term or trunc:
+            break
+    out.update(state=np.array(st), reward=np.array(rw, dtype=np.float64), terminated=np.array(te, dtype=np.uint8),
+               truncated=np.array(tr, dtype=np.uint8), gt_env_change=np.array(ec, dtype=np.uint8),
+               gt_delta_change=np.array(dc, dtype=np.float64), theta=np.array(th, dtype=np.float64),
+               relative_time=np.array(rt, dtype=np.int32))
+    if is_fl:
+        out["prob"] = np.array(pr, dtype=np.float64)
+    # the source env must be untouched by the fork's steps
+    out["src_theta_after"] = np.array(list(env.transition_prob) if is_fl else [getattr(env.unwrapped, p) for p in pnames])
+    out["src_t_after"] = np.int32(env.t)
+    return out
+
+
 # --------------------------------------------------------------------------- NumPy bit streams
 
 
@@ -505,6 +614,7 @@ def main():
         "scalar_update_specs": SCALAR_UPDATE_SPECS,
         "dist_update_specs": DIST_UPDATE_SPECS,
         "traj_specs": TRAJ_SPECS,
+        "planning_specs": PLANNING_SPECS,
     }
     np.savez_compressed(os.path.join(HERE, "numpy_streams.npz"), **gen_numpy_streams())
     np.savez_compressed(os.path.join(HERE, "schedulers.npz"), **gen_schedulers(S))
@@ -514,6 +624,10 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"traj_{name}.npz"), **rec)
         print(name, "episodes:", int(rec["was_reset"].sum()), "fired:", int(rec["gt_env_change"].sum()))
     np.savez_compressed(os.path.join(HERE, "reset_semantics.npz"), **gen_reset_semantics(gym, S, U, CC))
+    for name, spec in PLANNING_SPECS.items():
+        rec = gen_planning(gym, S, U, CC, FL, spec)
+        np.savez_compressed(os.path.join(HERE, f"plan_{name}.npz"), **rec)
+        print(name, "fork steps:", len(rec["reward"]), "fork theta:", rec["fork_theta"], "last theta:", rec["theta"][-1])
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)  # dict order is semantic (child-seed index)
     print("golden vectors written to", HERE)

@@ -1,0 +1,124 @@
+"""Planning-env snapshots on the GPU: nsg_fork through VecNSEnv against
+(1) the reference's own get_planning_env()/__deepcopy__ fixtures and (2) the oracle at scale;
+plus the relational checks of the reference's tests/test_deepcopy.py."""
+import copy
+
+import numpy as np
+import pytest
+
+from tests.test_oracle_planning import PLAN, run_planning
+from tests.util import TRAJ_SPECS, GpuView, OracleView, compare_views, make_env_from_spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _vec(*a, **k):
+    from ns_gym_amd.vec_env import VecNSEnv
+
+    return VecNSEnv(*a, **k)
+
+
+class _PlanView(GpuView):
+    """GpuView whose env accepts the oracle binding's seed_streams(seeds, which=0|1) signature."""
+
+    def __init__(self, env):
+        super().__init__(env)
+        if not hasattr(env, "_which_int"):
+            orig = env.seed_streams
+            env.seed_streams = lambda seeds, which=0: orig(seeds, "env" if which in (0, "env") else "update")
+            env._which_int = True
+
+
+@pytest.mark.parametrize("name", sorted(PLAN))
+def test_planning_env_matches_reference(name):
+    run_planning(_vec, _PlanView, name, lambda env, mode: env.fork(theta_mode=mode, entropy=99))
+
+
+def test_deepcopy_semantics_like_reference_tests():
+    """tests/test_deepcopy.py of the reference: is_sim_env set, params match at copy time, copies
+    independent, θ frozen in the copy unless in_sim_change, t preserved."""
+    import torch
+
+    from ns_gym_amd import make
+    from ns_gym_amd.schedulers import ContinuousScheduler
+    from ns_gym_amd.update_functions import IncrementUpdate
+
+    n = 512
+    for in_sim_change in (False, True):
+        env = _vec(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1),
+                                         "gravity": IncrementUpdate(ContinuousScheduler(), k=0.1)}, n,
+                   change_notification=True, delta_change_notification=True, in_sim_change=in_sim_change)
+        env.reset(seed=0)
+        a = torch.zeros(n, dtype=torch.int32, device="cuda")
+        for _ in range(3):
+            env.step(a)
+        sim = copy.deepcopy(env)
+        assert sim.is_sim_env and not env.is_sim_env
+        torch.testing.assert_close(sim.theta, env.theta)
+        torch.testing.assert_close(sim.t, env.t)
+        th0 = sim.theta.clone()
+        obs, *_ = sim.step(a)
+        live = (sim.t == env.t + 1)                      # envs that stepped (not autoreset)
+        assert live.any()
+        if in_sim_change:
+            assert torch.all(sim.theta[:, live] > th0[:, live])
+            assert torch.all(obs["env_change"]["masspole"][live] == 1)
+        else:
+            torch.testing.assert_close(sim.theta[:, live], th0[:, live])
+            assert torch.all(obs["env_change"]["masspole"] == 0)
+        # the source is untouched by the copy's step
+        assert torch.all(env.t[live] == sim.t[live] - 1)
+        env.step(a)
+        assert not torch.equal(env.theta, th0)
+        sim.close(); env.close()
+
+
+def test_get_planning_env_theta_modes_and_reset_requirement():
+    import torch
+
+    from ns_gym_amd import make
+    from ns_gym_amd.schedulers import ContinuousScheduler
+    from ns_gym_amd.update_functions import IncrementUpdate
+
+    for delta_notif in (False, True):
+        env = _vec(make("Pendulum-v1"), {"m": IncrementUpdate(ContinuousScheduler(), k=0.25)}, 256,
+                   change_notification=True, delta_change_notification=delta_notif)
+        with pytest.raises(AssertionError):
+            env.get_planning_env()
+        env.reset(seed=1)
+        a = torch.zeros(256, dtype=torch.float32, device="cuda")
+        for _ in range(4):
+            env.step(a)
+        plan = env.get_planning_env()
+        want = env.theta if delta_notif else torch.full_like(env.theta, 1.0)
+        torch.testing.assert_close(plan.theta, want)
+        assert plan.is_sim_env
+        plan2 = plan.get_planning_env()          # a planning copy of a planning copy keeps its θ
+        torch.testing.assert_close(plan2.theta, plan.theta)
+        for e in (plan2, plan, env):
+            e.close()
+
+
+@pytest.mark.parametrize("name,theta_mode", [("c1_cartpole_masspole_inc", 1), ("c2_cartpole_gravity_rw", 0),
+                                              ("c3_frozenlake_step50", 0), ("c4_acrobot_mass2_inc", 0)])
+def test_fork_matches_oracle_at_scale(name, theta_mode):
+    from oracle.oracle import OracleVecEnv
+    from tests.golden.make_golden import make_actions
+
+    n, pre, post = 4096, 40, 80
+    spec = dict(TRAJ_SPECS[name])
+    spec["flags"] = {**spec["flags"], "in_sim_change": name.startswith("c2")}
+    is_fl = spec["env_id"] == "FrozenLake-v1"
+    g = GpuView(make_env_from_spec(_vec, spec, n=n))
+    o = OracleView(make_env_from_spec(OracleVecEnv, spec, n=n))
+    seeds = np.arange(n, dtype=np.uint64) + np.uint64(777)
+    acts = make_actions(spec["env_id"], pre + post, n)
+    g.reset(seeds); o.reset(seeds)
+    for k in range(pre):
+        g.step(acts[k]); o.step(acts[k])
+    gs, os_ = GpuView(g.env.fork(theta_mode=theta_mode, entropy=31337)), OracleView(o.env.fork(theta_mode=theta_mode, entropy=31337))
+    compare_views(gs._out(), os_._out(), is_fl, "at fork")
+    for k in range(pre, pre + post):
+        compare_views(gs.step(acts[k]), os_.step(acts[k]), is_fl, f"fork step {k - pre}")
+    # the sources advance independently of their copies
+    compare_views(g.step(acts[0]), o.step(acts[0]), is_fl, "source after fork")

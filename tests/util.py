@@ -135,3 +135,4 @@ def compare_views(a, b, is_fl, tag=""):
     np.testing.assert_allclose(a["reward"], b["reward"], rtol=1e-5, atol=1e-5, err_msg=tag)
     for k in ("terminated", "truncated", "env_change", "t"):
         np.testing.assert_array_equal(a[k], b[k], err_msg=f"{tag} {k}")
+
