@@ -48,8 +48,11 @@ enum {
                                     LINK_COM_POS_1 LINK_COM_POS_2 LINK_MOI                    */
   NSG_ENV_MOUNTAINCAR = 3,       /* gravity force                                             */
   NSG_ENV_MOUNTAINCAR_CONT = 4,  /* power                                                     */
-  NSG_ENV_FROZENLAKE = 5,        /* P  (3-way slip distribution, ns_gym/wrappers/toy_text.py) */
-  NSG_ENV_COUNT = 6
+  NSG_ENV_FROZENLAKE = 5,        /* P  (3-way slip distribution, ns_gym/wrappers/toy_text.py:265-519) */
+  NSG_ENV_CLIFFWALKING = 6,      /* P  (4-way slip [a,a+1,a-1,a+2], toy_text.py:14-262)        */
+  NSG_ENV_BRIDGE = 7,            /* P | P_left, P_right (3-way slip, toy_text.py:524-715,
+                                    ns_gym/envs/Bridge.py); θ slots 0 = P, 1 = P_left, 2 = P_right */
+  NSG_ENV_COUNT = 8
 };
 
 /* ---- schedulers (ns_gym/schedulers.py; range gate ns_gym/base.py:67-81) -------------- */
@@ -83,15 +86,16 @@ enum {
   NSG_UPD_RW_DRIFT_TREND = 14,/* :43-81   u0=alpha u1=mu u2=sigma u3=slope */
   NSG_UPD_OU = 15,            /* :310-346 u0=theta u1=mu u2=sigma */
   NSG_UPD_BOUNDED_RW = 16,    /* :411-448 u0=mu u1=sigma u2=lo u3=hi */
-  /* distribution update functions (ns_gym/update_functions/distribution.py), n = 3 */
+  /* distribution update functions (ns_gym/update_functions/distribution.py); n = 3 (FrozenLake,
+     Bridge) or 4 (CliffWalking); vector constants are packed n at a time in u[] */
   NSG_UPD_D_INCREMENT = 32,   /* :41-67   u0=k                    */
   NSG_UPD_D_DECREMENT = 33,   /* :70-97   u0=k                    */
   NSG_UPD_D_STEPWISE = 34,    /* :100-130 triples in value table  */
   NSG_UPD_D_CYCLIC = 35,      /* :334-356 triples in value table  */
   NSG_UPD_D_NOUPDATE = 36,    /* :217-231                         */
   NSG_UPD_D_UNIFORMDRIFT = 37,/* :234-261 u0=rate                 */
-  NSG_UPD_D_TARGETREV = 38,   /* :264-293 u0..u2=target u3=theta  */
-  NSG_UPD_D_LERP = 39         /* :296-331 u0..u2=start u3..u5=end u6=T */
+  NSG_UPD_D_TARGETREV = 38,   /* :264-293 u[0..n)=target u[n]=theta */
+  NSG_UPD_D_LERP = 39         /* :296-331 u[0..n)=start u[n..2n)=end u[2n]=T */
 };
 
 /* flags of nsg_config.flags (constructor kwargs of NSWrapper, ns_gym/base.py:222-232) */
@@ -100,6 +104,7 @@ enum {
 #define NSG_F_PERSISTENT_PARAMS 0x4u
 #define NSG_F_TRACK_RETURNS 0x8u   /* keep per-env episode return / length accumulators   */
 #define NSG_F_MODIFIED_REWARDS 0x10u /* FrozenLake modified_rewards (toy_text.py:465-468)  */
+#define NSG_F_TERMINAL_CLIFF 0x100u /* CliffWalking terminal_cliff (toy_text.py:39,126-128)              */
 #define NSG_F_SIM_ENV 0x40u        /* planning copy: is_sim_env (base.py:270, classic_control.py:184)   */
 #define NSG_F_IN_SIM_CHANGE 0x80u  /* in_sim_change: θ keeps evolving inside planning copies            */
 
@@ -135,7 +140,7 @@ typedef struct nsg_param_cfg {
   int32_t sched_tab_len; /* bit table: number of valid bits                                 */
   int32_t val_tab_off;   /* value table: offset in doubles into the table blob              */
   int32_t val_tab_len;   /* value table: number of entries (triples for distributions)      */
-  double u[8];
+  double u[10];
   uint64_t fn_seed;      /* constructor seed of a stochastic fn (valid if has_fn_seed)      */
   int32_t has_fn_seed;
   int32_t uses_rng;      /* 1 if the update fn owns a PCG64 stream                          */
@@ -150,8 +155,9 @@ typedef struct nsg_config {
   int32_t nrow, ncol;         /* FrozenLake map (ns_gym/wrappers/toy_text.py:314-319)       */
   int32_t desc_tab_off;       /* FrozenLake desc bytes: offset in BYTES into the table blob */
   double base_theta[NSG_MAX_THETA]; /* construction-time θ (TUNABLE_PARAMS, base.py:1156)   */
-  double initial_prob[3];     /* FrozenLake initial_prob_dist (toy_text.py:291)             */
-  double letter_reward[4];    /* FrozenLake modified_rewards for S,F,H,G                    */
+  double initial_prob[2][4];  /* initial_prob_dist of the grid wrappers (toy_text.py:37,291,556);
+                                 row 1 = Bridge's right-half initial distribution            */
+  double letter_reward[4];    /* modified_rewards for S,F,H,G (FrozenLake, CliffWalking)     */
   nsg_param_cfg params[NSG_MAX_PARAMS];
 } nsg_config;
 
@@ -160,9 +166,9 @@ typedef struct nsg_config {
  * which are needed). */
 typedef struct nsg_buffers {
   double* phys;          /* [F][N] integrator state, fp64 like the reference              */
-  int32_t* cell;         /* [N]    FrozenLake state s                                     */
-  double* theta;         /* [P][N] tuned θ   (FrozenLake: [3][N] transition_prob)         */
-  double* table_prob;    /* [3][N] FrozenLake: probabilities baked into the wrapper's P table.
+  int32_t* cell;         /* [N]    grid envs: state index s                                */
+  double* theta;         /* [P][N] tuned θ   (grid envs: [P][n][N] distributions, n = 3 or 4) */
+  double* table_prob;    /* [n][N] FrozenLake / CliffWalking: probabilities baked into the wrapper's P table.
                             Differs from theta after a reset: the reference's reset restores
                             transition_prob (toy_text.py:396) but its next step re-installs the
                             wrapper's un-reset self.P (toy_text.py:365-367), so the previous

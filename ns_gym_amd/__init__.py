@@ -10,7 +10,7 @@ from .envs import TUNABLE_PARAMS, make  # noqa: F401
 
 __version__ = "0.1.0"
 
-_LAZY = {"VecNSEnv": "vec_env", "NSClassicControlWrapper": "wrappers", "NSFrozenLakeWrapper": "wrappers",
+_LAZY = {"VecNSEnv": "vec_env", "NSClassicControlWrapper": "wrappers", "NSFrozenLakeWrapper": "wrappers", "NSCliffWalkingWrapper": "wrappers", "NSBridgeWrapper": "wrappers",
          "ConstraintViolationWarning": "wrappers", "functional": None, "vec_env": None, "wrappers": None,
          "distributed": None}
 

@@ -9,7 +9,10 @@ NSG_MAX_THETA = 8
 NSG_MAX_SEGMENTS = 8
 
 # env types
-ENV_CARTPOLE, ENV_PENDULUM, ENV_ACROBOT, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONT, ENV_FROZENLAKE = range(6)
+(ENV_CARTPOLE, ENV_PENDULUM, ENV_ACROBOT, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONT, ENV_FROZENLAKE,
+ ENV_CLIFFWALKING, ENV_BRIDGE) = range(8)
+GRID_ENVS = (ENV_FROZENLAKE, ENV_CLIFFWALKING, ENV_BRIDGE)
+N_DIST = {ENV_FROZENLAKE: 3, ENV_CLIFFWALKING: 4, ENV_BRIDGE: 3}
 
 # schedulers
 (SCHED_CONTINUOUS, SCHED_PERIODIC, SCHED_BURST, SCHED_TABLE, SCHED_RANDOM, SCHED_DECAYING,
@@ -28,6 +31,7 @@ F_DELTA_NOTIFICATION = 0x2
 F_PERSISTENT_PARAMS = 0x4
 F_TRACK_RETURNS = 0x8
 F_MODIFIED_REWARDS = 0x10
+F_TERMINAL_CLIFF = 0x100
 F_SIM_ENV = 0x40
 F_IN_SIM_CHANGE = 0x80
 
@@ -54,7 +58,7 @@ class ParamCfg(C.Structure):
         ("sched_tab_len", C.c_int32),
         ("val_tab_off", C.c_int32),
         ("val_tab_len", C.c_int32),
-        ("u", C.c_double * 8),
+        ("u", C.c_double * 10),
         ("fn_seed", C.c_uint64),
         ("has_fn_seed", C.c_int32),
         ("uses_rng", C.c_int32),
@@ -72,7 +76,7 @@ class Config(C.Structure):
         ("ncol", C.c_int32),
         ("desc_tab_off", C.c_int32),
         ("base_theta", C.c_double * NSG_MAX_THETA),
-        ("initial_prob", C.c_double * 3),
+        ("initial_prob", (C.c_double * 4) * 2),
         ("letter_reward", C.c_double * 4),
         ("params", ParamCfg * NSG_MAX_PARAMS),
     ]

@@ -400,134 +400,218 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
 }
 
 // ============================================================================================
-// FrozenLake step for env i (integer / categorical path, bit-exact).
+// Grid envs (FrozenLake, CliffWalking, Bridge): integer / categorical path, one env per lane.
+// FrozenLake and CliffWalking are bit-exact with the reference incl. the env-stream draws.
 // ============================================================================================
-__device__ __forceinline__ void step_frozenlake(const Segment& sg, const Tables& tb, const void* actions, const StepOut& out,
-                                                int64_t i, bool active, WaveCounts& wc) {
+__host__ __device__ inline bool is_grid_env(int e) { return e == NSG_ENV_FROZENLAKE || e == NSG_ENV_CLIFFWALKING || e == NSG_ENV_BRIDGE; }
+
+__device__ __forceinline__ const double* grid_initial(const nsg_config& cfg, int p) {
+  return (cfg.env_type == NSG_ENV_BRIDGE && cfg.params[p].theta_slot == 2) ? cfg.initial_prob[1] : cfg.initial_prob[0];
+}
+__device__ __forceinline__ int grid_start_state(const nsg_config& cfg, const uint8_t* desc) {
+  if (cfg.env_type == NSG_ENV_CLIFFWALKING) return (cfg.nrow - 1) * cfg.ncol;  // start_state_index = (3, 0)
+  if (cfg.env_type == NSG_ENV_BRIDGE) return 2 * cfg.ncol + 4;                  // envs/Bridge.py:110
+  const int nS = cfg.nrow * cfg.ncol;
+  for (int k = 0; k < nS; k++)
+    if (desc[k] == 'S') return k;
+  return 0;
+}
+
+template <int ENV>
+__device__ __forceinline__ void step_grid(const Segment& sg, const Tables& tb, const void* actions, const StepOut& out,
+                                          int64_t i, bool active, WaveCounts& wc) {
+  constexpr int ND = ENV == NSG_ENV_CLIFFWALKING ? 4 : 3;
   const nsg_config& cfg = sg.cfg;
   const nsg_buffers& b = sg.buf;
   const int64_t N = sg.N;
-  const nsg_param_cfg& pc = cfg.params[0];
+  const int P = cfg.n_params;
   const bool persistent = (cfg.flags & NSG_F_PERSISTENT_PARAMS) != 0;
   const bool sim = (cfg.flags & NSG_F_SIM_ENV) != 0;
-  const bool theta_live = !(sim && !(cfg.flags & NSG_F_IN_SIM_CHANGE));  // toy_text.py:354-360
+  const bool theta_live = !(sim && !(cfg.flags & NSG_F_IN_SIM_CHANGE));  // toy_text.py:170-176,354-360,636-645
   const uint8_t* desc = tb.base + cfg.desc_tab_off;
 
-  const uint32_t o1 = (uint32_t)i, o4 = o1 * 4u, o8 = o1 * 8u;  // per-lane byte offsets (N <= 2^27)
-  const unsigned st = active ? ldg(b.status, o1) : 0u;
-  const int t = active ? ldg(b.t, o4) : 0;
+  const unsigned st = active ? b.status[i] : 0u;
+  const int t = active ? b.t[i] : 0;
   const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);
   const bool do_step = active && !do_reset;
 
   int cell = do_step ? b.cell[i] : 0;
   const int a = do_step ? ((const int32_t*)actions)[i] : 0;
-  Pcg g = {0, 0, 0, 0};
-  if (active) pcg_load(b.rng_env, N, i, g);
-  // both paths consume exactly one random(): FrozenLakeEnv.step's categorical_sample and
-  // FrozenLakeEnv.reset's categorical_sample over the one-hot initial_state_distrib
-  const double r = active ? pcg_double(g) : 0.0;
-  if (active) pcg_store_state(b.rng_env, N, i, g);
+  // one uniform per step from the env stream (categorical_sample / np.random.choice); FrozenLakeEnv
+  // and CliffWalkingEnv.reset also draw one (categorical_sample over the one-hot start distribution),
+  // Bridge.reset draws nothing (envs/Bridge.py:103-111)
+  double r = 0.0;
+  if (do_step || (do_reset && ENV != NSG_ENV_BRIDGE)) {
+    Pcg g;
+    pcg_load(b.rng_env, N, i, g);
+    r = pcg_double(g);
+    pcg_store_state(b.rng_env, N, i, g);
+  }
 
-  bool fired = false;
-  double delta = 0.0, reward = 0.0, prob = 1.0;
+  // ---- θ: every distribution parameter (toy_text.py:178-185, 362-366, 605-631) ---------------
+  unsigned n_fired = 0;
+  double pt[ND];  // the probabilities the transition samples from
+#pragma unroll
+  for (int k = 0; k < ND; k++) pt[k] = cfg.initial_prob[0][k];
+  bool have_table = false;
+  int want = 0;  // Bridge: which param's distribution applies to this cell (0 = P, 1 = P_left, 2 = P_right)
+  if constexpr (ENV == NSG_ENV_BRIDGE) {
+    bool split = false;
+    for (int p = 0; p < P; p++) split |= cfg.params[p].theta_slot != 0;
+    if (split) {
+      const int col = cell % cfg.ncol;
+      want = col < cfg.ncol / 2 ? 1 : 2;  // get_loc_based_prob, envs/Bridge.py:149-158
+      const double* ini = want == 2 ? cfg.initial_prob[1] : cfg.initial_prob[0];
+#pragma unroll
+      for (int k = 0; k < ND; k++) pt[k] = ini[k];  // an omitted side stays at its initial value
+    }
+  }
+  for (int p = 0; p < P; p++) {
+    const nsg_param_cfg& pc = cfg.params[p];
+    const bool fired = do_step && theta_live && sched_fire(pc, tb, t);
+    double delta = 0.0;
+    double q[ND];
+    bool have_q = false;
+    if (fired) {
+      double pp[ND];
+#pragma unroll
+      for (int k = 0; k < ND; k++) pp[k] = b.theta[(int64_t)(p * ND + k) * N + i];
+      int cursor = 0;
+      const bool has_cur = upd_uses_cursor(pc.upd_kind);
+      if (has_cur) cursor = b.cursor[(int64_t)p * N + i];
+      upd_dist<ND>(pc, tb, pp, t, cursor, q);
+      if (has_cur) b.cursor[(int64_t)p * N + i] = cursor;
+      delta = w1_n<ND>(pp, q);  // base.py:192-203
+#pragma unroll
+      for (int k = 0; k < ND; k++) {
+        b.theta[(int64_t)(p * ND + k) * N + i] = q[k];
+        if constexpr (ENV != NSG_ENV_BRIDGE) b.table_prob[(int64_t)k * N + i] = q[k];  // P re-weighted on a fire only
+      }
+      have_q = true;
+    }
+    if constexpr (ENV == NSG_ENV_BRIDGE) {
+      if (do_step && pc.theta_slot == want) {  // Bridge reads the live attribute every step (toy_text.py:626-630)
+#pragma unroll
+        for (int k = 0; k < ND; k++) pt[k] = have_q ? q[k] : b.theta[(int64_t)(p * ND + k) * N + i];
+      }
+    } else {
+      if (have_q) {
+#pragma unroll
+        for (int k = 0; k < ND; k++) pt[k] = q[k];
+        have_table = true;
+      }
+    }
+    if (do_reset && !persistent) {  // toy_text.py:206-209, 394-399, 657-666 (the P TABLE is not restored)
+      const double* ini = grid_initial(cfg, p);
+#pragma unroll
+      for (int k = 0; k < ND; k++) b.theta[(int64_t)(p * ND + k) * N + i] = ini[k];
+      if (upd_uses_cursor(pc.upd_kind)) b.cursor[(int64_t)p * N + i] = 0;
+    }
+    if (active) {
+      out.env_change[(int64_t)p * N + i] = fired ? 1 : 0;
+      out.delta_change[(int64_t)p * N + i] = (float)delta;
+    }
+    n_fired += fired ? 1u : 0u;
+  }
+  if constexpr (ENV != NSG_ENV_BRIDGE) {
+    if (do_step && !have_table) {
+#pragma unroll
+      for (int k = 0; k < ND; k++) pt[k] = b.table_prob[(int64_t)k * N + i];
+    }
+  }
+
+  // ---- transition ---------------------------------------------------------------------------
+  double reward = 0.0, prob = 1.0;
   bool term = false, trunc = false;
   int tnew = 0;
   if (do_step) {
-    fired = theta_live && sched_fire(pc, tb, t);
-    double p0, p1, p2;
-    if (fired) {  // toy_text.py:362-366
-      double p[3] = {b.theta[0 * N + i], b.theta[1 * N + i], b.theta[2 * N + i]}, q[3];
-      int cursor = 0;
-      const bool has_cur = upd_uses_cursor(pc.upd_kind);
-      if (has_cur) cursor = b.cursor[i];
-      upd_dist(pc, tb, p, t, cursor, q);
-      if (has_cur) b.cursor[i] = cursor;
-      delta = w1_3(p, q);  // base.py:192-203
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        b.theta[(int64_t)k * N + i] = q[k];
-        b.table_prob[(int64_t)k * N + i] = q[k];  // _update_transition_prob_table(): P rebuilt on a fire only
+    int row = cell / cfg.ncol, col = cell - row * cfg.ncol;
+    if constexpr (ENV == NSG_ENV_FROZENLAKE) {  // gymnasium FrozenLakeEnv.step over the wrapper's P (toy_text.py:426-469)
+      const int letter = desc[cell];
+      if (letter == 'G' || letter == 'H') {  // single self-loop entry (1.0, s, 0, True), :435-436
+        prob = 1.0; reward = 0.0; term = true;
+      } else {
+        const double c0 = pt[0], c1 = c0 + pt[1], c2 = c1 + pt[2];          // np.cumsum
+        const int idx = c0 > r ? 0 : c1 > r ? 1 : c2 > r ? 2 : 0;          // np.argmax(cs > r); all-False -> 0
+        const int dir = idx == 0 ? a : idx == 1 ? ((a + 1) & 3) : ((a + 3) & 3);  // [a, a+1, a-1], :438
+        if (dir == 0) col = col - 1 > 0 ? col - 1 : 0;                      // inc(), :449-458
+        else if (dir == 1) row = row + 1 < cfg.nrow - 1 ? row + 1 : cfg.nrow - 1;
+        else if (dir == 2) col = col + 1 < cfg.ncol - 1 ? col + 1 : cfg.ncol - 1;
+        else row = row - 1 > 0 ? row - 1 : 0;
+        cell = row * cfg.ncol + col;
+        const int nl = desc[cell];
+        term = nl == 'G' || nl == 'H';
+        if (cfg.flags & NSG_F_MODIFIED_REWARDS) reward = cfg.letter_reward[nl == 'S' ? 0 : nl == 'F' ? 1 : nl == 'H' ? 2 : 3];
+        else reward = nl == 'G' ? 1.0 : 0.0;
+        prob = idx == 0 ? pt[0] : idx == 1 ? pt[1] : pt[2];
       }
-      p0 = q[0]; p1 = q[1]; p2 = q[2];
-    } else {
-      p0 = b.table_prob[0 * N + i]; p1 = b.table_prob[1 * N + i]; p2 = b.table_prob[2 * N + i];
-    }
-    // gymnasium FrozenLakeEnv.step over the wrapper's P table (toy_text.py:426-469)
-    const int letter = desc[cell];
-    if (letter == 'G' || letter == 'H') {  // single self-loop entry (1.0, s, 0, True), :435-436
-      prob = 1.0; reward = 0.0; term = true;
-    } else {
-      const double c0 = p0, c1 = c0 + p1, c2 = c1 + p2;               // np.cumsum
-      const int idx = c0 > r ? 0 : c1 > r ? 1 : c2 > r ? 2 : 0;        // np.argmax(cs > r); all-False -> 0
-      const int dir = idx == 0 ? a : idx == 1 ? ((a + 1) & 3) : ((a + 3) & 3);  // [a, a+1, a-1], :438
-      int row = cell / cfg.ncol, col = cell - row * cfg.ncol;
-      if (dir == 0) col = col - 1 > 0 ? col - 1 : 0;                    // inc(), :449-458
-      else if (dir == 1) row = row + 1 < cfg.nrow - 1 ? row + 1 : cfg.nrow - 1;
-      else if (dir == 2) col = col + 1 < cfg.ncol - 1 ? col + 1 : cfg.ncol - 1;
-      else row = row - 1 > 0 ? row - 1 : 0;
-      cell = row * cfg.ncol + col;
+    } else if constexpr (ENV == NSG_ENV_CLIFFWALKING) {  // CliffWalkingEnv.step over the NS table (toy_text.py:86-148)
+      const double c0 = pt[0], c1 = c0 + pt[1], c2 = c1 + pt[2], c3 = c2 + pt[3];
+      const int idx = c0 > r ? 0 : c1 > r ? 1 : c2 > r ? 2 : c3 > r ? 3 : 0;
+      const int off = idx == 0 ? 0 : idx == 1 ? 1 : idx == 2 ? 3 : 2;      // b_actions = [a, a+1, a-1, a+2], :96
+      const int dir = (a + off) & 3;                                      // UP RIGHT DOWN LEFT, :74-76
+      int nr = row + (dir == 0 ? -1 : dir == 2 ? 1 : 0), nc = col + (dir == 1 ? 1 : dir == 3 ? -1 : 0);
+      nr = nr < 0 ? 0 : nr > cfg.nrow - 1 ? cfg.nrow - 1 : nr;
+      nc = nc < 0 ? 0 : nc > cfg.ncol - 1 ? cfg.ncol - 1 : nc;
+      const bool cliff = nr == cfg.nrow - 1 && nc >= 1 && nc <= cfg.ncol - 2;
+      const bool goal = nr == cfg.nrow - 1 && nc == cfg.ncol - 1;
+      reward = cliff ? cfg.letter_reward[2] : goal ? cfg.letter_reward[3] : cfg.letter_reward[1];  // :117-125
+      term = cliff ? ((cfg.flags & NSG_F_TERMINAL_CLIFF) != 0) : goal;                              // :126-128
+      cell = cliff ? (cfg.nrow - 1) * cfg.ncol : nr * cfg.ncol + nc;                                 // :129
+      prob = idx == 0 ? pt[0] : idx == 1 ? pt[1] : idx == 2 ? pt[2] : pt[3];
+    } else {  // Bridge.step (envs/Bridge.py:89-134): np.random.choice([a, a+1, a-1], p=P)
+      // choice(p=): cdf = cumsum(p); cdf /= cdf[-1]; idx = searchsorted(cdf, u, side="right")
+      const double c0 = pt[0], c1 = c0 + pt[1], c2 = c1 + pt[2];
+      int idx = (c0 / c2 <= r ? 1 : 0) + (c1 / c2 <= r ? 1 : 0) + (c2 / c2 <= r ? 1 : 0);
+      idx = idx > 2 ? 2 : idx;
+      const int dir = idx == 0 ? a : idx == 1 ? ((a + 1) & 3) : ((a + 3) & 3);  // LEFT DOWN RIGHT UP, :13-16
+      int nr = row + (dir == 1 ? 1 : dir == 3 ? -1 : 0), nc = col + (dir == 0 ? -1 : dir == 2 ? 1 : 0);
+      if (nr < 0 || nr >= cfg.nrow || nc < 0 || nc >= cfg.ncol) { nr = row; nc = col; }  // out of bounds: stay, :127-128
+      cell = nr * cfg.ncol + nc;
       const int nl = desc[cell];
-      term = nl == 'G' || nl == 'H';
-      if (cfg.flags & NSG_F_MODIFIED_REWARDS) reward = cfg.letter_reward[nl == 'S' ? 0 : nl == 'F' ? 1 : nl == 'H' ? 2 : 3];
-      else reward = nl == 'G' ? 1.0 : 0.0;
-      prob = idx == 0 ? p0 : idx == 1 ? p1 : p2;
+      if (nl == 'H') { reward = -1.0; term = true; } else if (nl == 'G') { reward = 1.0; term = true; }
+      prob = pt[0];
     }
     tnew = t + 1;
     trunc = cfg.max_episode_steps > 0 && (tnew - (sim ? b.t_fork[i] : 0)) >= cfg.max_episode_steps;
   } else if (do_reset) {
     if (sim) b.t_fork[i] = 0;
-    // start cell: argmax(cumsum(one-hot S) > r)
-    const int nS = cfg.nrow * cfg.ncol;
-    int s0 = 0;
-    for (int k = 0; k < nS; k++)
-      if (desc[k] == 'S') { s0 = k; break; }
-    cell = 1.0 > r ? s0 : 0;
-    if (!persistent) {  // toy_text.py:394-399; the P table itself is NOT restored (see nsgym_hip.h)
-#pragma unroll
-      for (int k = 0; k < 3; k++) b.theta[(int64_t)k * N + i] = cfg.initial_prob[k];
-      if (upd_uses_cursor(pc.upd_kind)) b.cursor[i] = 0;
-    }
+    cell = grid_start_state(cfg, desc);
   }
   const bool done = term || trunc;
   if (active) {
     b.cell[i] = cell;
     if (out.obs) ((int32_t*)out.obs)[i] = cell;  // trajectory slice (rollout); NULL for nsg_step: cell[] is the obs
-    stg(b.t, o4, tnew);
-    stg(out.reward, o4, (float)reward);
-    stg(out.terminated, o1, (uint8_t)(term ? 1 : 0));
-    stg(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
-    stg(b.status, o1, (uint8_t)(done ? NSG_ST_NEEDS_RESET : 0));
-    out.env_change[i] = fired ? 1 : 0;
-    out.delta_change[i] = (float)delta;
+    b.t[i] = tnew;
+    out.reward[i] = (float)reward;
+    out.terminated[i] = term ? 1 : 0;
+    out.truncated[i] = trunc ? 1 : 0;
+    b.status[i] = done ? NSG_ST_NEEDS_RESET : 0;
     if (b.prob) b.prob[i] = (float)prob;
     if (cfg.flags & NSG_F_TRACK_RETURNS) {
       float er = do_reset ? 0.f : b.ep_return[i] + (float)reward;
-      int el = do_reset ? 0 : b.ep_length[i] + 1;
       if (done) {
         b.last_return[i] = er;
-        b.last_length[i] = el;
+        b.last_length[i] = tnew;
         er = 0.f;
-        el = 0;
       }
-      stg(b.ep_return, o4, er);
-      b.ep_length[i] = el;
+      b.ep_return[i] = er;
     }
   }
   const unsigned long long done_mask = __ballot(done);
   if (b.done_bits && (threadIdx.x & 63) == 0 && i < N) b.done_bits[i >> 6] = done_mask;
   wc.done += __popcll(done_mask);
   wc.steps += __popcll(__ballot(do_step));
-  wc.fired += __popcll(__ballot(fired));
+  for (unsigned bit = 0; bit < 2; bit++) wc.fired += __popcll(__ballot((n_fired >> bit) & 1u)) << bit;
 }
-
 
 // One chunk of kBlock envs of any env type (block-level call: contains workgroup barriers).
 template <int ENV, bool FULL>
 __device__ __forceinline__ void step_block(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
                                            const StepOut& out, int64_t base, int parity, LdsTables& lds, WaveCounts& wc) {
-  if constexpr (ENV == NSG_ENV_FROZENLAKE) {
+  if constexpr (ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE) {
     const int64_t i = base + threadIdx.x;
-    step_frozenlake(sg, tb, actions, out, i, i < sg.N, wc);
+    step_grid<ENV>(sg, tb, actions, out, i, i < sg.N, wc);
   } else {
     step_chunk<ENV, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc);
   }
@@ -575,7 +659,9 @@ __global__ __launch_bounds__(kBlock) void step_group_kernel(const Segment* __res
       case NSG_ENV_ACROBOT: step_block<NSG_ENV_ACROBOT, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
       case NSG_ENV_MOUNTAINCAR: step_block<NSG_ENV_MOUNTAINCAR, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
       case NSG_ENV_MOUNTAINCAR_CONT: step_block<NSG_ENV_MOUNTAINCAR_CONT, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
-      default: step_block<NSG_ENV_FROZENLAKE, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
+      case NSG_ENV_FROZENLAKE: step_block<NSG_ENV_FROZENLAKE, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
+      case NSG_ENV_CLIFFWALKING: step_block<NSG_ENV_CLIFFWALKING, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
+      default: step_block<NSG_ENV_BRIDGE, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
     }
   }
   flush_counts(sg, lds, wc);
@@ -599,13 +685,11 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
     Pcg g;
     if (seeds) pcg_seed(g, seeds[i], -1);  // gymnasium Env.reset(seed) -> np_random(seed) [UPSTREAM]
     else pcg_load(b.rng_env, N, i, g);
-    if constexpr (ENV == NSG_ENV_FROZENLAKE) {
-      const uint8_t* desc = sg.tables + cfg.desc_tab_off;
-      const double r = pcg_double(g);
-      int s0 = 0;
-      for (int k = 0; k < cfg.nrow * cfg.ncol; k++)
-        if (desc[k] == 'S') { s0 = k; break; }
-      b.cell[i] = 1.0 > r ? s0 : 0;
+    if constexpr (ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE) {
+      // FrozenLakeEnv / CliffWalkingEnv.reset consume one random() (categorical_sample over the one-hot
+      // start distribution); Bridge.reset draws nothing
+      if constexpr (ENV != NSG_ENV_BRIDGE) (void)pcg_double(g);
+      b.cell[i] = grid_start_state(cfg, sg.tables + cfg.desc_tab_off);
       if (b.prob) b.prob[i] = 1.0f;
     } else {
       using T = EnvTraits<ENV>;
@@ -623,9 +707,11 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
     for (int p = 0; p < P; p++) {
       const nsg_param_cfg& pc = cfg.params[p];
       if (!persistent) {
-        if constexpr (ENV == NSG_ENV_FROZENLAKE) {
+        if constexpr (ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE) {
+          constexpr int ND = ENV == NSG_ENV_CLIFFWALKING ? 4 : 3;
+          const double* ini = grid_initial(cfg, p);
 #pragma unroll
-          for (int k = 0; k < 3; k++) b.theta[(int64_t)k * N + i] = cfg.initial_prob[k];
+          for (int k = 0; k < ND; k++) b.theta[(int64_t)(p * ND + k) * N + i] = ini[k];
         } else {
           b.theta[(int64_t)p * N + i] = cfg.base_theta[pc.theta_slot];
         }
@@ -659,12 +745,16 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const Segment* __restrict_
   const nsg_config& cfg = sg.cfg;
   const nsg_buffers& b = sg.buf;
   const int64_t N = sg.N;
-  const bool fl = cfg.env_type == NSG_ENV_FROZENLAKE;
+  const bool fl = is_grid_env(cfg.env_type);
+  const int nd = cfg.env_type == NSG_ENV_CLIFFWALKING ? 4 : 3;
   if (blockIdx.x == 0 && b.counters)
     for (int k = threadIdx.x; k < NSG_CNT_COUNT * kCntShards; k += kBlock) b.counters[k] = 0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
     if (fl) {
-      for (int k = 0; k < 3; k++) b.theta[(int64_t)k * N + i] = b.table_prob[(int64_t)k * N + i] = cfg.initial_prob[k];
+      for (int p = 0; p < cfg.n_params; p++)
+        for (int k = 0; k < nd; k++) b.theta[(int64_t)(p * nd + k) * N + i] = grid_initial(cfg, p)[k];
+      if (b.table_prob)
+        for (int k = 0; k < nd; k++) b.table_prob[(int64_t)k * N + i] = cfg.initial_prob[0][k];
       b.cell[i] = 0;
       if (b.prob) b.prob[i] = 1.f;
     }
@@ -730,22 +820,28 @@ __global__ __launch_bounds__(kBlock) void theta_trace_kernel(const Segment* __re
   stage_tables(sg, lds, tb, zg);
   const nsg_param_cfg& pc = sg.cfg.params[p];
   const bool dist = pc.upd_kind >= NSG_UPD_D_INCREMENT;
+  const int nd = sg.cfg.env_type == NSG_ENV_CLIFFWALKING ? 4 : 3;
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   Pcg r = {0, 0, 0, 0};
   if (pc.uses_rng && rng_state) pcg_load(rng_state, n, i, r);
   int cursor = 0;
-  double th[3] = {theta0[dist ? 3 * i : i], dist ? theta0[3 * i + 1] : 0.0, dist ? theta0[3 * i + 2] : 0.0};
+  double th[4] = {0, 0, 0, 0};
+  if (dist) {
+    for (int c = 0; c < nd; c++) th[c] = theta0[nd * i + c];
+  } else {
+    th[0] = theta0[i];
+  }
   for (int k = 0; k < T; k++) {
     const int t = t0 + k;
     const bool fired = sched_fire(pc, tb, t);
     double delta = 0.0;
     if (fired) {
       if (dist) {
-        double q[3];
-        upd_dist(pc, tb, th, t, cursor, q);
-        delta = w1_3(th, q);
-        th[0] = q[0]; th[1] = q[1]; th[2] = q[2];
+        double q[4] = {0, 0, 0, 0};
+        if (nd == 4) { upd_dist<4>(pc, tb, th, t, cursor, q); delta = w1_n<4>(th, q); }
+        else { upd_dist<3>(pc, tb, th, t, cursor, q); delta = w1_n<3>(th, q); }
+        for (int c = 0; c < nd; c++) th[c] = q[c];
       } else {
         double nvv = upd_scalar<true>(pc, tb, zg, th[0], t, r, cursor);
         delta = nvv - th[0];
@@ -753,7 +849,7 @@ __global__ __launch_bounds__(kBlock) void theta_trace_kernel(const Segment* __re
       }
     }
     if (dist) {
-      for (int c = 0; c < 3; c++) theta_out[((int64_t)k * 3 + c) * n + i] = th[c];
+      for (int c = 0; c < nd; c++) theta_out[((int64_t)k * nd + c) * n + i] = th[c];
     } else {
       theta_out[(int64_t)k * n + i] = th[0];
     }
@@ -795,7 +891,8 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
   const nsg_buffers& db = ds.buf;
   const int64_t N = ss.N;
   const int env = cfg.env_type, P = cfg.n_params;
-  const bool fl = env == NSG_ENV_FROZENLAKE;
+  const bool fl = is_grid_env(env);
+  const int nd = env == NSG_ENV_CLIFFWALKING ? 4 : 3;
   const bool in_sim_change = (ds.cfg.flags & NSG_F_IN_SIM_CHANGE) != 0;
   const int phys = fl ? 0 : (env == NSG_ENV_CARTPOLE || env == NSG_ENV_ACROBOT ? 4 : 2);
   const int obs = fl ? 0 : (env == NSG_ENV_CARTPOLE ? 4 : env == NSG_ENV_PENDULUM ? 3 : env == NSG_ENV_ACROBOT ? 6 : 2);
@@ -806,9 +903,9 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
     db.t[i] = t;
     db.t_fork[i] = t;
     db.status[i] = sb.status[i];
-    for (int r = 0; r < (fl ? 3 : P); r++) {
+    for (int r = 0; r < (fl ? nd * P : P); r++) {
       const double cur = sb.theta[(int64_t)r * N + i];
-      const double init = fl ? cfg.initial_prob[r] : cfg.base_theta[cfg.params[r].theta_slot];
+      const double init = fl ? grid_initial(cfg, r / nd)[r % nd] : cfg.base_theta[cfg.params[r].theta_slot];
       db.theta[(int64_t)r * N + i] = theta_mode == 1 ? init : cur;
     }
     if (env == NSG_ENV_CARTPOLE && db.derived) {  // sim_env._dependency_resolver() at copy time (:183)
@@ -823,9 +920,15 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
       db.derived[i] = c[2] + c[1];
       db.derived[N + i] = c[5] * c[2];
     }
-    if (fl) {  // which P the copy steps with: toy_text.py:479-480 (planning), :505-508 (deepcopy), :365-367
-      for (int k = 0; k < 3; k++)
-        db.table_prob[(int64_t)k * N + i] = (in_sim_change || theta_mode == 1) ? cfg.initial_prob[k] : sb.table_prob[(int64_t)k * N + i];
+    if (fl) {
+      if (db.table_prob) {
+        // which P table the copy steps with.  FrozenLake (toy_text.py:479-480,505-508,365-367): an
+        // in_sim_change copy re-installs ITS OWN table, built from initial_prob_dist by its constructor.
+        // CliffWalking (toy_text.py:219-221,246-249,187): the copy's own table IS the copied current one.
+        const bool use_initial = env == NSG_ENV_FROZENLAKE ? (in_sim_change || theta_mode == 1) : (theta_mode == 1 && !in_sim_change);
+        for (int k = 0; k < nd; k++)
+          db.table_prob[(int64_t)k * N + i] = use_initial ? cfg.initial_prob[0][k] : sb.table_prob[(int64_t)k * N + i];
+      }
       if (db.prob && sb.prob) db.prob[i] = sb.prob[i];
     }
     for (int p = 0; p < P; p++) {

@@ -21,14 +21,15 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const Segment* __restri
   const int64_t N = sg.N;
   const int P = sg.cfg.n_params > 0 ? sg.cfg.n_params : 1;
   const StepOut dflt = default_out(sg.buf);
-  constexpr int D = ENV == NSG_ENV_FROZENLAKE ? 1 : EnvTraits<ENV == NSG_ENV_FROZENLAKE ? NSG_ENV_CARTPOLE : ENV>::OBS;
+  constexpr bool GRID = ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE;
+  constexpr int D = GRID ? 1 : EnvTraits<GRID ? NSG_ENV_CARTPOLE : ENV>::OBS;
   constexpr bool FA = ENV == NSG_ENV_PENDULUM || ENV == NSG_ENV_MOUNTAINCAR_CONT;
   const int64_t chunks = (N + kBlock - 1) / kBlock;
   int parity = 0;
   for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
     for (int k = 0; k < k_steps; k++) {
       StepOut out;
-      out.obs = ro.obs ? ro.obs + (int64_t)k * N * D : (ENV == NSG_ENV_FROZENLAKE ? nullptr : dflt.obs);
+      out.obs = ro.obs ? ro.obs + (int64_t)k * N * D : (GRID ? nullptr : dflt.obs);
       out.reward = ro.reward ? ro.reward + (int64_t)k * N : dflt.reward;
       out.terminated = ro.terminated ? ro.terminated + (int64_t)k * N : dflt.terminated;
       out.truncated = ro.truncated ? ro.truncated + (int64_t)k * N : dflt.truncated;

@@ -127,65 +127,76 @@ __device__ __forceinline__ bool upd_uses_cursor(int kind) {
   return kind == NSG_UPD_STEPWISE || kind == NSG_UPD_CYCLIC || kind == NSG_UPD_D_STEPWISE || kind == NSG_UPD_D_CYCLIC;
 }
 
-// 1-Wasserstein distance between two pmfs on {0,1,2}: SciPy's _cdf_distance(p=1) with
-// values = arange(3): sum |cdf_u - cdf_v| * diff(all_values); weights normalised by their sums.
-__device__ __forceinline__ double w1_3(const double* a, const double* b) {
-  double a01 = a[0] + a[1], at = a01 + a[2];
-  double b01 = b[0] + b[1], bt = b01 + b[2];
-  double d0 = fabs(a[0] / at - b[0] / bt);
-  double d1 = fabs(a01 / at - b01 / bt);
-  return ((((0.0 + d0) + 0.0) + d1) + 0.0);
+// 1-Wasserstein distance between two pmfs on {0..ND-1}: SciPy's _cdf_distance(p=1) with
+// values = arange(ND): np.sum(|cdf_u - cdf_v| * deltas), deltas = [0,1,0,1,...,0] over the merged
+// support (fewer than 8 terms: summed in index order); weights normalised by their sums.
+template <int ND> __device__ __forceinline__ double w1_n(const double* a, const double* b) {
+  double ca[ND], cb[ND];
+  ca[0] = a[0]; cb[0] = b[0];
+#pragma unroll
+  for (int k = 1; k < ND; k++) { ca[k] = ca[k - 1] + a[k]; cb[k] = cb[k - 1] + b[k]; }
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < ND - 1; k++) {
+    acc = acc + 0.0;
+    acc = acc + fabs(ca[k] / ca[ND - 1] - cb[k] / cb[ND - 1]);
+  }
+  return acc + 0.0;
 }
 
-// UpdateDistributionFn._update for the 3-way FrozenLake slip distribution.
+// UpdateDistributionFn._update for the slip distributions of the grid wrappers (ND = 3 or 4).
+template <int ND>
 __device__ inline void upd_dist(const nsg_param_cfg& pc, const Tables& tb, const double* p, int t, int& cursor, double* q) {
   const double* u = pc.u;
   const double td = (double)t;
-  q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+#pragma unroll
+  for (int k = 0; k < ND; k++) q[k] = p[k];
   switch (pc.upd_kind) {
     case NSG_UPD_D_INCREMENT: {
       double v = p[0] + u[0];
       q[0] = v > 1.0 ? 1.0 : v;
-      q[1] = (1.0 - q[0]) / 2.0;
-      q[2] = (1.0 - q[0]) / 2.0;
+#pragma unroll
+      for (int k = 1; k < ND; k++) q[k] = (1.0 - q[0]) / (double)(ND - 1);
       break;
     }
     case NSG_UPD_D_DECREMENT: {
       double v = p[0] - u[0];
       q[0] = v < 0.0 ? 0.0 : v;
-      q[1] = (1.0 - q[0]) / 2.0;
-      q[2] = (1.0 - q[0]) / 2.0;
+#pragma unroll
+      for (int k = 1; k < ND; k++) q[k] = (1.0 - q[0]) / (double)(ND - 1);
       break;
     }
     case NSG_UPD_D_STEPWISE:
       if (cursor < pc.val_tab_len) {
-        const double* v = tb.vals(pc.val_tab_off) + 3 * cursor;
-        q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+        const double* v = tb.vals(pc.val_tab_off) + ND * cursor;
+#pragma unroll
+        for (int k = 0; k < ND; k++) q[k] = v[k];
         cursor++;
       }
       break;
     case NSG_UPD_D_CYCLIC: {
-      const double* v = tb.vals(pc.val_tab_off) + 3 * cursor;
-      q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+      const double* v = tb.vals(pc.val_tab_off) + ND * cursor;
+#pragma unroll
+      for (int k = 0; k < ND; k++) q[k] = v[k];
       cursor = cursor + 1 == pc.val_tab_len ? 0 : cursor + 1;
       break;
     }
     case NSG_UPD_D_NOUPDATE: break;
     case NSG_UPD_D_UNIFORMDRIFT: {
-      double un = 1.0 / 3;
+      const double un = 1.0 / ND;
 #pragma unroll
-      for (int k = 0; k < 3; k++) q[k] = (1 - u[0]) * p[k] + u[0] * un;
+      for (int k = 0; k < ND; k++) q[k] = (1 - u[0]) * p[k] + u[0] * un;
       break;
     }
     case NSG_UPD_D_TARGETREV:
 #pragma unroll
-      for (int k = 0; k < 3; k++) q[k] = p[k] + u[3] * (u[k] - p[k]);
+      for (int k = 0; k < ND; k++) q[k] = p[k] + u[ND] * (u[k] - p[k]);
       break;
     case NSG_UPD_D_LERP: {
-      double frac = td / u[6];
+      double frac = td / u[2 * ND];
       if (!(frac < 1.0)) frac = 1.0;
 #pragma unroll
-      for (int k = 0; k < 3; k++) q[k] = u[k] + (u[3 + k] - u[k]) * frac;
+      for (int k = 0; k < ND; k++) q[k] = u[k] + (u[ND + k] - u[k]) * frac;
       break;
     }
     default: break;

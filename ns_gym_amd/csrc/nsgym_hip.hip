@@ -35,10 +35,11 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(NSG_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-const int kPhysDim[NSG_ENV_COUNT] = {4, 2, 4, 2, 2, 0};
-const int kObsDim[NSG_ENV_COUNT] = {4, 3, 6, 2, 2, 1};
-const int kNTheta[NSG_ENV_COUNT] = {6, 4, 8, 2, 1, 1};
-const int kNActions[NSG_ENV_COUNT] = {2, 0, 3, 3, 0, 4};
+const int kPhysDim[NSG_ENV_COUNT] = {4, 2, 4, 2, 2, 0, 0, 0};
+const int kObsDim[NSG_ENV_COUNT] = {4, 3, 6, 2, 2, 1, 1, 1};
+const int kNTheta[NSG_ENV_COUNT] = {6, 4, 8, 2, 1, 1, 1, 3};
+const int kNActions[NSG_ENV_COUNT] = {2, 0, 3, 3, 0, 4, 4, 4};
+const int kNDist[NSG_ENV_COUNT] = {0, 0, 0, 0, 0, 3, 4, 3};
 
 bool upd_is_normal(int k) {
   return k == NSG_UPD_RANDOMWALK || k == NSG_UPD_RW_DRIFT || k == NSG_UPD_RW_DRIFT_TREND || k == NSG_UPD_OU ||
@@ -51,10 +52,11 @@ int validate(const nsg_config* cfg, size_t table_bytes) {
   if (cfg->env_type < 0 || cfg->env_type >= NSG_ENV_COUNT) return fail(NSG_EINVAL, "bad env_type %d", cfg->env_type);
   if (cfg->n_params < 0 || cfg->n_params > NSG_MAX_PARAMS) return fail(NSG_EINVAL, "bad n_params %d", cfg->n_params);
   if (table_bytes > (size_t)kMaxTableBytes) return fail(NSG_EINVAL, "constant tables are %zu bytes, limit %d", table_bytes, kMaxTableBytes);
-  const bool fl = cfg->env_type == NSG_ENV_FROZENLAKE;
+  const bool fl = is_grid_env(cfg->env_type);
   if (fl) {
-    if (cfg->n_params != 1) return fail(NSG_EINVAL, "FrozenLake takes exactly one tunable parameter (P)");
-    if (cfg->nrow <= 0 || cfg->ncol <= 0) return fail(NSG_EINVAL, "bad FrozenLake map %dx%d", cfg->nrow, cfg->ncol);
+    if (cfg->env_type != NSG_ENV_BRIDGE && cfg->n_params != 1) return fail(NSG_EINVAL, "FrozenLake / CliffWalking take exactly one tunable parameter (P)");
+    if (cfg->env_type == NSG_ENV_BRIDGE && (cfg->n_params < 1 || cfg->n_params > 2)) return fail(NSG_EINVAL, "Bridge takes P, or P_left and/or P_right");
+    if (cfg->nrow <= 0 || cfg->ncol <= 0) return fail(NSG_EINVAL, "bad grid map %dx%d", cfg->nrow, cfg->ncol);
     if ((size_t)cfg->desc_tab_off + (size_t)cfg->nrow * cfg->ncol > table_bytes) return fail(NSG_EINVAL, "desc table out of range");
   }
   unsigned seen = 0;
@@ -86,7 +88,7 @@ int validate(const nsg_config* cfg, size_t table_bytes) {
     const int k = pc.upd_kind;
     const bool needs_tab = k == NSG_UPD_POLY || k == NSG_UPD_STEPWISE || k == NSG_UPD_CYCLIC || k == NSG_UPD_D_STEPWISE || k == NSG_UPD_D_CYCLIC;
     if (needs_tab) {
-      const size_t per = dist ? 3 : 1;
+      const size_t per = dist ? (size_t)kNDist[cfg->env_type] : 1;
       if (pc.val_tab_len < 0 || pc.val_tab_off < 0 || ((size_t)pc.val_tab_off + (size_t)pc.val_tab_len * per) * 8 > table_bytes)
         return fail(NSG_EINVAL, "param %d: value table out of range", p);
       if ((k == NSG_UPD_CYCLIC || k == NSG_UPD_D_CYCLIC) && pc.val_tab_len == 0) return fail(NSG_EINVAL, "param %d: empty cyclic list", p);
@@ -122,7 +124,7 @@ int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
   if (!cfg || cfg->env_type < 0 || cfg->env_type >= NSG_ENV_COUNT) return fail(NSG_EINVAL, "bad config");
   memset(out, 0, sizeof(*out));
   const int e = cfg->env_type, P = cfg->n_params;
-  const bool fl = e == NSG_ENV_FROZENLAKE;
+  const bool fl = is_grid_env(e);
   bool any_rng = false, any_cursor = false;
   for (int p = 0; p < P; p++) {
     any_rng |= cfg->params[p].uses_rng != 0;
@@ -133,13 +135,13 @@ int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
   out->phys_dim = kPhysDim[e];
   out->obs_dim = kObsDim[e];
   out->n_params = P;
-  out->n_theta_rows = fl ? 3 : P;
+  out->n_theta_rows = fl ? kNDist[e] * P : P;
   out->action_is_float = (e == NSG_ENV_PENDULUM || e == NSG_ENV_MOUNTAINCAR_CONT) ? 1 : 0;
   out->n_actions = kNActions[e];
   out->phys = (int64_t)kPhysDim[e] * n;
   out->cell = fl ? n : 0;
   out->theta = (int64_t)out->n_theta_rows * n;
-  out->table_prob = fl ? 3 * n : 0;
+  out->table_prob = (fl && e != NSG_ENV_BRIDGE) ? (int64_t)kNDist[e] * n : 0;
   out->t = n;
   const bool simenv = (cfg->flags & NSG_F_SIM_ENV) != 0;
   out->t_fork = simenv ? n : 0;
@@ -246,7 +248,9 @@ int nsg_bind(nsg_handle* h, const nsg_buffers* bufs) {
     case NSG_ENV_ACROBOT: { constexpr int E = NSG_ENV_ACROBOT; CALL; } break;                \
     case NSG_ENV_MOUNTAINCAR: { constexpr int E = NSG_ENV_MOUNTAINCAR; CALL; } break;        \
     case NSG_ENV_MOUNTAINCAR_CONT: { constexpr int E = NSG_ENV_MOUNTAINCAR_CONT; CALL; } break; \
-    default: { constexpr int E = NSG_ENV_FROZENLAKE; CALL; } break;                          \
+    case NSG_ENV_FROZENLAKE: { constexpr int E = NSG_ENV_FROZENLAKE; CALL; } break;          \
+    case NSG_ENV_CLIFFWALKING: { constexpr int E = NSG_ENV_CLIFFWALKING; CALL; } break;      \
+    default: { constexpr int E = NSG_ENV_BRIDGE; CALL; } break;                              \
   }
 
 int nsg_reset(nsg_handle* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, void* stream) {
@@ -351,6 +355,7 @@ int nsg_fork(nsg_handle* src, nsg_handle* dst, uint64_t entropy, int32_t theta_m
   if (theta_mode != 0 && theta_mode != 1) return fail(NSG_EINVAL, "fork: theta_mode must be 0 or 1");
   nsg_config a = src->host.cfg, b = dst->host.cfg;
   a.flags = b.flags = 0;
+  a.max_episode_steps = b.max_episode_steps = 0;  // copies of CliffWalking / Bridge are re-made with 1000 (toy_text.py:229,685)
   if (memcmp(&a, &b, sizeof(a)) != 0 || src->host.table_bytes != dst->host.table_bytes)
     return fail(NSG_EINVAL, "fork: dst was not created from the same configuration");
   hipLaunchKernelGGL(fork_kernel, dim3(grid_for(src->n)), dim3(kBlock), 0, (hipStream_t)stream, src->dev, dst->dev, entropy, theta_mode);

@@ -42,13 +42,20 @@ ENV_TYPES = {
     "Continuous_MountainCarEnv": EnvType(A.ENV_MOUNTAINCAR_CONT, "Continuous_MountainCarEnv", ("power",),
                                          (0.0015,), 2, 2, 0, -1.0, 1.0),
     "FrozenLakeEnv": EnvType(A.ENV_FROZENLAKE, "FrozenLakeEnv", ("P",), (), 0, 1, 4),
+    "CliffWalkingEnv": EnvType(A.ENV_CLIFFWALKING, "CliffWalkingEnv", ("P",), (), 0, 1, 4),
+    # in-tree env of the reference (ns_gym/envs/Bridge.py); TUNABLE_PARAMS["Bridge"] at ns_gym/base.py:1161
+    "Bridge": EnvType(A.ENV_BRIDGE, "Bridge", ("P", "P_left", "P_right"), (), 0, 1, 4),
 }
+GRID_CLASSES = ("FrozenLakeEnv", "CliffWalkingEnv", "Bridge")
 
 #: mirror of ns_gym.base.TUNABLE_PARAMS for the hot-path env classes
 TUNABLE_PARAMS = {
-    name: ({"P": None} if name == "FrozenLakeEnv" else dict(zip(et.theta_names, et.theta_defaults)))
+    name: ({k: ([1.0, 0.0, 0.0] if name == "Bridge" else None) for k in et.theta_names} if name in GRID_CLASSES
+           else dict(zip(et.theta_names, et.theta_defaults)))
     for name, et in ENV_TYPES.items()
 }
+
+BRIDGE_MAP = ["HHHHHHHH", "FFFFFHHH", "GFHFSFFG", "FFFFFHHH", "HHHHHHHH"]   # ns_gym/envs/Bridge.py:11
 
 FROZENLAKE_MAPS = {
     "4x4": ["SFFF", "FHFH", "FFFH", "HFFG"],
@@ -63,6 +70,8 @@ _REGISTRY = {
     "MountainCarContinuous-v0": ("Continuous_MountainCarEnv", 999),
     "FrozenLake-v1": ("FrozenLakeEnv", 100),
     "FrozenLake8x8-v1": ("FrozenLakeEnv", 200),
+    "CliffWalking-v1": ("CliffWalkingEnv", None),       # no TimeLimit in gymnasium's registration [UPSTREAM]
+    "ns_gym/Bridge-v0": ("Bridge", 100),                # ns_gym/__init__.py:17-21
 }
 
 
@@ -99,11 +108,27 @@ def make(env_id: str, max_episode_steps: int | None = None, **kwargs) -> BaseEnv
         kwargs.pop("is_slippery", None)   # the NS wrapper overwrites P entirely (toy_text.py:337-340)
         kwargs.pop("render_mode", None)
         desc = [str(r) for r in (d if d is not None else FROZENLAKE_MAPS[map_name])]
+    elif class_name == "CliffWalkingEnv":
+        kwargs.pop("render_mode", None)
+        kwargs.pop("is_slippery", None)
+        desc = ["F" * 12] * 3 + ["S" + "H" * 10 + "G"]   # shape (4, 12), cliff = row 3 cols 1..10 [UPSTREAM]
+    elif class_name == "Bridge":
+        kwargs.pop("render_mode", None)
+        desc = list(BRIDGE_MAP)
     else:
         kwargs.pop("render_mode", None)
     if kwargs:
         raise TypeError(f"make({env_id!r}): unsupported keyword arguments {sorted(kwargs)}")
     return BaseEnvSpec(env_id, class_name, max_episode_steps if max_episode_steps is not None else steps, desc)
+
+
+def _gym_desc(un, class_name):
+    if class_name == "FrozenLakeEnv":
+        return ["".join(chr(c[0]) if isinstance(c, (bytes, np.bytes_)) else str(c) for c in row) for row in un.desc]
+    if class_name == "CliffWalkingEnv":
+        nr, nc = un.shape
+        return ["F" * nc] * (nr - 1) + ["S" + "H" * (nc - 2) + "G"]
+    return ["".join(chr(c[0]) if isinstance(c, (bytes, np.bytes_)) else str(c) for c in row) for row in un.map]
 
 
 def from_gym_env(env) -> BaseEnvSpec:
@@ -121,8 +146,8 @@ def from_gym_env(env) -> BaseEnvSpec:
     et = ENV_TYPES[class_name]
     desc = None
     overrides = {}
-    if class_name == "FrozenLakeEnv":
-        desc = ["".join(chr(c[0]) if isinstance(c, (bytes, np.bytes_)) else str(c) for c in row) for row in un.desc]
+    if class_name in GRID_CLASSES:
+        desc = _gym_desc(un, class_name)
     else:
         for name, default in zip(et.theta_names, et.theta_defaults):
             v = float(getattr(un, name, default))

@@ -42,19 +42,21 @@ def theta_trace(fn: UpdateFn, theta0, t0: int = 0, T: int = 1, n: int = 1, seeds
     Returns (theta[T, n] or [T, 3, n], fired[T, n], delta[T, n]) as NumPy arrays."""
     lib, dev = _lib.load(), _dev()
     dist = isinstance(fn, UpdateDistributionFn)
-    cfg, tables, _, _ = compile_config(make("FrozenLake-v1") if dist else make("CartPole-v1"),
-                                       {"P" if dist else "gravity": fn})
+    nd = len(theta0) if dist else 0          # 3: FrozenLake / Bridge support, 4: CliffWalking
+    env = (make("CliffWalking-v1") if nd == 4 else make("FrozenLake-v1")) if dist else make("CartPole-v1")
+    kw = {"initial_prob_dist": [1.0] + [0.0] * (nd - 1)} if dist else {}
+    cfg, tables, _, _ = compile_config(env, {"P" if dist else "gravity": fn}, **kw)
     h = C.c_void_p()
     _lib.check(lib.nsg_create(C.byref(cfg), tables, len(tables), max(n, 1), C.byref(h)), "nsg_create")
     try:
-        th0 = np.array(np.broadcast_to(np.asarray(theta0, dtype=np.float64), (n, 3) if dist else (n,)))  # writable copy
+        th0 = np.array(np.broadcast_to(np.asarray(theta0, dtype=np.float64), (n, nd) if dist else (n,)))  # writable copy
         d_th0 = torch.from_numpy(th0).to(dev)
         rng = None
         if cfg.params[0].uses_rng:
             sd = np.asarray(seeds if seeds is not None else [cfg.params[0].fn_seed] * n, dtype=np.uint64)
             _, st = rng_fill(0, sd, 0)
             rng = torch.from_numpy(np.ascontiguousarray(st.T).view(np.int64)).to(dev)  # [n, 4] records
-        th = torch.zeros((T, 3, n) if dist else (T, n), dtype=torch.float64, device=dev)
+        th = torch.zeros((T, nd, n) if dist else (T, n), dtype=torch.float64, device=dev)
         fired = torch.zeros((T, n), dtype=torch.uint8, device=dev)
         delta = torch.zeros((T, n), dtype=torch.float64, device=dev)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

@@ -20,7 +20,7 @@ _INF = "inf"
 
 
 def compile_config(env, tunable_params: dict, *, change_notification=False, delta_change_notification=False,
-                   in_sim_change=False, scalar_reward=True, persistent_params=False, track_returns=False, initial_prob_dist=None, modified_rewards=None, is_sim_env=False):
+                   in_sim_change=False, scalar_reward=True, persistent_params=False, track_returns=False, initial_prob_dist=None, modified_rewards=None, is_sim_env=False, terminal_cliff=False):
     """Returns (Config, tables_blob: bytes, BaseEnvSpec, param_names)."""
     spec: BaseEnvSpec = from_gym_env(env)
     et = spec.env_type
@@ -35,7 +35,8 @@ def compile_config(env, tunable_params: dict, *, change_notification=False, delt
     )
     if len(tunable_params) > A.NSG_MAX_PARAMS:
         raise ValueError(f"at most {A.NSG_MAX_PARAMS} tunable parameters")
-    is_fl = et.env_type == A.ENV_FROZENLAKE
+    is_fl = et.env_type in A.GRID_ENVS          # grid envs: θ is a slip distribution
+    nd = A.N_DIST.get(et.env_type, 3)
     cfg = A.Config()
     cfg.abi_version = A.NSG_ABI_VERSION
     cfg.env_type = et.env_type
@@ -55,21 +56,48 @@ def compile_config(env, tunable_params: dict, *, change_notification=False, delt
     if is_sim_env:
         flags |= A.F_SIM_ENV
     tables = TableBuilder()
+    tables.nd = nd
     if is_fl:
-        assert "P" in tunable_params, "NSFrozenLakeWrapper requires tunable_params['P']"
-        ipd = [1, 0, 0] if initial_prob_dist is None else list(initial_prob_dist)
-        assert sum(ipd) == 1 or math.isclose(sum(ipd), 1), "The sum of transition probabilities must be 1."
-        assert len(ipd) == 3, (
-            "The length of the transition probability distribution must be 3. Each action can have at most 3 possible outcomes."
-        )
-        for k in range(3):
-            cfg.initial_prob[k] = float(ipd[k])
+        cls = spec.class_name
+        default = [1, 0, 0, 0] if nd == 4 else [1, 0, 0]
+        ipd = default if initial_prob_dist is None else initial_prob_dist
+        if cls == "Bridge":
+            # uniform mode {"P"} or split mode {"P_left", "P_right"} (toy_text.py:569-597); a 2-tuple gives
+            # asymmetric initial distributions
+            split = ("P_left" in tunable_params) or ("P_right" in tunable_params)
+            assert not (split and "P" in tunable_params), "Bridge: use either 'P' or 'P_left'/'P_right'"
+            if isinstance(ipd, tuple) and len(ipd) == 2:
+                left, right = list(ipd[0]), list(ipd[1])
+            else:
+                left, right = list(ipd), list(ipd)
+            for k in range(3):
+                cfg.initial_prob[0][k] = float(left[k])
+                cfg.initial_prob[1][k] = float(right[k])
+            assert len(left) == 3 and len(right) == 3
+        else:
+            assert "P" in tunable_params, f"{cls} wrapper requires tunable_params['P']"
+            ipd = list(ipd)
+            if cls == "FrozenLakeEnv":
+                assert sum(ipd) == 1 or math.isclose(sum(ipd), 1), "The sum of transition probabilities must be 1."
+                assert len(ipd) == 3, (
+                    "The length of the transition probability distribution must be 3. Each action can have at most 3 possible outcomes."
+                )
+            else:
+                assert len(ipd) == 4, "CliffWalking: initial_prob_dist must have 4 entries"
+            for k in range(nd):
+                cfg.initial_prob[0][k] = float(ipd[k])
         desc = spec.desc
         cfg.nrow, cfg.ncol = len(desc), len(desc[0])
         raw = "".join(desc).encode()
-        assert set(raw) <= set(b"SFHG"), "FrozenLake desc may contain only S, F, H, G"
+        assert set(raw) <= set(b"SFHG"), "grid desc may contain only S, F, H, G"
         cfg.desc_tab_off = tables.add_bytes(raw)
-        if modified_rewards:
+        if cls == "CliffWalkingEnv":   # modified_rewards default (toy_text.py:56-59)
+            mr = modified_rewards or {"H": -100, "G": 0, "F": -1, "S": -1}
+            for j, letter in enumerate("SFHG"):
+                cfg.letter_reward[j] = float(mr[letter])
+            if terminal_cliff:
+                flags |= A.F_TERMINAL_CLIFF
+        elif modified_rewards and cls == "FrozenLakeEnv":
             flags |= A.F_MODIFIED_REWARDS
             for j, letter in enumerate("SFHG"):
                 cfg.letter_reward[j] = float(modified_rewards[letter])
@@ -81,11 +109,11 @@ def compile_config(env, tunable_params: dict, *, change_notification=False, delt
     for j, (name, fn) in enumerate(tunable_params.items()):
         assert isinstance(fn, UpdateFn), f"tunable_params[{name!r}] must be an UpdateFn, got {type(fn)}"
         if is_fl:
-            assert isinstance(fn, UpdateDistributionFn), "FrozenLake 'P' needs an UpdateDistributionFn"
+            assert isinstance(fn, UpdateDistributionFn), f"{spec.class_name} '{name}' needs an UpdateDistributionFn"
         else:
             assert not isinstance(fn, UpdateDistributionFn), f"{name}: scalar parameter needs a scalar UpdateFn"
         pc = cfg.params[j]
-        pc.theta_slot = 0 if is_fl else et.theta_names.index(name)
+        pc.theta_slot = et.theta_names.index(name)
         pc.rng_child = j
         pc.sched_end = float("inf")
         fields = {}

@@ -1,6 +1,6 @@
 """Distribution update functions with the reference's names and signatures
-(ns_gym/update_functions/distribution.py), specialised to the 3-way slip distribution that
-NSFrozenLakeWrapper accepts (ns_gym/wrappers/toy_text.py:332-334)."""
+(ns_gym/update_functions/distribution.py), for the slip distributions of the grid wrappers: n = 3
+(NSFrozenLakeWrapper, NSBridgeWrapper) or n = 4 (NSCliffWalkingWrapper) (ns_gym/wrappers/toy_text.py)."""
 from __future__ import annotations
 
 from .. import _abi as A
@@ -8,17 +8,20 @@ from ..base import Scheduler, UpdateDistributionFn
 
 
 def _u(*vals):
-    u = [0.0] * 8
+    u = [0.0] * 10
     for i, v in enumerate(vals):
         u[i] = float(v)
     return u
 
 
-def _triples(rows, what):
+def _rows(rows, what, tables):
+    """Distributions as float rows of the env's support size n (3: FrozenLake/Bridge, 4: CliffWalking;
+    `tables.nd` is set by the config compiler before the update fns are compiled)."""
+    n = getattr(tables, "nd", 3)
     out = []
     for r in rows:
-        if len(r) != 3:
-            raise ValueError(f"{what}: every distribution must have length 3")
+        if len(r) != n:
+            raise ValueError(f"{what}: every distribution must have length {n} for this environment")
         out.append([float(x) for x in r])
     return out
 
@@ -53,8 +56,8 @@ class DistributionStepWiseUpdate(UpdateDistributionFn):
         self.update_values = update_values
 
     def _compile(self, tables):
-        rows = _triples(self.update_values, "DistributionStepWiseUpdate")
-        off, _ = tables.add_values([x for r in rows for x in r] or [0.0, 0.0, 0.0])
+        rows = _rows(self.update_values, "DistributionStepWiseUpdate", tables)
+        off, _ = tables.add_values([x for r in rows for x in r] or [0.0] * 4)
         return {"upd_kind": A.UPD_D_STEPWISE, "val_tab_off": off, "val_tab_len": len(rows)}
 
 
@@ -67,7 +70,7 @@ class DistributionCyclicUpdate(UpdateDistributionFn):
         self._index = 0
 
     def _compile(self, tables):
-        rows = _triples(self.dist_list, "DistributionCyclicUpdate")
+        rows = _rows(self.dist_list, "DistributionCyclicUpdate", tables)
         if not rows:
             raise ValueError("DistributionCyclicUpdate: dist_list must not be empty")
         off, _ = tables.add_values([x for r in rows for x in r])
@@ -104,8 +107,8 @@ class TargetReversion(UpdateDistributionFn):
         self.theta = theta
 
     def _compile(self, tables):
-        (t,) = _triples([self.target], "TargetReversion")
-        return {"upd_kind": A.UPD_D_TARGETREV, "u": _u(t[0], t[1], t[2], self.theta)}
+        (t,) = _rows([self.target], "TargetReversion", tables)
+        return {"upd_kind": A.UPD_D_TARGETREV, "u": _u(*t, self.theta)}
 
 
 class DistributionLinearInterpolation(UpdateDistributionFn):
@@ -116,7 +119,7 @@ class DistributionLinearInterpolation(UpdateDistributionFn):
         self.start_dist, self.end_dist, self.T = start_dist, end_dist, T
 
     def _compile(self, tables):
-        s, e = _triples([self.start_dist, self.end_dist], "DistributionLinearInterpolation")
+        s, e = _rows([self.start_dist, self.end_dist], "DistributionLinearInterpolation", tables)
         return {"upd_kind": A.UPD_D_LERP, "u": _u(*s, *e, self.T)}
 
 

@@ -10,7 +10,7 @@ from ..base import Scheduler, UpdateFn
 
 
 def _u(*vals):
-    u = [0.0] * 8
+    u = [0.0] * 10
     for i, v in enumerate(vals):
         u[i] = float(v)
     return u

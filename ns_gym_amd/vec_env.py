@@ -64,7 +64,9 @@ class VecNSEnv:
         self.is_sim_env = bool(is_sim_env)
         self.has_reset = False
         self.num_envs = self.N = int(num_envs)
-        self.is_frozenlake = self.cfg.env_type == A.ENV_FROZENLAKE
+        self.is_grid = self.cfg.env_type in A.GRID_ENVS     # FrozenLake / CliffWalking / Bridge: int state, θ = slip distribution
+        self.is_frozenlake = self.is_grid                  # historical alias used by the adaptors
+        self.n_dist = A.N_DIST.get(self.cfg.env_type, 0)
 
         lay = A.Layout()
         _lib.check(self.lib.nsg_layout_query(C.byref(self.cfg), self.N, C.byref(lay)), "nsg_layout_query")
@@ -96,12 +98,12 @@ class VecNSEnv:
         self.truncated = b["truncated"].view(torch.bool)
         self.gt_env_change = b["env_change"].view(P, N)
         self.gt_delta_change = b["delta_change"].view(P, N)
-        rows = 3 if self.is_frozenlake else P
-        self.theta = b["theta"].view(rows, N)
-        if self.is_frozenlake:
+        rows = self.n_dist * P if self.is_grid else P
+        self.theta = b["theta"].view(rows, N)     # grid envs: param p occupies rows [p*n, (p+1)*n)
+        if self.is_grid:
             self.state = b["cell"]
             self.prob = b["prob"]
-            self.table_prob = b["table_prob"].view(3, N)
+            self.table_prob = b["table_prob"].view(self.n_dist, N) if b["table_prob"] is not None else None
         else:
             self.state = b["obs"].view(N, self.obs_dim)
             self.phys = b["phys"].view(self.layout.phys_dim, N)
@@ -193,9 +195,11 @@ class VecNSEnv:
             "Ground Truth Env Change": {p: self.gt_env_change[j] for j, p in enumerate(self.param_names)},
             "Ground Truth Delta Change": {p: self.gt_delta_change[j] for j, p in enumerate(self.param_names)},
         }
-        if self.is_frozenlake:
+        if self.is_grid:
             info["prob"] = self.prob
-            info["transition_prob"] = self.theta
+            n = self.n_dist
+            info["transition_prob"] = (self.theta if len(self.param_names) == 1 else
+                                       {p: self.theta[j * n:(j + 1) * n] for j, p in enumerate(self.param_names)})
         return info
 
     # ------------------------------------------------------------------ reductions / bookkeeping
@@ -253,6 +257,11 @@ class VecNSEnv:
         kw = dict(self._ctor)
         kw["is_sim_env"] = True
         kw["device"] = self.device
+        if self.spec.class_name in ("CliffWalkingEnv", "Bridge"):
+            # the reference re-makes these copies with max_episode_steps=1000 (toy_text.py:229,685)
+            import dataclasses
+
+            kw["env"] = dataclasses.replace(self.spec, max_episode_steps=1000)
         dst = VecNSEnv(**kw)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.nsg_fork(self._h, dst._h, C.c_uint64(entropy & (2**64 - 1)), int(theta_mode), self._stream),

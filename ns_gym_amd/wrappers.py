@@ -22,7 +22,8 @@ from .base import Reward
 from .envs import BaseEnvSpec, from_gym_env
 from .vec_env import ConstraintViolationWarning, VecNSEnv
 
-__all__ = ["NSClassicControlWrapper", "NSFrozenLakeWrapper", "ConstraintViolationWarning"]
+__all__ = ["NSClassicControlWrapper", "NSFrozenLakeWrapper", "NSCliffWalkingWrapper", "NSBridgeWrapper",
+           "ConstraintViolationWarning"]
 
 
 class _Space:
@@ -64,6 +65,8 @@ class _Unwrapped:
             return o._vec.phys[:, 0].cpu().numpy().copy()
         if name == "s" and o._vec.is_frozenlake:
             return int(o._vec.state[0].item())
+        if name in ("P", "P_left", "P_right") and o.spec.class_name == "Bridge":
+            return o._dist(name)
         if name == "P" and o._vec.is_frozenlake:
             return o._build_P()
         if name in ("nrow", "ncol") and o._vec.is_frozenlake:
@@ -143,7 +146,7 @@ class _NSSingle:
         o, inf = self._scalars(obs, info)
         r = float(rew[0].item())
         terminated, truncated = bool(term[0].item()), bool(trunc[0].item())
-        if self.spec.class_name != "FrozenLakeEnv":
+        if not self._vec.is_grid:
             self._vec.check_constraints()  # aggregated ConstraintViolationWarning (classic_control.py:212-234)
         if not self.scalar_reward:
             r = Reward(reward=r, env_change=o["env_change"], delta_change=o["delta_change"],
@@ -190,7 +193,7 @@ class NSClassicControlWrapper(_NSSingle):
         spec = from_gym_env(env)
         from .envs import TUNABLE_PARAMS
 
-        assert spec.class_name in TUNABLE_PARAMS.keys() and spec.class_name != "FrozenLakeEnv", (
+        assert spec.class_name in TUNABLE_PARAMS.keys() and spec.class_name not in ("FrozenLakeEnv", "CliffWalkingEnv", "Bridge"), (
             f"{spec.class_name} is not a supported environment"
         )
         for key in tunable_params.keys():
@@ -268,3 +271,70 @@ class NSFrozenLakeWrapper(_NSSingle):
                         rew = float(self.modified_rewards[letter]) if self.modified_rewards else float(letter == "G")
                         P[s][a].append((tp[ind], nr * self.ncol + nc, rew, letter in "GH"))
         return P
+
+
+class NSCliffWalkingWrapper(_NSSingle):
+    """Non-stationary CliffWalking wrapper (ns_gym/wrappers/toy_text.py:14-262), N = 1 view:
+    4-way slip [a, a+1, a-1, a+2], cliff teleport, `modified_rewards`, `terminal_cliff`."""
+
+    def __init__(self, env, tunable_params, change_notification: bool = False,
+                 delta_change_notification: bool = False, in_sim_change: bool = False,
+                 initial_prob_dist=[1, 0, 0, 0], modified_rewards: Union[dict, None] = None,
+                 terminal_cliff: bool = False, **kwargs: Any):
+        spec = from_gym_env(env)
+        assert spec.class_name == "CliffWalkingEnv", f"{spec.class_name} is not a CliffWalking environment"
+        super().__init__(spec, tunable_params, change_notification, delta_change_notification, in_sim_change,
+                         initial_prob_dist=initial_prob_dist, modified_rewards=modified_rewards,
+                         terminal_cliff=terminal_cliff, **kwargs)
+        self.initial_prob_dist = initial_prob_dist
+        self.modified_rewards = modified_rewards or {"H": -100, "G": 0, "F": -1, "S": -1}
+        self.terminal_cliff = terminal_cliff
+        self.shape = (int(self._vec.cfg.nrow), int(self._vec.cfg.ncol))
+        self.nS, self.nA = self.shape[0] * self.shape[1], 4
+        self.start_state_index = (self.shape[0] - 1) * self.shape[1]
+
+    @property
+    def transition_prob(self):
+        return [float(x) for x in self._vec.theta[:, 0].tolist()]
+
+    def step(self, action: int):
+        obs, reward, terminated, truncated, info = self._step(action)
+        info["prob"] = float(self._vec.prob[0].item())
+        info["transition_prob"] = self.transition_prob  # toy_text.py:192
+        return obs, reward, terminated, truncated, info
+
+    def reset(self, *, seed: int | None = None, options: dict | None = None):
+        obs, info = super().reset(seed=seed, options=options)
+        info["prob"] = 1
+        return obs, info
+
+
+class NSBridgeWrapper(_NSSingle):
+    """Non-stationary Bridge wrapper (ns_gym/wrappers/toy_text.py:524-715), N = 1 view.  Uniform mode
+    `{"P": fn}` or split mode `{"P_left": fn_l, "P_right": fn_r}` (either side may be omitted)."""
+
+    def __init__(self, env, tunable_params, change_notification: bool = False,
+                 delta_change_notification: bool = False, in_sim_change: bool = False,
+                 initial_prob_dist=[1, 0, 0], modified_rewards: Union[dict, None] = None, **kwargs: Any):
+        spec = from_gym_env(env)
+        assert spec.class_name == "Bridge", f"{spec.class_name} is not the Bridge environment"
+        super().__init__(spec, tunable_params, change_notification, delta_change_notification, in_sim_change,
+                         initial_prob_dist=initial_prob_dist, **kwargs)
+        self._split_mode = ("P_left" in tunable_params) or ("P_right" in tunable_params)
+        self.initial_prob_dist = initial_prob_dist
+
+    def _dist(self, name):
+        v = self._vec
+        if name in v.param_names:
+            j = v.param_names.index(name)
+            return [float(x) for x in v.theta[3 * j:3 * j + 3, 0].tolist()]
+        side = 1 if name == "P_right" else 0
+        return [float(v.cfg.initial_prob[side][k]) for k in range(3)]
+
+    def step(self, action: int):
+        obs, reward, terminated, truncated, info = self._step(action)
+        reward = int(reward) if self.scalar_reward else reward   # Bridge returns int rewards (envs/Bridge.py:101)
+        col = obs["state"] % int(self._vec.cfg.ncol)
+        info["prob"] = (self._dist("P_left" if col < int(self._vec.cfg.ncol) // 2 else "P_right")
+                        if self._split_mode else self._dist("P"))
+        return obs, reward, terminated, truncated, info

@@ -668,6 +668,71 @@ class FrozenLakeEnv(Env):
         return int(self.s), {"prob": 1}
 
 
+# --------------------------------------------------------------------------- CliffWalking
+
+
+class CliffWalkingEnv(Env):
+    """gymnasium.envs.toy_text.cliffwalking.CliffWalkingEnv [UPSTREAM 1.2.1], non-slippery."""
+
+    UP, RIGHT, DOWN, LEFT = 0, 1, 2, 3
+    POSITION_MAPPING = {0: [-1, 0], 1: [0, 1], 2: [1, 0], 3: [0, -1]}
+
+    def __init__(self, render_mode=None, is_slippery=False):
+        self.shape = (4, 12)
+        self.start_state_index = np.ravel_multi_index((3, 0), self.shape)
+        self.nS = int(np.prod(self.shape))
+        self.nA = 4
+        self.is_slippery = is_slippery
+        self._cliff = np.zeros(self.shape, dtype=bool)
+        self._cliff[3, 1:-1] = True
+        self.P = {}
+        for s in range(self.nS):
+            position = np.unravel_index(s, self.shape)
+            self.P[s] = {a: self._calculate_transition_prob(position, a) for a in range(self.nA)}
+        self.initial_state_distrib = np.zeros(self.nS)
+        self.initial_state_distrib[self.start_state_index] = 1.0
+        self.observation_space = Discrete(self.nS)
+        self.action_space = Discrete(self.nA)
+        self.render_mode = render_mode
+        self.s = None
+        self.lastaction = None
+
+    def _limit_coordinates(self, coord):
+        coord[0] = min(coord[0], self.shape[0] - 1)
+        coord[0] = max(coord[0], 0)
+        coord[1] = min(coord[1], self.shape[1] - 1)
+        coord[1] = max(coord[1], 0)
+        return coord
+
+    def _calculate_transition_prob(self, current, move):
+        deltas = [self.POSITION_MAPPING[move]]
+        outcomes = []
+        for delta in deltas:
+            new_position = np.array(current) + np.array(delta)
+            new_position = self._limit_coordinates(new_position).astype(int)
+            new_state = np.ravel_multi_index(tuple(new_position), self.shape)
+            if self._cliff[tuple(new_position)]:
+                outcomes.append((1 / len(deltas), self.start_state_index, -100, False))
+            else:
+                terminal_state = (self.shape[0] - 1, self.shape[1] - 1)
+                outcomes.append((1 / len(deltas), new_state, -1, tuple(new_position) == terminal_state))
+        return outcomes
+
+    def step(self, a):
+        transitions = self.P[self.s][a]
+        i = categorical_sample([t[0] for t in transitions], self.np_random)
+        p, s, r, t = transitions[i]
+        self.s = s
+        self.lastaction = a
+        return int(s), r, t, False, {"prob": p}
+
+    def reset(self, *, seed=None, options=None):
+        super().reset(seed=seed)
+        self.s = categorical_sample(self.initial_state_distrib, self.np_random)
+        self.lastaction = None
+        return int(self.s), {"prob": 1}
+
+
 # --------------------------------------------------------------------------- registry
 
 _REGISTRY: dict[str, tuple[Any, int | None, dict]] = {
@@ -678,7 +743,17 @@ _REGISTRY: dict[str, tuple[Any, int | None, dict]] = {
     "MountainCarContinuous-v0": (Continuous_MountainCarEnv, 999, {}),
     "FrozenLake-v1": (FrozenLakeEnv, 100, {"map_name": "4x4"}),
     "FrozenLake8x8-v1": (FrozenLakeEnv, 200, {"map_name": "8x8"}),
+    "CliffWalking-v1": (CliffWalkingEnv, None, {}),   # registered without a TimeLimit upstream
 }
+
+
+def _resolve_entry_point(ep):
+    if isinstance(ep, str):   # "module:attr" (the reference registers ns_gym/Bridge-v0 this way)
+        import importlib
+
+        mod, attr = ep.split(":")
+        return getattr(importlib.import_module(mod), attr)
+    return ep
 
 
 def register(id, entry_point=None, max_episode_steps=None, **kwargs):
@@ -692,8 +767,10 @@ def make(id, max_episode_steps=None, **kwargs):
     OrderEnforcing / PassiveEnvChecker do no arithmetic and are not modelled.
     """
     cls, default_steps, default_kwargs = _REGISTRY[id]
-    if not isinstance(cls, type):
-        raise KeyError(f"{id}: entry point not instantiable in the restatement")
+    try:
+        cls = _resolve_entry_point(cls)
+    except Exception as e:  # an entry point whose module is absent (ns_gym/VehicleTracking-v0)
+        raise KeyError(f"{id}: entry point not instantiable in the restatement") from e
     kw = dict(default_kwargs)
     kw.update(kwargs)
     env = cls(**kw)

@@ -239,62 +239,68 @@ static double upd_scalar(const nsg_param_cfg* pc, const uint8_t* tables, double 
 }
 
 /* ------------------------------------------------------------------ distribution update fns */
-/* ns_gym/utils.py:55-94 -> scipy.stats.wasserstein_distance(values=arange(3), weights) ->
- * _cdf_distance(p=1): sum(|U_cdf - V_cdf| * deltas) with cdf_k = cumsum_k / cumsum_last. */
-static double w1_3(const double* a, const double* b) {
-  double a01 = a[0] + a[1], at = a01 + a[2];
-  double b01 = b[0] + b[1], bt = b01 + b[2];
-  double d0 = fabs(a[0] / at - b[0] / bt);
-  double d1 = fabs(a01 / at - b01 / bt);
-  /* np.sum over [0*d0', d0, 0*.., d1, 0*..] in index order */
-  return ((((0.0 + d0) + 0.0) + d1) + 0.0);
+#define NSG_ND_MAX 4
+static int is_grid_env(int env) { return env == NSG_ENV_FROZENLAKE || env == NSG_ENV_CLIFFWALKING || env == NSG_ENV_BRIDGE; }
+static int n_dist(int env) { return env == NSG_ENV_CLIFFWALKING ? 4 : 3; }
+
+/* ns_gym/utils.py:55-94 -> scipy.stats.wasserstein_distance(values=arange(n), weights) ->
+ * _cdf_distance(p=1): np.sum(|U_cdf - V_cdf| * deltas), deltas = [0,1,0,1,...,0] over the merged
+ * support, cdf_k = cumsum_k / cumsum_last; fewer than 8 terms -> summed in index order. */
+static double w1_n(const double* a, const double* b, int n) {
+  double ca[NSG_ND_MAX], cb[NSG_ND_MAX];
+  ca[0] = a[0]; cb[0] = b[0];
+  for (int k = 1; k < n; k++) { ca[k] = ca[k - 1] + a[k]; cb[k] = cb[k - 1] + b[k]; }
+  double acc = 0.0;
+  for (int k = 0; k < n - 1; k++) {
+    acc = acc + 0.0;
+    acc = acc + fabs(ca[k] / ca[n - 1] - cb[k] / cb[n - 1]);
+  }
+  return acc + 0.0;
 }
 
-static void upd_dist(const nsg_param_cfg* pc, const uint8_t* tables, const double* p, int t, int32_t* cursor,
+static void upd_dist(const nsg_param_cfg* pc, const uint8_t* tables, const double* p, int n, int t, int32_t* cursor,
                      double* q) {
   const double* u = pc->u;
   double td = (double)t;
-  q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+  for (int k = 0; k < n; k++) q[k] = p[k];
   switch (pc->upd_kind) {
     case NSG_UPD_D_INCREMENT: {                        /* distribution.py:61-67 */
       double v = p[0] + u[0];
       q[0] = v > 1.0 ? 1.0 : v;                        /* min(1, p0 + k) */
-      q[1] = (1.0 - q[0]) / 2.0;
-      q[2] = (1.0 - q[0]) / 2.0;
+      for (int k = 1; k < n; k++) q[k] = (1.0 - q[0]) / (double)(n - 1);
       break;
     }
     case NSG_UPD_D_DECREMENT: {                        /* :88-97 */
       double v = p[0] - u[0];
       q[0] = v < 0.0 ? 0.0 : v;                        /* max(0, p0 - k) */
-      q[1] = (1.0 - q[0]) / 2.0;
-      q[2] = (1.0 - q[0]) / 2.0;
+      for (int k = 1; k < n; k++) q[k] = (1.0 - q[0]) / (double)(n - 1);
       break;
     }
     case NSG_UPD_D_STEPWISE:                           /* :116-130 */
       if (*cursor < pc->val_tab_len) {
-        const double* v = val_table(pc, tables) + 3 * (*cursor)++;
-        q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+        const double* v = val_table(pc, tables) + n * (*cursor)++;
+        for (int k = 0; k < n; k++) q[k] = v[k];
       }
       break;
     case NSG_UPD_D_CYCLIC: {                           /* :353-356 */
-      const double* v = val_table(pc, tables) + 3 * (*cursor);
-      q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+      const double* v = val_table(pc, tables) + n * (*cursor);
+      for (int k = 0; k < n; k++) q[k] = v[k];
       *cursor = (*cursor + 1) % pc->val_tab_len;
       break;
     }
     case NSG_UPD_D_NOUPDATE: break;                    /* :230-231 */
     case NSG_UPD_D_UNIFORMDRIFT: {                     /* :256-261 */
-      double un = 1.0 / 3;
-      for (int k = 0; k < 3; k++) q[k] = (1 - u[0]) * p[k] + u[0] * un;
+      double un = 1.0 / n;
+      for (int k = 0; k < n; k++) q[k] = (1 - u[0]) * p[k] + u[0] * un;
       break;
     }
     case NSG_UPD_D_TARGETREV:                          /* :289-293 */
-      for (int k = 0; k < 3; k++) q[k] = p[k] + u[3] * (u[k] - p[k]);
+      for (int k = 0; k < n; k++) q[k] = p[k] + u[n] * (u[k] - p[k]);
       break;
     case NSG_UPD_D_LERP: {                             /* :326-331 */
-      double frac = td / u[6];
+      double frac = td / u[2 * n];
       if (!(frac < 1.0)) frac = 1.0;
-      for (int k = 0; k < 3; k++) q[k] = u[k] + (u[3 + k] - u[k]) * frac;
+      for (int k = 0; k < n; k++) q[k] = u[k] + (u[n + k] - u[k]) * frac;
       break;
     }
     default: break;
@@ -302,9 +308,9 @@ static void upd_dist(const nsg_param_cfg* pc, const uint8_t* tables, const doubl
 }
 
 /* ------------------------------------------------------------------ env tables */
-static const int PHYS_DIM[NSG_ENV_COUNT] = {4, 2, 4, 2, 2, 0};
-static const int OBS_DIM[NSG_ENV_COUNT] = {4, 3, 6, 2, 2, 1};
-static const int N_THETA[NSG_ENV_COUNT] = {6, 4, 8, 2, 1, 1};
+static const int PHYS_DIM[NSG_ENV_COUNT] = {4, 2, 4, 2, 2, 0, 0, 0};
+static const int OBS_DIM[NSG_ENV_COUNT] = {4, 3, 6, 2, 2, 1, 1, 1};
+static const int N_THETA[NSG_ENV_COUNT] = {6, 4, 8, 2, 1, 1, 1, 3};
 
 int orc_phys_dim(int env) { return PHYS_DIM[env]; }
 int orc_obs_dim(int env) { return OBS_DIM[env]; }
@@ -520,6 +526,20 @@ static int env_step(int env, const double* th, double* s, int ai, float af, doub
   }
 }
 
+/* ------------------------------------------------------------------ grid envs (FrozenLake, CliffWalking, Bridge) */
+/* initial distribution of param p: Bridge's P_right side starts from initial_prob[1] (toy_text.py:573-591) */
+static const double* grid_initial(const nsg_config* cfg, int p) {
+  return (cfg->env_type == NSG_ENV_BRIDGE && cfg->params[p].theta_slot == 2) ? cfg->initial_prob[1] : cfg->initial_prob[0];
+}
+static int grid_start_state(const nsg_config* cfg, const uint8_t* tables) {
+  if (cfg->env_type == NSG_ENV_CLIFFWALKING) return (cfg->nrow - 1) * cfg->ncol; /* start_state_index = (3, 0) */
+  if (cfg->env_type == NSG_ENV_BRIDGE) return 2 * cfg->ncol + 4;                  /* envs/Bridge.py:110 */
+  const uint8_t* desc = tables + cfg->desc_tab_off;
+  for (int k = 0; k < cfg->nrow * cfg->ncol; k++)
+    if (desc[k] == 'S') return k;
+  return 0;
+}
+
 /* ------------------------------------------------------------------ wrapper-level reset */
 static int letter_index(uint8_t c) { return c == 'S' ? 0 : c == 'F' ? 1 : c == 'H' ? 2 : 3; }
 
@@ -529,18 +549,15 @@ static void reset_one(const nsg_config* cfg, const uint8_t* tables, const nsg_bu
   pcg64 g;
   if (has_seed) pcg_seed(&g, seed, -1); /* gymnasium Env.reset(seed) -> np_random(seed) */
   else rng_load(b->rng_env, N, i, &g);
-  if (env == NSG_ENV_FROZENLAKE) {
-    /* FrozenLakeEnv.reset: categorical_sample(initial_state_distrib) consumes one random();
-       the one-hot distribution always yields the S cell. */
-    double r = pcg_double(&g);
-    const uint8_t* desc = tables + cfg->desc_tab_off;
-    int nS = cfg->nrow * cfg->ncol, s0 = 0, found = 0;
-    double cs = 0;
-    for (int k = 0; k < nS; k++) {
-      cs += desc[k] == 'S' ? 1.0 : 0.0; /* exactly one S on the supported maps */
-      if (!found && cs > r) { s0 = k; found = 1; }
+  if (is_grid_env(env)) {
+    /* FrozenLakeEnv / CliffWalkingEnv.reset: categorical_sample(initial_state_distrib) consumes one
+       random(); the one-hot distribution always yields the start cell.  Bridge.reset draws nothing
+       (envs/Bridge.py:103-111). */
+    if (env != NSG_ENV_BRIDGE) {
+      double r = pcg_double(&g);
+      (void)r; /* argmax(cumsum(one-hot) > r) is the start cell for every r in [0, 1) */
     }
-    b->cell[i] = s0;
+    b->cell[i] = grid_start_state(cfg, tables);
     if (b->prob) b->prob[i] = 1.0f;
   } else {
     double s[4] = {0, 0, 0, 0};
@@ -555,10 +572,12 @@ static void reset_one(const nsg_config* cfg, const uint8_t* tables, const nsg_bu
   for (int p = 0; p < P; p++) {
     const nsg_param_cfg* pc = &cfg->params[p];
     if (!persistent) { /* base.py:381-384 deepcopy(init_initial_params); classic_control.py:105-107 */
-      if (env == NSG_ENV_FROZENLAKE)
-        for (int k = 0; k < 3; k++) b->theta[k * N + i] = cfg->initial_prob[k]; /* toy_text.py:396;
-           table_prob is NOT restored: the wrapper's self.P survives reset (toy_text.py:365-367) */
-      else
+      if (is_grid_env(env)) {
+        const int nd = n_dist(env);
+        const double* ini = grid_initial(cfg, p);
+        for (int k = 0; k < nd; k++) b->theta[(p * nd + k) * N + i] = ini[k]; /* toy_text.py:207,396,659-664;
+           table_prob is NOT restored: the wrapper's self.P survives reset (toy_text.py:187,365-367) */
+      } else
         b->theta[p * N + i] = cfg->base_theta[pc->theta_slot];
       if (b->cursor) b->cursor[p * N + i] = 0;
     }
@@ -579,13 +598,19 @@ static void reset_one(const nsg_config* cfg, const uint8_t* tables, const nsg_bu
 
 /* initial (pre-first-reset) streams of stochastic update fns: default_rng(fn_seed) */
 int orc_init_streams(const nsg_config* cfg, const nsg_buffers* b, int64_t N, const uint64_t* entropy) {
-  if (cfg->env_type == NSG_ENV_FROZENLAKE) /* __init__ builds P from initial_prob_dist (toy_text.py:337-340) */
-    for (int64_t i = 0; i < N; i++)
-      for (int k = 0; k < 3; k++) b->table_prob[k * N + i] = b->theta[k * N + i] = cfg->initial_prob[k];
+  if (is_grid_env(cfg->env_type)) { /* __init__ builds P from initial_prob_dist (toy_text.py:82-84,337-340) */
+    const int nd = n_dist(cfg->env_type);
+    for (int64_t i = 0; i < N; i++) {
+      for (int p = 0; p < cfg->n_params; p++)
+        for (int k = 0; k < nd; k++) b->theta[(p * nd + k) * N + i] = grid_initial(cfg, p)[k];
+      if (b->table_prob)
+        for (int k = 0; k < nd; k++) b->table_prob[k * N + i] = cfg->initial_prob[0][k];
+    }
+  }
   /* construction-time θ (what persistent_params keeps across resets) and fresh list cursors */
   for (int p = 0; p < cfg->n_params; p++)
     for (int64_t i = 0; i < N; i++) {
-      if (cfg->env_type != NSG_ENV_FROZENLAKE) b->theta[p * N + i] = cfg->base_theta[cfg->params[p].theta_slot];
+      if (!is_grid_env(cfg->env_type)) b->theta[p * N + i] = cfg->base_theta[cfg->params[p].theta_slot];
       if (b->cursor) b->cursor[p * N + i] = 0;
     }
   for (int p = 0; p < cfg->n_params; p++) {
@@ -633,47 +658,102 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
   int term = 0;
   const int sim = (cfg->flags & NSG_F_SIM_ENV) != 0;
   const int theta_live = !(sim && !(cfg->flags & NSG_F_IN_SIM_CHANGE));
-  if (env == NSG_ENV_FROZENLAKE) {
-    /* toy_text.py:362-377 */
-    const nsg_param_cfg* pc = &cfg->params[0];
-    double p[3] = {b->theta[0 * N + i], b->theta[1 * N + i], b->theta[2 * N + i]}, q[3];
-    int fired = theta_live && sched_fire(pc, tables, t); /* frozen planning copy: toy_text.py:354-360 */
-    double delta = 0.0;
-    if (fired) {
-      upd_dist(pc, tables, p, t, b->cursor ? &b->cursor[i] : NULL, q);
-      delta = w1_3(p, q); /* base.py:192-203 */
-      for (int k = 0; k < 3; k++) { b->theta[k * N + i] = q[k]; b->table_prob[k * N + i] = q[k]; }
-    } /* toy_text.py:365-366: the P table is rebuilt only on a fire */
-    for (int k = 0; k < 3; k++) p[k] = b->table_prob[k * N + i];
-    b->env_change[i] = (uint8_t)fired;
-    b->delta_change[i] = (float)delta;
-    if (fired) cnt[NSG_CNT_FIRED * NSG_CNT_SHARDS]++;
-    /* gymnasium FrozenLakeEnv.step over the NS table (toy_text.py:426-444) */
+  if (is_grid_env(env)) {
+    const int nd = n_dist(env);
+    /* ---- θ: every distribution param (toy_text.py:178-185, 362-366, 605-631) ---- */
+    for (int p = 0; p < P; p++) {
+      const nsg_param_cfg* pc = &cfg->params[p];
+      double pp[NSG_ND_MAX], q[NSG_ND_MAX];
+      for (int k = 0; k < nd; k++) pp[k] = b->theta[(p * nd + k) * N + i];
+      int fired = theta_live && sched_fire(pc, tables, t); /* frozen planning copy: toy_text.py:170-176,354-360,636-645 */
+      double delta = 0.0;
+      if (fired) {
+        upd_dist(pc, tables, pp, nd, t, b->cursor ? &b->cursor[p * N + i] : NULL, q);
+        delta = w1_n(pp, q, nd); /* base.py:192-203 */
+        for (int k = 0; k < nd; k++) {
+          b->theta[(p * nd + k) * N + i] = q[k];
+          if (b->table_prob) b->table_prob[k * N + i] = q[k]; /* P rebuilt / re-weighted only on a fire (:181-182,:365-366) */
+        }
+      }
+      b->env_change[p * N + i] = (uint8_t)fired;
+      b->delta_change[p * N + i] = (float)delta;
+      if (fired) cnt[NSG_CNT_FIRED * NSG_CNT_SHARDS]++;
+    }
     int a = ((const int32_t*)actions)[i];
     int s = b->cell[i];
     int row = s / cfg->ncol, col = s % cfg->ncol;
-    const uint8_t* desc = tables + cfg->desc_tab_off;
     pcg64 g;
     rng_load(b->rng_env, N, i, &g);
-    double r = pcg_double(&g);
+    double r = pcg_double(&g); /* one uniform per step from the env stream */
     rng_store(b->rng_env, N, i, &g);
-    uint8_t letter = desc[s];
-    double prob;
-    if (letter == 'G' || letter == 'H') { /* :435-436 single self-loop entry (1.0, s, 0, True) */
-      prob = 1.0; reward = 0; term = 1;
-      /* argmax(cumsum([1.0]) > r) == 0 either way */
-    } else {
-      double c0 = p[0], c1 = c0 + p[1], c2 = c1 + p[2];
-      int idx = c0 > r ? 0 : c1 > r ? 1 : c2 > r ? 2 : 0; /* argmax of all-False is 0 */
-      int dir = idx == 0 ? a : idx == 1 ? (a + 1) % 4 : (a + 3) % 4; /* [a, a+1, a-1] :438 */
-      int nr, nc;
-      frozenlake_move(cfg, row, col, dir, &nr, &nc);
-      int ns = nr * cfg->ncol + nc;
-      uint8_t nl = desc[ns];
-      term = nl == 'G' || nl == 'H';
-      reward = (cfg->flags & NSG_F_MODIFIED_REWARDS) ? cfg->letter_reward[letter_index(nl)] : (nl == 'G' ? 1.0 : 0.0);
-      prob = p[idx];
-      s = ns;
+    double prob = 1.0;
+    if (env == NSG_ENV_FROZENLAKE) { /* gymnasium FrozenLakeEnv.step over the NS table (toy_text.py:426-444) */
+      const uint8_t* desc = tables + cfg->desc_tab_off;
+      double pt[3];
+      for (int k = 0; k < 3; k++) pt[k] = b->table_prob[k * N + i];
+      uint8_t letter = desc[s];
+      if (letter == 'G' || letter == 'H') { /* :435-436 single self-loop entry (1.0, s, 0, True) */
+        prob = 1.0; reward = 0; term = 1;
+      } else {
+        double c0 = pt[0], c1 = c0 + pt[1], c2 = c1 + pt[2];
+        int idx = c0 > r ? 0 : c1 > r ? 1 : c2 > r ? 2 : 0; /* argmax of all-False is 0 */
+        int dir = idx == 0 ? a : idx == 1 ? (a + 1) % 4 : (a + 3) % 4; /* [a, a+1, a-1] :438 */
+        int nr, nc;
+        frozenlake_move(cfg, row, col, dir, &nr, &nc);
+        int ns = nr * cfg->ncol + nc;
+        uint8_t nl = desc[ns];
+        term = nl == 'G' || nl == 'H';
+        reward = (cfg->flags & NSG_F_MODIFIED_REWARDS) ? cfg->letter_reward[letter_index(nl)] : (nl == 'G' ? 1.0 : 0.0);
+        prob = pt[idx];
+        s = ns;
+      }
+    } else if (env == NSG_ENV_CLIFFWALKING) { /* CliffWalkingEnv.step over the NS table (toy_text.py:86-148) */
+      double pt[4], cs = 0.0;
+      int idx = 0, found = 0;
+      for (int k = 0; k < 4; k++) pt[k] = b->table_prob[k * N + i];
+      for (int k = 0; k < 4; k++) { /* np.argmax(np.cumsum(p) > r); all-False -> 0 */
+        cs = k == 0 ? pt[0] : cs + pt[k];
+        if (!found && cs > r) { idx = k; found = 1; }
+      }
+      static const int off[4] = {0, 1, 3, 2}; /* b_actions = [a, a+1, a-1, a+2] (:96) */
+      int dir = (a + off[idx]) % 4;
+      static const int dr[4] = {-1, 0, 1, 0}, dc[4] = {0, 1, 0, -1}; /* UP RIGHT DOWN LEFT (:74-76) */
+      int nr = row + dr[dir], nc = col + dc[dir];
+      nr = nr < 0 ? 0 : nr > cfg->nrow - 1 ? cfg->nrow - 1 : nr;
+      nc = nc < 0 ? 0 : nc > cfg->ncol - 1 ? cfg->ncol - 1 : nc;
+      int cliff = nr == cfg->nrow - 1 && nc >= 1 && nc <= cfg->ncol - 2;
+      int goal = nr == cfg->nrow - 1 && nc == cfg->ncol - 1;
+      /* rewards: modified_rewards {S,F,H,G} -> letter_reward[0..3] (:117-125) */
+      reward = cliff ? cfg->letter_reward[2] : goal ? cfg->letter_reward[3] : cfg->letter_reward[1];
+      term = cliff ? ((cfg->flags & NSG_F_TERMINAL_CLIFF) != 0) : goal;
+      s = cliff ? (cfg->nrow - 1) * cfg->ncol : nr * cfg->ncol + nc;
+      prob = pt[idx];
+    } else { /* Bridge.step (envs/Bridge.py:89-134): np.random.choice([a, a+1, a-1], p=P) */
+      const uint8_t* desc = tables + cfg->desc_tab_off;
+      double pt[3] = {cfg->initial_prob[0][0], cfg->initial_prob[0][1], cfg->initial_prob[0][2]};
+      int want = 0; /* uniform mode: slot 0; split mode: P_left (col < ncol/2) or P_right (:149-158) */
+      int split = 0;
+      for (int p = 0; p < P; p++) split |= cfg->params[p].theta_slot != 0;
+      if (split) {
+        want = col < cfg->ncol / 2 ? 1 : 2;
+        const double* ini = want == 2 ? cfg->initial_prob[1] : cfg->initial_prob[0];
+        for (int k = 0; k < 3; k++) pt[k] = ini[k]; /* an omitted side stays at its initial value */
+      }
+      for (int p = 0; p < P; p++)
+        if (cfg->params[p].theta_slot == want)
+          for (int k = 0; k < 3; k++) pt[k] = b->theta[(p * 3 + k) * N + i];
+      /* Generator/RandomState.choice(p=): cdf = cumsum(p); cdf /= cdf[-1]; idx = searchsorted(cdf, u, 'right') */
+      double c0 = pt[0], c1 = c0 + pt[1], c2 = c1 + pt[2];
+      int idx = (c0 / c2 <= r) + (c1 / c2 <= r) + (c2 / c2 <= r);
+      if (idx > 2) idx = 2;
+      int dir = idx == 0 ? a : idx == 1 ? (a + 1) % 4 : (a + 3) % 4;
+      static const int dr[4] = {0, 1, 0, -1}, dc[4] = {-1, 0, 1, 0}; /* LEFT DOWN RIGHT UP (:13-16) */
+      int nr = row + dr[dir], nc = col + dc[dir];
+      if (nr < 0 || nr >= cfg->nrow || nc < 0 || nc >= cfg->ncol) { nr = row; nc = col; } /* out of bounds: stay (:127-128) */
+      uint8_t nl = desc[nr * cfg->ncol + nc];
+      if (nl == 'H') { reward = -1; term = 1; } else if (nl == 'G') { reward = 1; term = 1; } else { reward = 0; term = 0; }
+      s = nr * cfg->ncol + nc;
+      prob = pt[0];
     }
     b->cell[i] = s;
     if (b->prob) b->prob[i] = (float)prob;
@@ -773,7 +853,8 @@ int orc_step_range(const nsg_config* cfg, const uint8_t* tables, const nsg_buffe
 int orc_fork(const nsg_config* scfg, const nsg_buffers* sb, const nsg_config* dcfg, const nsg_buffers* db, int64_t N,
              uint64_t entropy, int theta_mode) {
   int env = scfg->env_type, P = scfg->n_params;
-  const int fl = env == NSG_ENV_FROZENLAKE;
+  const int fl = is_grid_env(env);
+  const int nd = n_dist(env);
   const int in_sim_change = (dcfg->flags & NSG_F_IN_SIM_CHANGE) != 0;
   for (int64_t i = 0; i < N; i++) {
     for (int k = 0; k < PHYS_DIM[env]; k++) db->phys[k * N + i] = sb->phys[k * N + i];
@@ -781,9 +862,9 @@ int orc_fork(const nsg_config* scfg, const nsg_buffers* sb, const nsg_config* dc
     db->t[i] = sb->t[i];
     db->t_fork[i] = sb->t[i];
     db->status[i] = sb->status[i];
-    for (int r = 0; r < (fl ? 3 : P); r++) {
+    for (int r = 0; r < (fl ? nd * P : P); r++) {
       double cur = sb->theta[r * N + i];
-      double init = fl ? scfg->initial_prob[r] : scfg->base_theta[scfg->params[r].theta_slot];
+      double init = fl ? grid_initial(scfg, r / nd)[r % nd] : scfg->base_theta[scfg->params[r].theta_slot];
       db->theta[r * N + i] = theta_mode == 1 ? init : cur;
     }
     if (env == NSG_ENV_CARTPOLE && db->derived) { /* sim_env._dependency_resolver() at copy time, :183 */
@@ -793,9 +874,15 @@ int orc_fork(const nsg_config* scfg, const nsg_buffers* sb, const nsg_config* dc
       db->derived[0 * N + i] = cur[2] + cur[1];
       db->derived[1 * N + i] = cur[5] * cur[2];
     }
-    if (fl) /* which P the copy steps with: see include/nsgym_hip.h nsg_fork and toy_text.py:479-480,505-508 */
-      for (int k = 0; k < 3; k++)
-        db->table_prob[k * N + i] = (in_sim_change || theta_mode == 1) ? scfg->initial_prob[k] : sb->table_prob[k * N + i];
+    if (fl && db->table_prob) { /* which P table the copy steps with (see include/nsgym_hip.h nsg_fork):
+         FrozenLake   toy_text.py:479-480,505-508 + :365-367: an in_sim_change copy re-installs ITS OWN table,
+                      built from initial_prob_dist by its constructor;
+         CliffWalking toy_text.py:219-221,246-249 + :187: the copy's own table IS the copied current one, so an
+                      in_sim_change planning copy steps with the current table although θ reads initial */
+      int use_initial = env == NSG_ENV_FROZENLAKE ? (in_sim_change || theta_mode == 1) : (theta_mode == 1 && !in_sim_change);
+      for (int k = 0; k < nd; k++)
+        db->table_prob[k * N + i] = use_initial ? scfg->initial_prob[0][k] : sb->table_prob[k * N + i];
+    }
     for (int p = 0; p < P; p++) {
       if (db->cursor && sb->cursor) db->cursor[p * N + i] = sb->cursor[p * N + i]; /* deepcopy(tunable_params) */
       db->env_change[p * N + i] = sb->env_change[p * N + i];
@@ -867,24 +954,27 @@ int orc_theta_trace(const nsg_config* cfg, const uint8_t* tables, int p, int n, 
     pcg64 r;
     if (pc->uses_rng && rng_state) rng_load(rng_state, n, i, &r);
     int32_t cursor = 0;
-    double th[3] = {theta0[dist ? 3 * i : i], dist ? theta0[3 * i + 1] : 0, dist ? theta0[3 * i + 2] : 0};
+    const int nd = n_dist(cfg->env_type);
+    double th[NSG_ND_MAX] = {0, 0, 0, 0};
+    if (dist) for (int c = 0; c < nd; c++) th[c] = theta0[nd * i + c];
+    else th[0] = theta0[i];
     for (int k = 0; k < T; k++) {
       int t = t0 + k;
       int fired = sched_fire(pc, tables, t);
       double delta = 0.0;
       if (fired) {
         if (dist) {
-          double q[3];
-          upd_dist(pc, tables, th, t, &cursor, q);
-          delta = w1_3(th, q);
-          th[0] = q[0]; th[1] = q[1]; th[2] = q[2];
+          double q[NSG_ND_MAX];
+          upd_dist(pc, tables, th, nd, t, &cursor, q);
+          delta = w1_n(th, q, nd);
+          for (int c = 0; c < nd; c++) th[c] = q[c];
         } else {
           double nvv = upd_scalar(pc, tables, th[0], t, pc->uses_rng ? &r : NULL, &cursor);
           delta = nvv - th[0];
           th[0] = nvv;
         }
       }
-      if (dist) for (int c = 0; c < 3; c++) theta_out[((int64_t)k * 3 + c) * n + i] = th[c];
+      if (dist) for (int c = 0; c < nd; c++) theta_out[((int64_t)k * nd + c) * n + i] = th[c];
       else theta_out[(int64_t)k * n + i] = th[0];
       fired_out[(int64_t)k * n + i] = (uint8_t)fired;
       delta_out[(int64_t)k * n + i] = delta;

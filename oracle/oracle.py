@@ -48,9 +48,9 @@ _NP = {C.c_double: np.float64, C.c_int32: np.int32, C.c_uint8: np.uint8, C.c_uin
        C.c_float: np.float32, C.c_uint32: np.uint32}
 
 PHYS_DIM = {A.ENV_CARTPOLE: 4, A.ENV_PENDULUM: 2, A.ENV_ACROBOT: 4, A.ENV_MOUNTAINCAR: 2,
-            A.ENV_MOUNTAINCAR_CONT: 2, A.ENV_FROZENLAKE: 0}
+            A.ENV_MOUNTAINCAR_CONT: 2, A.ENV_FROZENLAKE: 0, A.ENV_CLIFFWALKING: 0, A.ENV_BRIDGE: 0}
 OBS_DIM = {A.ENV_CARTPOLE: 4, A.ENV_PENDULUM: 3, A.ENV_ACROBOT: 6, A.ENV_MOUNTAINCAR: 2,
-           A.ENV_MOUNTAINCAR_CONT: 2, A.ENV_FROZENLAKE: 1}
+           A.ENV_MOUNTAINCAR_CONT: 2, A.ENV_FROZENLAKE: 1, A.ENV_CLIFFWALKING: 1, A.ENV_BRIDGE: 1}
 
 
 def _ptr(a):
@@ -65,12 +65,13 @@ class OracleVecEnv:
         self.N = N = int(num_envs)
         et = self.cfg.env_type
         P = self.cfg.n_params
-        self.is_fl = et == A.ENV_FROZENLAKE
-        rows = 3 if self.is_fl else P
+        self.is_fl = et in A.GRID_ENVS
+        self.nd = A.N_DIST.get(et, 3)
+        rows = self.nd * P if self.is_fl else P
         z = lambda shape, dt: np.zeros(shape, dtype=dt)  # noqa: E731
         self.a = {
             "phys": z((max(PHYS_DIM[et], 1), N), np.float64), "cell": z(N, np.int32),
-            "theta": z((max(rows, 1), N), np.float64), "table_prob": z((3, N), np.float64), "derived": z((2, N), np.float64), "t": z(N, np.int32), "t_fork": z(N, np.int32), "status": z(N, np.uint8),
+            "theta": z((max(rows, 1), N), np.float64), "table_prob": z((4, N), np.float64), "derived": z((2, N), np.float64), "t": z(N, np.int32), "t_fork": z(N, np.int32), "status": z(N, np.uint8),
             "rng_env": z((N, 4), np.uint64), "rng_upd": z((max(P, 1), N, 4), np.uint64),
             "cursor": z((max(P, 1), N), np.int32), "obs": z((N, OBS_DIM[et]), np.float32),
             "reward": z(N, np.float32), "terminated": z(N, np.uint8), "truncated": z(N, np.uint8),
@@ -134,17 +135,19 @@ def theta_trace(fn, theta0, t0=0, T=1, n=1, seeds=None):
     from ns_gym_amd.envs import make
 
     dist = isinstance(fn, UpdateDistributionFn)
-    env = make("FrozenLake-v1") if dist else make("CartPole-v1")
-    cfg, tables, _, _ = compile_config(env, {"P" if dist else "gravity": fn})
+    nd = len(theta0) if dist else 0
+    env = (make("CliffWalking-v1") if nd == 4 else make("FrozenLake-v1")) if dist else make("CartPole-v1")
+    kw = {"initial_prob_dist": [1.0] + [0.0] * (nd - 1)} if dist else {}
+    cfg, tables, _, _ = compile_config(env, {"P" if dist else "gravity": fn}, **kw)
     tab = np.frombuffer(tables, dtype=np.uint8).copy()
-    th0 = np.ascontiguousarray(np.broadcast_to(np.asarray(theta0, dtype=np.float64), (n, 3) if dist else (n,)))
+    th0 = np.ascontiguousarray(np.broadcast_to(np.asarray(theta0, dtype=np.float64), (n, nd) if dist else (n,)))
     rng = None
     if cfg.params[0].uses_rng:
         sd = np.asarray(seeds if seeds is not None else [cfg.params[0].fn_seed] * n, dtype=np.uint64)
         rng = np.zeros((n, 4), dtype=np.uint64)
         scratch = np.zeros((1, n), dtype=np.uint64)
         lib().orc_rng_fill(0, _ptr(sd), n, -1, 0, _ptr(scratch), _ptr(rng))
-    th = np.zeros((T, 3, n) if dist else (T, n), dtype=np.float64)
+    th = np.zeros((T, nd, n) if dist else (T, n), dtype=np.float64)
     fired = np.zeros((T, n), dtype=np.uint8)
     delta = np.zeros((T, n), dtype=np.float64)
     lib().orc_theta_trace(C.byref(cfg), _ptr(tab), 0, n, int(t0), int(T), _ptr(th0), _ptr(rng), _ptr(th),

@@ -54,7 +54,7 @@ def _bind_reference():
             pass
 
     def make(id, **kw):
-        if id == "FrozenLake-v1" or id in G._REGISTRY and isinstance(G._REGISTRY[id][0], type):
+        if id in G._REGISTRY and (isinstance(G._REGISTRY[id][0], type) or id == "ns_gym/Bridge-v0"):
             return G.make(id, **kw)
         return _Opaque()
 
@@ -81,6 +81,9 @@ def _bind_reference():
     import ns_gym.update_functions as U
     from ns_gym.wrappers import NSClassicControlWrapper, NSFrozenLakeWrapper
 
+    global _EXTRA_WRAPPERS
+    from ns_gym.wrappers import NSBridgeWrapper, NSCliffWalkingWrapper
+    _EXTRA_WRAPPERS = {"CliffWalking-v1": NSCliffWalkingWrapper, "ns_gym/Bridge-v0": NSBridgeWrapper}
     return gym, S, U, NSClassicControlWrapper, NSFrozenLakeWrapper
 
 
@@ -89,6 +92,7 @@ def _bind_reference():
 # instantiate same-named classes from it (see ns_gym_amd.spec.build_tunable_params).
 
 INF = "inf"
+_EXTRA_WRAPPERS = {}
 
 
 def _dec(v):
@@ -329,6 +333,128 @@ TRAJ_SPECS = {
 }
 
 
+GRID_SPECS = {
+    # CliffWalking: 4-way slip [a, a+1, a-1, a+2] (toy_text.py:96), cliff teleport, env-stream categorical draw
+    "cliff_decrement": {
+        "env_id": "CliffWalking-v1", "make_kwargs": {"max_episode_steps": 120}, "T": 300, "seeds": list(range(20, 32)),
+        "params": {"P": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["DistributionDecrementUpdate", {"k": 0.04}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [1.0, 0.0, 0.0, 0.0]},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "cliff_terminal_stepwise_rewards": {
+        "env_id": "CliffWalking-v1", "make_kwargs": {"max_episode_steps": 60}, "T": 200, "seeds": [1, 2, 3, 4, 5, 6],
+        "params": {"P": {"scheduler": SCHEDULER_SPECS["discrete"], "update": ["DistributionStepWiseUpdate",
+                   {"update_values": [[0.7, 0.1, 0.1, 0.1], [0.4, 0.3, 0.2, 0.1], [0.25, 0.25, 0.25, 0.25]]}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [0.85, 0.05, 0.05, 0.05], "terminal_cliff": True,
+                           "modified_rewards": {"H": -10, "G": 5, "F": -0.5, "S": -1}},
+        "flags": {"change_notification": True, "delta_change_notification": False},
+    },
+    "cliff_no_timelimit_drift": {
+        "env_id": "CliffWalking-v1", "T": 400, "seeds": [11, 12, 13, 14],
+        "params": {"P": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["UniformDrift", {"rate": 0.01}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [1.0, 0.0, 0.0, 0.0]},
+        "flags": {"change_notification": True, "delta_change_notification": True, "persistent_params": True},
+    },
+    # Bridge draws its slip from the unseeded GLOBAL np.random (envs/Bridge.py:95-97): exact trajectories are
+    # only defined for one-hot distributions, which these fixtures cycle through (uniform and split mode).
+    "bridge_uniform_onehot": {
+        "env_id": "ns_gym/Bridge-v0", "T": 160, "seeds": [0, 1, 2, 3, 4, 5],
+        "params": {"P": {"scheduler": SCHEDULER_SPECS["burst_3_2"], "update": ["DistributionCyclicUpdate",
+                   {"dist_list": [[0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0]]}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [1.0, 0.0, 0.0]},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "bridge_split_onehot": {
+        "env_id": "ns_gym/Bridge-v0", "T": 160, "seeds": [0, 1, 2, 3, 4, 5],
+        "params": {"P_left": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["DistributionCyclicUpdate",
+                              {"dist_list": [[0.0, 0.0, 1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]}]},
+                   "P_right": {"scheduler": SCHEDULER_SPECS["discrete"], "update": ["DistributionStepWiseUpdate",
+                               {"update_values": [[0.0, 1.0, 0.0], [1.0, 0.0, 0.0]]}]}},
+        "wrapper_kwargs": {"initial_prob_dist": {"__pair__": [[1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]}},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "bridge_split_right_only_persistent": {
+        "env_id": "ns_gym/Bridge-v0", "T": 120, "seeds": [0, 1, 2],
+        "params": {"P_right": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["DistributionCyclicUpdate",
+                               {"dist_list": [[0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [1.0, 0.0, 0.0]},
+        "flags": {"change_notification": True, "delta_change_notification": True, "persistent_params": True},
+    },
+}
+
+
+def _wk(v):
+    if isinstance(v, dict) and "__pair__" in v:
+        return (list(v["__pair__"][0]), list(v["__pair__"][1]))
+    return list(v) if isinstance(v, list) else v
+
+
+def gen_grid_trajectory(gym, S, U, spec):
+    """CliffWalking / Bridge through the reference's NSCliffWalkingWrapper / NSBridgeWrapper with the
+    same next-step autoreset driver as gen_trajectory."""
+    env_id, T, seeds = spec["env_id"], spec["T"], spec["seeds"]
+    N = len(seeds)
+    pnames = list(spec["params"].keys())
+    P = len(pnames)
+    nd = 4 if env_id == "CliffWalking-v1" else 3
+    actions = np.random.default_rng(123).integers(4, size=(T, N)).astype(np.int32)
+    rec = {
+        "actions": actions,
+        "state": np.zeros((T + 1, N, 1), dtype=np.int32),
+        "reward": np.zeros((T, N), dtype=np.float64),
+        "terminated": np.zeros((T, N), dtype=np.uint8), "truncated": np.zeros((T, N), dtype=np.uint8),
+        "gt_env_change": np.zeros((T + 1, N, P), dtype=np.uint8),
+        "gt_delta_change": np.zeros((T + 1, N, P), dtype=np.float64),
+        "env_change": np.zeros((T + 1, N, P), dtype=np.uint8),
+        "delta_change": np.zeros((T + 1, N, P), dtype=np.float64),
+        "relative_time": np.zeros((T + 1, N), dtype=np.int32),
+        "theta": np.zeros((T + 1, N, P * nd), dtype=np.float64),
+        "was_reset": np.zeros((T, N), dtype=np.uint8),
+    }
+    if env_id == "CliffWalking-v1":
+        rec["prob"] = np.zeros((T, N), dtype=np.float64)
+    for i, seed in enumerate(seeds):
+        tp = {p: build_fn(S, U, fs) for p, fs in spec["params"].items()}
+        env = _EXTRA_WRAPPERS[env_id](gym.make(env_id, **spec.get("make_kwargs", {})), tp, **spec["flags"],
+                                      **{k: _wk(v) for k, v in spec.get("wrapper_kwargs", {}).items()})
+        np.random.seed(1000 + int(seed))   # Bridge's global RNG; irrelevant for one-hot distributions
+
+        def theta_now():
+            if env_id == "CliffWalking-v1":
+                return [float(x) for x in env.transition_prob]
+            return [float(x) for p in pnames for x in getattr(env.unwrapped, p)]
+
+        def put(k, obs, info):
+            rec["state"][k, i, 0] = obs["state"]
+            rec["env_change"][k, i] = [obs["env_change"][p] for p in pnames]
+            rec["delta_change"][k, i] = [obs["delta_change"][p] for p in pnames]
+            rec["gt_env_change"][k, i] = [info["Ground Truth Env Change"][p] for p in pnames]
+            rec["gt_delta_change"][k, i] = [info["Ground Truth Delta Change"][p] for p in pnames]
+            rec["relative_time"][k, i] = obs["relative_time"]
+            rec["theta"][k, i] = theta_now()
+
+        obs, info = env.reset(seed=int(seed))
+        put(0, obs, info)
+        need_reset = False
+        for k in range(T):
+            if need_reset:
+                obs, info = env.reset()
+                r, term, trunc = 0.0, False, False
+                rec["was_reset"][k, i] = 1
+                if "prob" in rec:
+                    rec["prob"][k, i] = info["prob"]
+            else:
+                obs, r, term, trunc, info = env.step(int(actions[k, i]))
+                if "prob" in rec:
+                    rec["prob"][k, i] = info["prob"]
+            put(k + 1, obs, info)
+            rec["reward"][k, i] = r
+            rec["terminated"][k, i] = term
+            rec["truncated"][k, i] = trunc
+            need_reset = bool(term or trunc)
+    return rec
+
+
 def make_actions(env_id, T, N):
     """Fixed action stream: the reference's own idiom (tests/test_step_reset.py:1091-1095)."""
     rng = np.random.default_rng(123)
@@ -336,7 +462,7 @@ def make_actions(env_id, T, N):
         return rng.integers(2, size=(T, N)).astype(np.int32)
     if env_id in ("Acrobot-v1", "MountainCar-v0"):
         return rng.integers(3, size=(T, N)).astype(np.int32)
-    if env_id == "FrozenLake-v1":
+    if env_id in ("FrozenLake-v1", "CliffWalking-v1", "ns_gym/Bridge-v0"):
         return rng.integers(4, size=(T, N)).astype(np.int32)
     if env_id == "Pendulum-v1":
         return rng.uniform(-2.0, 2.0, size=(T, N)).astype(np.float32)
@@ -615,6 +741,7 @@ def main():
         "dist_update_specs": DIST_UPDATE_SPECS,
         "traj_specs": TRAJ_SPECS,
         "planning_specs": PLANNING_SPECS,
+        "grid_specs": GRID_SPECS,
     }
     np.savez_compressed(os.path.join(HERE, "numpy_streams.npz"), **gen_numpy_streams())
     np.savez_compressed(os.path.join(HERE, "schedulers.npz"), **gen_schedulers(S))
@@ -624,6 +751,11 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"traj_{name}.npz"), **rec)
         print(name, "episodes:", int(rec["was_reset"].sum()), "fired:", int(rec["gt_env_change"].sum()))
     np.savez_compressed(os.path.join(HERE, "reset_semantics.npz"), **gen_reset_semantics(gym, S, U, CC))
+    for name, spec in GRID_SPECS.items():
+        rec = gen_grid_trajectory(gym, S, U, spec)
+        np.savez_compressed(os.path.join(HERE, f"grid_{name}.npz"), **rec)
+        print(name, "episodes:", int(rec["was_reset"].sum()), "fired:", int(rec["gt_env_change"].sum()),
+              "terminated:", int(rec["terminated"].sum()), "truncated:", int(rec["truncated"].sum()))
     for name, spec in PLANNING_SPECS.items():
         rec = gen_planning(gym, S, U, CC, FL, spec)
         np.savez_compressed(os.path.join(HERE, f"plan_{name}.npz"), **rec)

@@ -1,0 +1,85 @@
+"""CliffWalking / Bridge on the GPU against the reference-wrapper fixtures and
+the oracle at scale; N = 1 adaptors like the reference's tests/test_gridworld_wrappers.py /
+tests/test_bridge.py."""
+import numpy as np
+import pytest
+
+from tests.test_oracle_grid import GRID, check_grid, grid_spec
+from tests.util import GpuView, OracleView, compare_views, load, make_env_from_spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _vec(*a, **k):
+    from ns_gym_amd.vec_env import VecNSEnv
+
+    return VecNSEnv(*a, **k)
+
+
+@pytest.mark.parametrize("name", sorted(GRID))
+def test_grid_trajectory_matches_reference_wrapper(name):
+    spec = grid_spec(name)
+    env = make_env_from_spec(_vec, spec)
+    check_grid(GpuView(env), spec, load(f"grid_{name}.npz"))
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["cliff_decrement", "cliff_terminal_stepwise_rewards", "bridge_split_onehot"])
+def test_grid_hip_matches_oracle_at_scale(name):
+    from oracle.oracle import OracleVecEnv
+
+    n, T = 16384, 200
+    spec = grid_spec(name)
+    g = GpuView(make_env_from_spec(_vec, spec, n=n, track_returns=True))
+    o = OracleView(make_env_from_spec(OracleVecEnv, spec, n=n, track_returns=True))
+    seeds = np.arange(n, dtype=np.uint64) + np.uint64(4321)
+    acts = np.random.default_rng(9).integers(4, size=(T, n)).astype(np.int32)
+    compare_views(g.reset(seeds), o.reset(seeds), True, "reset")
+    for k in range(T):
+        compare_views(g.step(acts[k]), o.step(acts[k]), True, f"step {k}")
+    c = g.env.counters()
+    oc = o.env.a["counters"].sum(axis=1)
+    assert [c["episodes"], c["updates_applied"], c["constraint_violations"], c["env_steps"]] == [int(x) for x in oc]
+    g.env.close()
+
+
+def test_bridge_slip_statistics_and_general_distribution():
+    """np.random.choice(p=P) is an unseeded global draw in the reference: distributional check."""
+    import torch
+
+    from ns_gym_amd import make
+    from ns_gym_amd.schedulers import ContinuousScheduler
+    from ns_gym_amd.update_functions import DistributionNoUpdate
+
+    n = 400_000
+    env = _vec(make("ns_gym/Bridge-v0"), {"P": DistributionNoUpdate(ContinuousScheduler())}, n, initial_prob_dist=[0.6, 0.3, 0.1])
+    env.reset(seed=0)
+    env.step(torch.full((n,), 2, dtype=torch.int32, device="cuda"))
+    cells = env.state.cpu().numpy()
+    freq = [np.mean(cells == c) for c in (2 * 8 + 5, 1 * 8 + 4, 3 * 8 + 4)]
+    np.testing.assert_allclose(freq, [0.6, 0.3, 0.1], atol=4e-3)
+    env.close()
+
+
+def test_single_env_adaptors():
+    from ns_gym_amd import make
+    from ns_gym_amd.schedulers import ContinuousScheduler
+    from ns_gym_amd.update_functions import DistributionDecrementUpdate
+    from ns_gym_amd.wrappers import NSBridgeWrapper, NSCliffWalkingWrapper
+
+    env = NSCliffWalkingWrapper(make("CliffWalking-v1"), {"P": DistributionDecrementUpdate(ContinuousScheduler(), k=0.1)},
+                                change_notification=True, delta_change_notification=True)
+    obs, info = env.reset(seed=0)
+    assert obs["state"] == 36 and isinstance(obs["state"], int) and info["prob"] == 1
+    obs, r, term, trunc, info = env.step(0)
+    assert info["transition_prob"] == pytest.approx([0.9, 0.1 / 3, 0.1 / 3, 0.1 / 3]) and r in (-1.0, -100.0)
+    assert obs["env_change"] == {"P": 1}
+    env.close()
+    env = NSBridgeWrapper(make("ns_gym/Bridge-v0"), {"P_left": DistributionDecrementUpdate(ContinuousScheduler(), k=0.2)},
+                          change_notification=True)
+    obs, info = env.reset(seed=1)
+    assert obs["state"] == 20                       # (2, 4), envs/Bridge.py:110
+    obs, r, term, trunc, info = env.step(2)          # RIGHT with P_right = [1,0,0] (right half) -> (2,5)
+    assert obs["state"] == 21 and r == 0 and isinstance(r, int) and not term
+    assert env.unwrapped.P_left == pytest.approx([0.8, 0.1, 0.1]) and env.unwrapped.P_right == [1.0, 0.0, 0.0]
+    env.close()

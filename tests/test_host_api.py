@@ -23,7 +23,8 @@ def test_tunable_params_match_reference_defaults():
                                                   "LINK_COM_POS_1", "LINK_COM_POS_2", "LINK_MOI"]
     assert TUNABLE_PARAMS["MountainCarEnv"] == {"gravity": 0.0025, "force": 0.001}
     assert TUNABLE_PARAMS["Continuous_MountainCarEnv"] == {"power": 0.0015}
-    assert list(TUNABLE_PARAMS["FrozenLakeEnv"]) == ["P"]
+    assert list(TUNABLE_PARAMS["FrozenLakeEnv"]) == ["P"] and list(TUNABLE_PARAMS["CliffWalkingEnv"]) == ["P"]
+    assert TUNABLE_PARAMS["Bridge"] == {"P": [1.0, 0.0, 0.0], "P_left": [1.0, 0.0, 0.0], "P_right": [1.0, 0.0, 0.0]}  # base.py:1161
 
 
 def test_update_fn_requires_scheduler_instance():
@@ -135,7 +136,7 @@ def test_frozenlake_config():
     desc = blob[cfg.desc_tab_off:cfg.desc_tab_off + 64]
     assert desc[:8] == b"SFFFFFFF" and desc[-1:] == b"G" and desc.count(b"H") == 10
     assert cfg.flags & A.F_MODIFIED_REWARDS and list(cfg.letter_reward) == [0.0, 0.0, -1.0, 1.0]
-    assert list(cfg.initial_prob) == [1.0, 0.0, 0.0]
+    assert list(cfg.initial_prob[0])[:3] == [1.0, 0.0, 0.0]
 
 
 def test_product_has_no_cpu_fallback():
@@ -164,3 +165,25 @@ def test_product_has_no_cpu_fallback():
             src = open(f, errors="replace").read()
             assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src.replace(
                 "never routes through the oracle", ""), f"{f} must not touch oracle/"
+
+
+def test_cliffwalking_and_bridge_configs():
+    from ns_gym_amd.update_functions import DistributionCyclicUpdate, DistributionDecrementUpdate
+
+    cfg, blob, spec, names = compile_config(make("CliffWalking-v1"), {"P": DistributionDecrementUpdate(ContinuousScheduler(), 0.1)},
+                                            terminal_cliff=True)
+    assert (cfg.env_type, cfg.nrow, cfg.ncol, cfg.max_episode_steps) == (A.ENV_CLIFFWALKING, 4, 12, 0)
+    assert list(cfg.initial_prob[0]) == [1.0, 0.0, 0.0, 0.0] and cfg.flags & A.F_TERMINAL_CLIFF
+    assert list(cfg.letter_reward) == [-1.0, -1.0, -100.0, 0.0]          # S F H G defaults (toy_text.py:56-59)
+    desc = blob[cfg.desc_tab_off:cfg.desc_tab_off + 48]
+    assert desc[36:] == b"S" + b"H" * 10 + b"G" and desc[:36] == b"F" * 36
+    with pytest.raises(ValueError):   # 3-vectors do not fit the 4-way CliffWalking distribution
+        compile_config(make("CliffWalking-v1"), {"P": DistributionCyclicUpdate(ContinuousScheduler(), [[1, 0, 0]])})
+    cfg, blob, spec, names = compile_config(make("ns_gym/Bridge-v0"),
+                                            {"P_right": DistributionCyclicUpdate(ContinuousScheduler(), [[0, 1, 0]])},
+                                            initial_prob_dist=([1, 0, 0], [0, 0, 1]))
+    assert (cfg.env_type, cfg.nrow, cfg.ncol, cfg.max_episode_steps, cfg.n_params) == (A.ENV_BRIDGE, 5, 8, 100, 1)
+    assert cfg.params[0].theta_slot == 2 and list(cfg.initial_prob[1])[:3] == [0.0, 0.0, 1.0]
+    with pytest.raises(AssertionError):
+        compile_config(make("ns_gym/Bridge-v0"), {"P": DistributionCyclicUpdate(ContinuousScheduler(), [[0, 1, 0]]),
+                                                  "P_left": DistributionCyclicUpdate(ContinuousScheduler(), [[0, 1, 0]])})

@@ -28,7 +28,8 @@ def make_env_from_spec(factory, spec, n=None, seeds=None, **extra):
     env = make(spec["env_id"], **spec.get("make_kwargs", {}))
     tp = build_tunable_params(spec["params"])
     n = n if n is not None else len(spec["seeds"])
-    return factory(env, tp, n, **spec["flags"], **spec.get("wrapper_kwargs", {}), **extra)
+    kw = {**spec["flags"], **spec.get("wrapper_kwargs", {}), **extra}
+    return factory(env, tp, n, **kw)
 
 
 def check_trajectory(view, spec, rec, T=None, strict_theta=False):
