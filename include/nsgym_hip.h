@@ -95,7 +95,8 @@ enum {
   NSG_UPD_D_NOUPDATE = 36,    /* :217-231                         */
   NSG_UPD_D_UNIFORMDRIFT = 37,/* :234-261 u0=rate                 */
   NSG_UPD_D_TARGETREV = 38,   /* :264-293 u[0..n)=target u[n]=theta */
-  NSG_UPD_D_LERP = 39         /* :296-331 u[0..n)=start u[n..2n)=end u[2n]=T */
+  NSG_UPD_D_LERP = 39,        /* :296-331 u[0..n)=start u[n..2n)=end u[2n]=T */
+  NSG_UPD_D_RANDOMCAT = 40    /* :11-38   rng.dirichlet(ones(n)): n standard exponentials, normalised */
 };
 
 /* flags of nsg_config.flags (constructor kwargs of NSWrapper, ns_gym/base.py:222-232) */
@@ -144,6 +145,9 @@ typedef struct nsg_param_cfg {
   uint64_t fn_seed;      /* constructor seed of a stochastic fn (valid if has_fn_seed)      */
   int32_t has_fn_seed;
   int32_t uses_rng;      /* 1 if the update fn owns a PCG64 stream                          */
+  uint64_t sched_seed;   /* constructor seed of a stochastic scheduler (valid if has_sched_seed) */
+  int32_t has_sched_seed;
+  int32_t reserved0;
 } nsg_param_cfg;
 
 typedef struct nsg_config {
@@ -185,6 +189,11 @@ typedef struct nsg_buffers {
   uint64_t* rng_env;     /* [N][4] env np_random PCG64 records: state_hi,state_lo,inc_hi,inc_lo
                             (32-byte record per env: streams are touched by few scattered lanes) */
   uint64_t* rng_upd;     /* [P][N][4] update-fn PCG64 streams (only rows with uses_rng)   */
+  uint64_t* rng_sched;   /* [P][N][4] PCG64 records of stochastic schedulers (Random, DecayingProbability,
+                            Memoryless).  A scheduler lives inside the deep-copied init_initial_params, so a
+                            non-persistent reset REWINDS its stream to the construction state
+                            (base.py:381-384); it is never re-seeded by reset(seed) (base.py:151-158)   */
+  int32_t* sched_next;   /* [P][N] MemorylessScheduler.transition_time (schedulers.py:108-113)   */
   int32_t* cursor;       /* [P][N] StepWise/Cyclic list cursor                            */
   float* obs;            /* [N][D] obs["state"] float32 (classic control)                 */
   float* reward;         /* [N]                                                           */
@@ -207,7 +216,7 @@ typedef struct nsg_layout {
   int64_t n;
   int32_t phys_dim, obs_dim, n_params, n_theta_rows, action_is_float;
   int32_t n_actions;           /* discrete action count, 0 for continuous                  */
-  int64_t phys, cell, theta, table_prob, derived, t, t_fork, status, rng_env, rng_upd, cursor, obs, reward, terminated,
+  int64_t phys, cell, theta, table_prob, derived, t, t_fork, status, rng_env, rng_upd, rng_sched, sched_next, cursor, obs, reward, terminated,
       truncated, env_change, delta_change, prob, ep_return, ep_length, last_return, last_length,
       counters, done_bits;
 } nsg_layout;

@@ -24,7 +24,7 @@ N_DIST = {ENV_FROZENLAKE: 3, ENV_CLIFFWALKING: 4, ENV_BRIDGE: 3}
  UPD_RW_DRIFT_TREND, UPD_OU, UPD_BOUNDED_RW) = range(17)
 # distribution update fns
 (UPD_D_INCREMENT, UPD_D_DECREMENT, UPD_D_STEPWISE, UPD_D_CYCLIC, UPD_D_NOUPDATE, UPD_D_UNIFORMDRIFT,
- UPD_D_TARGETREV, UPD_D_LERP) = range(32, 40)
+ UPD_D_TARGETREV, UPD_D_LERP, UPD_D_RANDOMCAT) = range(32, 41)
 
 F_CHANGE_NOTIFICATION = 0x1
 F_DELTA_NOTIFICATION = 0x2
@@ -62,6 +62,9 @@ class ParamCfg(C.Structure):
         ("fn_seed", C.c_uint64),
         ("has_fn_seed", C.c_int32),
         ("uses_rng", C.c_int32),
+        ("sched_seed", C.c_uint64),
+        ("has_sched_seed", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -84,7 +87,7 @@ class Config(C.Structure):
 
 BUFFER_FIELDS = [
     ("phys", C.c_double), ("cell", C.c_int32), ("theta", C.c_double), ("table_prob", C.c_double), ("derived", C.c_double), ("t", C.c_int32), ("t_fork", C.c_int32),
-    ("status", C.c_uint8), ("rng_env", C.c_uint64), ("rng_upd", C.c_uint64), ("cursor", C.c_int32),
+    ("status", C.c_uint8), ("rng_env", C.c_uint64), ("rng_upd", C.c_uint64), ("rng_sched", C.c_uint64), ("sched_next", C.c_int32), ("cursor", C.c_int32),
     ("obs", C.c_float), ("reward", C.c_float), ("terminated", C.c_uint8), ("truncated", C.c_uint8),
     ("env_change", C.c_uint8), ("delta_change", C.c_float), ("prob", C.c_float),
     ("ep_return", C.c_float), ("ep_length", C.c_int32), ("last_return", C.c_float),

@@ -35,9 +35,10 @@ struct Segment {
   nsg_buffers buf;
   int64_t N;
   const uint8_t* tables;   // constant-table blob (global copy)
-  const uint64_t* zig;     // ki[256] | wi[256] | fi[256] (global copy)
+  const uint64_t* zig;     // ki | wi | fi | ke | we | fe, 256 words each (global copy)
   int32_t table_bytes;
-  int32_t uses_normal;     // some update fn draws normals -> stage the ziggurat tables
+  int32_t uses_normal;     // some update fn draws normals -> stage the normal ziggurat tables
+  int32_t uses_exp;        // Memoryless (p < 1/3) / RandomCategorical -> stage the exponential ziggurat tables
   int32_t simple_theta;    // every update fn is plain arithmetic / table look-up (upd_kind_is_simple)
   int32_t block_begin;     // first block of this segment in a heterogeneous launch
   int32_t block_count;
@@ -57,12 +58,12 @@ struct LdsTables {
   short* reset_list;    // [kBlock] lanes whose env resets in this chunk
   double* reset_state;  // [kBlock][4] initial states drawn by the helper lanes, read back by the owners
   uint64_t* blob;       // constant-table blob
-  uint64_t* zig;        // 768 words, only when some update fn draws normals
+  uint64_t* zig;        // 768 words (normal) + 768 words (exponential), each only when needed
 };
 constexpr int kLdsHeaderBytes = 32 + kBlock * 2 + kBlock * 4 * 8;
 
-__host__ __device__ inline int lds_bytes_for(int table_bytes, int uses_normal) {
-  return kLdsHeaderBytes + ((table_bytes + 7) & ~7) + (uses_normal ? 768 * 8 : 0);
+__host__ __device__ inline int lds_bytes_for(int table_bytes, int uses_normal, int uses_exp) {
+  return kLdsHeaderBytes + ((table_bytes + 7) & ~7) + (uses_normal ? 768 * 8 : 0) + (uses_exp ? 768 * 8 : 0);
 }
 
 // Cooperative staging of the constant tables into LDS (once per workgroup).
@@ -76,8 +77,12 @@ __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, 
   lds.blob = (uint64_t*)(base + kLdsHeaderBytes);
   lds.zig = (uint64_t*)(base + kLdsHeaderBytes + ((sg.table_bytes + 7) & ~7));
   const int tid = threadIdx.x;
+  uint64_t* zexp = lds.zig + (sg.uses_normal ? 768 : 0);
   if (sg.uses_normal) {
     for (int k = tid; k < 768; k += kBlock) lds.zig[k] = sg.zig[k];
+  }
+  if (sg.uses_exp) {
+    for (int k = tid; k < 768; k += kBlock) zexp[k] = sg.zig[768 + k];
   }
   const int words = (sg.table_bytes + 7) >> 3;
   const uint64_t* src = (const uint64_t*)sg.tables;
@@ -89,6 +94,9 @@ __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, 
   zg.ki = lds.zig;
   zg.wi = (const double*)(lds.zig + 256);
   zg.fi = (const double*)(lds.zig + 512);
+  zg.ke = zexp;
+  zg.we = (const double*)(zexp + 256);
+  zg.fe = (const double*)(zexp + 512);
 }
 
 // Where one step's per-env outputs go: the handle's own buffers (nsg_step) or the k-th slice of
@@ -165,6 +173,38 @@ template <int ENV> __device__ __forceinline__ bool own_constraint_violated(int s
   }
 }
 
+// Fire predicate of param p of env i.  Deterministic schedulers are pure functions of t; the
+// stochastic ones (FULL builds) advance their own PCG64 record and, for Memoryless, transition_time.
+// On a non-persistent reset the scheduler is rewound to its construction state together with the
+// rest of the deep-copied init_initial_params (base.py:381-384).
+template <bool FULL>
+__device__ __forceinline__ bool fire_param(const nsg_config& cfg, const nsg_buffers& b, const Tables& tb, const ZigLds& zg,
+                                           int64_t N, int64_t i, int p, int t, bool eval, bool rewind) {
+  const nsg_param_cfg& pc = cfg.params[p];
+  if constexpr (FULL) {
+    if (sched_is_stochastic(pc.sched_kind)) {
+      bool f = false;
+      if (eval) {
+        Pcg r;
+        pcg_load(b.rng_sched + (int64_t)p * 4 * N, N, i, r);
+        int next = pc.sched_kind == NSG_SCHED_MEMORYLESS ? b.sched_next[(int64_t)p * N + i] : 0;
+        f = sched_fire_stoch(pc, zg, t, r, next);
+        pcg_store_state(b.rng_sched + (int64_t)p * 4 * N, N, i, r);
+        if (pc.sched_kind == NSG_SCHED_MEMORYLESS) b.sched_next[(int64_t)p * N + i] = next;
+      }
+      if (rewind) {
+        Pcg r;
+        int next;
+        sched_construct(pc, zg, p, i, r, next);
+        pcg_store_all(b.rng_sched + (int64_t)p * 4 * N, N, i, r);
+        b.sched_next[(int64_t)p * N + i] = next;
+      }
+      return f;
+    }
+  }
+  return eval && sched_fire(pc, tb, t);
+}
+
 // ============================================================================================
 // classic-control step for one chunk of kBlock envs (the whole workgroup; one env per lane).
 //   phase 1: every lane steps its env (θ-engine, constraints, integrator, outputs); an env that
@@ -222,7 +262,7 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
       const int slot = pc.theta_slot;
       const double c = active ? ldg(b.theta + (int64_t)p * N, o8) : cfg.base_theta[slot];
       double n = c;
-      bool fired = do_step && theta_live && sched_fire(pc, tb, t);
+      bool fired = fire_param<FULL>(cfg, b, tb, zg, N, i, p, t, do_step && theta_live, do_reset && !persistent);
       if (fired) {
         Pcg r = {0, 0, 0, 0};
         int cursor = 0;
@@ -266,7 +306,7 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
       const int slot = pc.theta_slot;
       const double c = active ? ldg(b.theta + (int64_t)p * N, o8) : cfg.base_theta[slot];
       double n = c;
-      if (do_step && theta_live && sched_fire(pc, tb, t)) {
+      if (fire_param<FULL>(cfg, b, tb, zg, N, i, p, t, do_step && theta_live, do_reset && !persistent)) {
         Pcg r = {0, 0, 0, 0};
         int cursor = 0;
         const bool has_cur = upd_uses_cursor(pc.upd_kind);
@@ -417,9 +457,9 @@ __device__ __forceinline__ int grid_start_state(const nsg_config& cfg, const uin
   return 0;
 }
 
-template <int ENV>
-__device__ __forceinline__ void step_grid(const Segment& sg, const Tables& tb, const void* actions, const StepOut& out,
-                                          int64_t i, bool active, WaveCounts& wc) {
+template <int ENV, bool FULL>
+__device__ __forceinline__ void step_grid(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
+                                          const StepOut& out, int64_t i, bool active, WaveCounts& wc) {
   constexpr int ND = ENV == NSG_ENV_CLIFFWALKING ? 4 : 3;
   const nsg_config& cfg = sg.cfg;
   const nsg_buffers& b = sg.buf;
@@ -468,7 +508,7 @@ __device__ __forceinline__ void step_grid(const Segment& sg, const Tables& tb, c
   }
   for (int p = 0; p < P; p++) {
     const nsg_param_cfg& pc = cfg.params[p];
-    const bool fired = do_step && theta_live && sched_fire(pc, tb, t);
+    const bool fired = fire_param<FULL>(cfg, b, tb, zg, N, i, p, t, do_step && theta_live, do_reset && !persistent);
     double delta = 0.0;
     double q[ND];
     bool have_q = false;
@@ -479,7 +519,10 @@ __device__ __forceinline__ void step_grid(const Segment& sg, const Tables& tb, c
       int cursor = 0;
       const bool has_cur = upd_uses_cursor(pc.upd_kind);
       if (has_cur) cursor = b.cursor[(int64_t)p * N + i];
-      upd_dist<ND>(pc, tb, pp, t, cursor, q);
+      Pcg ur = {0, 0, 0, 0};
+      if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, i, ur);
+      upd_dist<ND, FULL>(pc, tb, zg, pp, t, cursor, ur, q);
+      if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, i, ur);
       if (has_cur) b.cursor[(int64_t)p * N + i] = cursor;
       delta = w1_n<ND>(pp, q);  // base.py:192-203
 #pragma unroll
@@ -611,7 +654,7 @@ __device__ __forceinline__ void step_block(const Segment& sg, const Tables& tb, 
                                            const StepOut& out, int64_t base, int parity, LdsTables& lds, WaveCounts& wc) {
   if constexpr (ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE) {
     const int64_t i = base + threadIdx.x;
-    step_grid<ENV>(sg, tb, actions, out, i, i < sg.N, wc);
+    step_grid<ENV, FULL>(sg, tb, zg, actions, out, i, i < sg.N, wc);
   } else {
     step_chunk<ENV, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc);
   }
@@ -680,6 +723,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
   const int64_t N = sg.N;
   const int P = cfg.n_params;
   const bool persistent = (cfg.flags & NSG_F_PERSISTENT_PARAMS) != 0;
+  // not a hot path: the ziggurat tables are read from their global copy
+  const ZigLds zg = {sg.zig, (const double*)(sg.zig + 256), (const double*)(sg.zig + 512),
+                     sg.zig + 768, (const double*)(sg.zig + 1024), (const double*)(sg.zig + 1280)};
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
     if (mask && !mask[i]) continue;
     Pcg g;
@@ -716,6 +762,13 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
           b.theta[(int64_t)p * N + i] = cfg.base_theta[pc.theta_slot];
         }
         if (b.cursor) b.cursor[(int64_t)p * N + i] = 0;
+        if (sched_is_stochastic(pc.sched_kind)) {  // rewound with the rest of init_initial_params
+          Pcg sr;
+          int nx;
+          sched_construct(pc, zg, p, i, sr, nx);
+          pcg_store_all(b.rng_sched + (int64_t)p * 4 * N, N, i, sr);
+          b.sched_next[(int64_t)p * N + i] = nx;
+        }
       }
       if (pc.uses_rng && seeds) {  // SeedSequence(seed).spawn(P)[rng_child], base.py:412-421
         Pcg r;
@@ -747,6 +800,8 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const Segment* __restrict_
   const int64_t N = sg.N;
   const bool fl = is_grid_env(cfg.env_type);
   const int nd = cfg.env_type == NSG_ENV_CLIFFWALKING ? 4 : 3;
+  const ZigLds zg = {sg.zig, (const double*)(sg.zig + 256), (const double*)(sg.zig + 512),
+                     sg.zig + 768, (const double*)(sg.zig + 1024), (const double*)(sg.zig + 1280)};
   if (blockIdx.x == 0 && b.counters)
     for (int k = threadIdx.x; k < NSG_CNT_COUNT * kCntShards; k += kBlock) b.counters[k] = 0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
@@ -762,6 +817,13 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const Segment* __restrict_
       const nsg_param_cfg& pc = cfg.params[p];
       if (!fl) b.theta[(int64_t)p * N + i] = cfg.base_theta[pc.theta_slot];
       if (b.cursor) b.cursor[(int64_t)p * N + i] = 0;
+      if (sched_is_stochastic(pc.sched_kind)) {
+        Pcg sr;
+        int nx;
+        sched_construct(pc, zg, p, i, sr, nx);
+        pcg_store_all(b.rng_sched + (int64_t)p * 4 * N, N, i, sr);
+        b.sched_next[(int64_t)p * N + i] = nx;
+      }
       if (pc.uses_rng) {
         Pcg r;
         if (pc.has_fn_seed) pcg_seed(r, pc.fn_seed, -1);
@@ -825,7 +887,10 @@ __global__ __launch_bounds__(kBlock) void theta_trace_kernel(const Segment* __re
   if (i >= n) return;
   Pcg r = {0, 0, 0, 0};
   if (pc.uses_rng && rng_state) pcg_load(rng_state, n, i, r);
-  int cursor = 0;
+  int cursor = 0, snext = 0;
+  Pcg sr = {0, 0, 0, 0};
+  const bool stoch = sched_is_stochastic(pc.sched_kind);
+  if (stoch) sched_construct(pc, zg, p, i, sr, snext);
   double th[4] = {0, 0, 0, 0};
   if (dist) {
     for (int c = 0; c < nd; c++) th[c] = theta0[nd * i + c];
@@ -834,13 +899,13 @@ __global__ __launch_bounds__(kBlock) void theta_trace_kernel(const Segment* __re
   }
   for (int k = 0; k < T; k++) {
     const int t = t0 + k;
-    const bool fired = sched_fire(pc, tb, t);
+    const bool fired = stoch ? sched_fire_stoch(pc, zg, t, sr, snext) : sched_fire(pc, tb, t);
     double delta = 0.0;
     if (fired) {
       if (dist) {
         double q[4] = {0, 0, 0, 0};
-        if (nd == 4) { upd_dist<4>(pc, tb, th, t, cursor, q); delta = w1_n<4>(th, q); }
-        else { upd_dist<3>(pc, tb, th, t, cursor, q); delta = w1_n<3>(th, q); }
+        if (nd == 4) { upd_dist<4, true>(pc, tb, zg, th, t, cursor, r, q); delta = w1_n<4>(th, q); }
+        else { upd_dist<3, true>(pc, tb, zg, th, t, cursor, r, q); delta = w1_n<3>(th, q); }
         for (int c = 0; c < nd; c++) th[c] = q[c];
       } else {
         double nvv = upd_scalar<true>(pc, tb, zg, th[0], t, r, cursor);
@@ -933,6 +998,10 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
     }
     for (int p = 0; p < P; p++) {
       if (db.cursor && sb.cursor) db.cursor[(int64_t)p * N + i] = sb.cursor[(int64_t)p * N + i];  // deepcopy(tunable_params)
+      if (sched_is_stochastic(cfg.params[p].sched_kind)) {  // scheduler state is copied, never re-seeded (base.py:433-441)
+        for (int k = 0; k < 4; k++) db.rng_sched[((int64_t)p * N + i) * 4 + k] = sb.rng_sched[((int64_t)p * N + i) * 4 + k];
+        db.sched_next[(int64_t)p * N + i] = sb.sched_next[(int64_t)p * N + i];
+      }
       db.env_change[(int64_t)p * N + i] = sb.env_change[(int64_t)p * N + i];
       db.delta_change[(int64_t)p * N + i] = sb.delta_change[(int64_t)p * N + i];
       if (cfg.params[p].uses_rng) {  // _reseed_planning_env_rngs (base.py:433-441): fresh entropy

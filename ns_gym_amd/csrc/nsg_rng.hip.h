@@ -152,9 +152,12 @@ __device__ __forceinline__ void pcg_store_all(uint64_t* base, int64_t N, int64_t
 
 // ---- ziggurat normal (numpy random_standard_normal), tables in LDS --------------------
 struct ZigLds {
-  const uint64_t* ki;
+  const uint64_t* ki;   // normal ziggurat
   const double* wi;
   const double* fi;
+  const uint64_t* ke;   // exponential ziggurat (geometric inversion, Dirichlet)
+  const double* we;
+  const double* fe;
 };
 
 __device__ inline double pcg_std_normal(Pcg& g, const ZigLds& z) {
@@ -183,6 +186,40 @@ __device__ inline double pcg_std_normal(Pcg& g, const ZigLds& z) {
 
 __device__ __forceinline__ double pcg_normal(Pcg& g, const ZigLds& z, double loc, double scale) {
   return loc + scale * pcg_std_normal(g, z);
+}
+
+// numpy random_standard_exponential (256-layer ziggurat), tables in LDS
+__device__ inline double pcg_std_exponential(Pcg& g, const ZigLds& z) {
+  const double ZER = 7.69711747013104972;
+  for (;;) {
+    uint64_t ri = pcg_next64(g);
+    ri >>= 3;
+    const int idx = (int)(ri & 0xFF);
+    ri >>= 8;
+    const double x = (double)ri * z.we[idx];
+    if (ri < z.ke[idx]) return x;  // 98.9 % of draws
+    if (idx == 0) return ZER - nsg_log1p(-pcg_double(g));
+    const double f1 = z.fe[idx - 1], f0 = z.fe[idx];
+    if ((f1 - f0) * pcg_double(g) + f0 < nsg_exp(-x)) return x;
+  }
+}
+
+// numpy random_geometric: search for p >= 1/3, inversion (ceil(-Exp / log1p(-p))) otherwise
+__device__ inline int64_t pcg_geometric(Pcg& g, const ZigLds& z, double p) {
+  if (p >= 0.333333333333333333333333) {
+    int64_t X = 1;
+    double sum = p, prod = p;
+    const double q = 1.0 - p, U = pcg_double(g);
+    while (U > sum && X < 0x7fffffff) {  // bounded: the kernel must terminate for any p
+      prod *= q;
+      sum += prod;
+      X++;
+    }
+    return X;
+  }
+  const double zz = ceil(-pcg_std_exponential(g, z) / nsg_log1p(-p));
+  if (zz >= 9.223372036854776e+18) return 0x7fffffffffffffffLL;
+  return (int64_t)zz;
 }
 
 }  // namespace nsg

@@ -41,6 +41,40 @@ __device__ __forceinline__ bool sched_fire(const nsg_param_cfg& pc, const Tables
   }
 }
 
+__host__ __device__ inline bool sched_is_stochastic(int k) {
+  return k == NSG_SCHED_RANDOM || k == NSG_SCHED_DECAYING || k == NSG_SCHED_MEMORYLESS;
+}
+
+// Construction-time state of a stochastic scheduler: rng = default_rng(seed) (+ the constructor's first
+// geometric draw for Memoryless, schedulers.py:107-108); seed=None -> a fixed per-env stream.
+__device__ inline void sched_construct(const nsg_param_cfg& pc, const ZigLds& zg, int p, int64_t i, Pcg& r, int& next) {
+  if (pc.has_sched_seed) pcg_seed(r, pc.sched_seed, -1);
+  else pcg_seed(r, (uint64_t)i, 2000 + p);
+  next = 0;
+  if (pc.sched_kind == NSG_SCHED_MEMORYLESS) {
+    const int64_t g = pcg_geometric(r, zg, pc.sched_p0);
+    next = g > 0x7fffffff ? 0x7fffffff : (int)g;
+  }
+}
+
+// Scheduler.__call__ of the stochastic kinds: a draw happens only when start <= t <= end
+__device__ inline bool sched_fire_stoch(const nsg_param_cfg& pc, const ZigLds& zg, int t, Pcg& r, int& next) {
+  const double td = (double)t;
+  if (!(pc.sched_start <= td && td <= pc.sched_end)) return false;
+  switch (pc.sched_kind) {
+    case NSG_SCHED_RANDOM: return pcg_double(r) < pc.sched_p0;                                   // schedulers.py:27-28
+    case NSG_SCHED_DECAYING: return pcg_double(r) < pc.sched_p0 * nsg_exp(-pc.sched_p1 * td);   // :175-177
+    case NSG_SCHED_MEMORYLESS:                                                                  // :110-116
+      if (t == next) {
+        const int64_t g = pcg_geometric(r, zg, pc.sched_p0) + t;
+        next = g > 0x7fffffff ? 0x7fffffff : (int)g;
+        return true;
+      }
+      return false;
+    default: return false;
+  }
+}
+
 // Which update kinds need the "full" θ-engine build (float64 exp/sin/log1p from the device
 // library + the ziggurat sampler).  Batches whose update fns are all plain arithmetic /
 // table look-ups run a kernel instantiated without those paths: its register footprint is
@@ -48,7 +82,7 @@ __device__ __forceinline__ bool sched_fire(const nsg_param_cfg& pc, const Tables
 __host__ __device__ inline bool upd_kind_is_simple(int k) {
   return k == NSG_UPD_INCREMENT || k == NSG_UPD_DECREMENT || k == NSG_UPD_TREND || k == NSG_UPD_POLY ||
          k == NSG_UPD_GEOMETRIC || k == NSG_UPD_LERP || k == NSG_UPD_STEPWISE || k == NSG_UPD_CYCLIC ||
-         k == NSG_UPD_NOUPDATE || k >= NSG_UPD_D_INCREMENT;
+         k == NSG_UPD_NOUPDATE || (k >= NSG_UPD_D_INCREMENT && k != NSG_UPD_D_RANDOMCAT);
 }
 
 // UpdateFn._update for the scalar classes.  `rng` is touched only by the stochastic kinds.
@@ -145,8 +179,9 @@ template <int ND> __device__ __forceinline__ double w1_n(const double* a, const 
 }
 
 // UpdateDistributionFn._update for the slip distributions of the grid wrappers (ND = 3 or 4).
-template <int ND>
-__device__ inline void upd_dist(const nsg_param_cfg& pc, const Tables& tb, const double* p, int t, int& cursor, double* q) {
+template <int ND, bool FULL>
+__device__ inline void upd_dist(const nsg_param_cfg& pc, const Tables& tb, const ZigLds& zg, const double* p, int t, int& cursor,
+                                Pcg& rng, double* q) {
   const double* u = pc.u;
   const double td = (double)t;
 #pragma unroll
@@ -192,6 +227,17 @@ __device__ inline void upd_dist(const nsg_param_cfg& pc, const Tables& tb, const
 #pragma unroll
       for (int k = 0; k < ND; k++) q[k] = p[k] + u[ND] * (u[k] - p[k]);
       break;
+    case NSG_UPD_D_RANDOMCAT: {  // rng.dirichlet(ones(n)): n standard exponentials, then val *= 1/acc
+      if constexpr (FULL) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < ND; k++) { q[k] = pcg_std_exponential(rng, zg); acc = acc + q[k]; }
+        const double invacc = 1.0 / acc;
+#pragma unroll
+        for (int k = 0; k < ND; k++) q[k] = q[k] * invacc;
+      }
+      break;
+    }
     case NSG_UPD_D_LERP: {
       double frac = td / u[2 * ND];
       if (!(frac < 1.0)) frac = 1.0;

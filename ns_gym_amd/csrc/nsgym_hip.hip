@@ -67,7 +67,7 @@ int validate(const nsg_config* cfg, size_t table_bytes) {
     seen |= 1u << pc.theta_slot;
     const bool dist = pc.upd_kind >= NSG_UPD_D_INCREMENT;
     if (dist != fl) return fail(NSG_EINVAL, "param %d: update kind %d does not fit env type %d", p, pc.upd_kind, cfg->env_type);
-    if (dist ? pc.upd_kind > NSG_UPD_D_LERP : (pc.upd_kind < 0 || pc.upd_kind > NSG_UPD_BOUNDED_RW))
+    if (dist ? pc.upd_kind > NSG_UPD_D_RANDOMCAT : (pc.upd_kind < 0 || pc.upd_kind > NSG_UPD_BOUNDED_RW))
       return fail(NSG_EINVAL, "param %d: unknown update kind %d", p, pc.upd_kind);
     switch (pc.sched_kind) {
       case NSG_SCHED_CONTINUOUS: break;
@@ -83,6 +83,13 @@ int validate(const nsg_config* cfg, size_t table_bytes) {
             (size_t)pc.sched_tab_off * 4 + ((size_t)pc.sched_tab_len + 31) / 32 * 4 > table_bytes)
           return fail(NSG_EINVAL, "param %d: schedule bit table out of range", p);
         break;
+      case NSG_SCHED_RANDOM:
+      case NSG_SCHED_DECAYING:
+        if (!(pc.sched_p0 == pc.sched_p0)) return fail(NSG_EINVAL, "param %d: scheduler probability is NaN", p);
+        break;
+      case NSG_SCHED_MEMORYLESS:
+        if (!(pc.sched_p0 > 0.0 && pc.sched_p0 <= 1.0)) return fail(NSG_EINVAL, "param %d: Memoryless p must be in (0, 1]", p);
+        break;
       default: return fail(NSG_EINVAL, "param %d: scheduler kind %d is not supported by the kernels", p, pc.sched_kind);
     }
     const int k = pc.upd_kind;
@@ -93,7 +100,7 @@ int validate(const nsg_config* cfg, size_t table_bytes) {
         return fail(NSG_EINVAL, "param %d: value table out of range", p);
       if ((k == NSG_UPD_CYCLIC || k == NSG_UPD_D_CYCLIC) && pc.val_tab_len == 0) return fail(NSG_EINVAL, "param %d: empty cyclic list", p);
     }
-    if (pc.uses_rng != (upd_is_normal(k) ? 1 : 0)) return fail(NSG_EINVAL, "param %d: uses_rng does not match update kind %d", p, k);
+    if (pc.uses_rng != ((upd_is_normal(k) || k == NSG_UPD_D_RANDOMCAT) ? 1 : 0)) return fail(NSG_EINVAL, "param %d: uses_rng does not match update kind %d", p, k);
   }
   return NSG_OK;
 }
@@ -125,9 +132,10 @@ int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
   memset(out, 0, sizeof(*out));
   const int e = cfg->env_type, P = cfg->n_params;
   const bool fl = is_grid_env(e);
-  bool any_rng = false, any_cursor = false;
+  bool any_rng = false, any_cursor = false, any_sched = false;
   for (int p = 0; p < P; p++) {
     any_rng |= cfg->params[p].uses_rng != 0;
+    any_sched |= sched_is_stochastic(cfg->params[p].sched_kind);
     const int k = cfg->params[p].upd_kind;
     any_cursor |= k == NSG_UPD_STEPWISE || k == NSG_UPD_CYCLIC || k == NSG_UPD_D_STEPWISE || k == NSG_UPD_D_CYCLIC;
   }
@@ -150,6 +158,8 @@ int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
   out->rng_env = 4 * n;
   out->rng_upd = any_rng ? (int64_t)P * 4 * n : 0;
   out->cursor = any_cursor ? (int64_t)P * n : 0;
+  out->rng_sched = any_sched ? (int64_t)P * 4 * n : 0;
+  out->sched_next = any_sched ? (int64_t)P * n : 0;
   out->obs = fl ? 0 : (int64_t)kObsDim[e] * n;
   out->reward = n;
   out->terminated = n;
@@ -183,10 +193,13 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
   HIP_TRY(hipMalloc((void**)&h->d_tables, tb));
   HIP_TRY(hipMemset(h->d_tables, 0, tb));
   if (table_bytes) HIP_TRY(hipMemcpy(h->d_tables, tables, table_bytes, hipMemcpyHostToDevice));
-  uint64_t zig[768];
+  uint64_t zig[1536];
   memcpy(zig, NSG_ZIG_KI, 2048);
   memcpy(zig + 256, NSG_ZIG_WI_BITS, 2048);
   memcpy(zig + 512, NSG_ZIG_FI_BITS, 2048);
+  memcpy(zig + 768, NSG_ZIGE_KE, 2048);
+  memcpy(zig + 1024, NSG_ZIGE_WE_BITS, 2048);
+  memcpy(zig + 1280, NSG_ZIGE_FE_BITS, 2048);
   HIP_TRY(hipMalloc((void**)&h->d_zig, sizeof(zig)));
   HIP_TRY(hipMemcpy(h->d_zig, zig, sizeof(zig), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&h->dev, sizeof(Segment)));
@@ -197,9 +210,12 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
   h->host.table_bytes = (int32_t)table_bytes;
   h->host.uses_normal = 0;
   h->host.simple_theta = 1;
+  h->host.uses_exp = 0;
   for (int p = 0; p < cfg->n_params; p++) {
-    h->host.uses_normal |= cfg->params[p].uses_rng;
-    if (!upd_kind_is_simple(cfg->params[p].upd_kind)) h->host.simple_theta = 0;
+    const nsg_param_cfg& pc = cfg->params[p];
+    if (upd_is_normal(pc.upd_kind)) h->host.uses_normal = 1;
+    if (pc.upd_kind == NSG_UPD_D_RANDOMCAT || pc.sched_kind == NSG_SCHED_MEMORYLESS) h->host.uses_exp = 1;
+    if (!upd_kind_is_simple(pc.upd_kind) || sched_is_stochastic(pc.sched_kind)) h->host.simple_theta = 0;
   }
   h->host.block_begin = 0;
   h->host.block_count = 0;
@@ -228,7 +244,7 @@ int nsg_bind(nsg_handle* h, const nsg_buffers* bufs) {
   if (rc) return rc;
 #define NEED(field) \
   if (lay.field > 0 && !bufs->field) return fail(NSG_EINVAL, "buffer '%s' is required (%lld elements)", #field, (long long)lay.field)
-  NEED(phys); NEED(cell); NEED(theta); NEED(table_prob); NEED(derived); NEED(t); NEED(t_fork); NEED(status); NEED(rng_env); NEED(rng_upd); NEED(cursor);
+  NEED(phys); NEED(cell); NEED(theta); NEED(table_prob); NEED(derived); NEED(t); NEED(t_fork); NEED(status); NEED(rng_env); NEED(rng_upd); NEED(rng_sched); NEED(sched_next); NEED(cursor);
   NEED(obs); NEED(reward); NEED(terminated); NEED(truncated); NEED(env_change); NEED(delta_change);
   NEED(ep_return); NEED(ep_length); NEED(last_return); NEED(last_length);
 #undef NEED
@@ -269,7 +285,7 @@ int nsg_step(nsg_handle* h, const void* actions_dev, void* stream) {
   if (!actions_dev) return fail(NSG_EINVAL, "actions_dev is NULL");
   hipStream_t s = (hipStream_t)stream;
   const int grid = grid_for(h->n);
-  const size_t lds = (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal);
+  const size_t lds = (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp);
   if (h->host.simple_theta) {
     DISPATCH_ENV(h->host.cfg.env_type,
                  hipLaunchKernelGGL((step_kernel<E, false>), dim3(grid), dim3(kBlock), lds, s, h->dev, actions_dev));
@@ -291,10 +307,10 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
   hipStream_t s = (hipStream_t)stream;
   if (h->host.simple_theta) {
     DISPATCH_ENV(h->host.cfg.env_type,
-                 hipLaunchKernelGGL((rollout_kernel<E, false>), dim3(grid_for(h->n)), dim3(kBlock), (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal), s, h->dev, actions_dev, k_steps, o));
+                 hipLaunchKernelGGL((rollout_kernel<E, false>), dim3(grid_for(h->n)), dim3(kBlock), (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp), s, h->dev, actions_dev, k_steps, o));
   } else {
     DISPATCH_ENV(h->host.cfg.env_type,
-                 hipLaunchKernelGGL((rollout_kernel<E, true>), dim3(grid_for(h->n)), dim3(kBlock), (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal), s, h->dev, actions_dev, k_steps, o));
+                 hipLaunchKernelGGL((rollout_kernel<E, true>), dim3(grid_for(h->n)), dim3(kBlock), (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp), s, h->dev, actions_dev, k_steps, o));
   }
   HIP_TRY(hipGetLastError());
   return NSG_OK;
@@ -331,7 +347,7 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
     group_lds = 0;
     for (int k = 0; k < n_handles; k++) {
       all_simple &= hs[k]->host.simple_theta;
-      const int l = lds_bytes_for(hs[k]->host.table_bytes, hs[k]->host.uses_normal);
+      const int l = lds_bytes_for(hs[k]->host.table_bytes, hs[k]->host.uses_normal, hs[k]->host.uses_exp);
       if (l > group_lds) group_lds = l;
     }
   }
@@ -391,7 +407,7 @@ int nsg_theta_trace(nsg_handle* h, int32_t p, int32_t n, int32_t t0, int32_t T, 
   if (h->host.cfg.params[p].uses_rng && !rng_state) return fail(NSG_EINVAL, "rng_state required for a stochastic update fn");
   if (!h->bound) HIP_TRY(hipMemcpy(h->dev, &h->host, sizeof(Segment), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(theta_trace_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock),
-                     (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal), (hipStream_t)stream, h->dev, p, n, t0, T,
+                     (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp), (hipStream_t)stream, h->dev, p, n, t0, T,
                      theta0, rng_state, theta_out, fired_out, delta_out);
   HIP_TRY(hipGetLastError());
   return NSG_OK;

@@ -114,35 +114,54 @@ class CustomScheduler(Scheduler):
 
 
 class _StochasticScheduler(Scheduler):
-    """RandomScheduler / DecayingProbabilityScheduler / MemorylessScheduler
-    (ns_gym/schedulers.py:9-28,92-116,143-177) own a PCG64 stream; SURVEY §8(f) rank 3."""
+    """Schedulers that own a NumPy-compatible PCG64 stream (`self.rng` in the reference).  The stream
+    is part of the wrapper's deep-copied initial params: a non-persistent reset rewinds it, and
+    `reset(seed=...)` never re-seeds it (ns_gym/base.py:151-158,381-384)."""
 
-    def _compile(self, tables, horizon):
-        raise NotImplementedError(
-            f"{type(self).__name__}: stochastic schedulers are not fused into the kernel yet"
-        )
+    seed_value = None
+
+    def _seed_fields(self):
+        return {"has_sched_seed": 1, "sched_seed": int(self.seed_value)} if self.seed_value is not None else {}
 
 
 class RandomScheduler(_StochasticScheduler):
+    """Fires with a fixed probability at every step in range (ns_gym/schedulers.py:9-28)."""
+
     def __init__(self, probability: float = 0.5, start=0, end=np.inf, seed=None) -> None:
         super().__init__(start, end)
         self.probability = probability
         self.seed_value = seed
 
+    def _compile(self, tables, horizon):
+        return {"sched_kind": A.SCHED_RANDOM, "sched_p0": float(self.probability), **self._seed_fields(), **self._range()}
+
 
 class DecayingProbabilityScheduler(_StochasticScheduler):
+    """Fires with probability p0·exp(−λt) (ns_gym/schedulers.py:143-177)."""
+
     def __init__(self, initial_probability: float, decay_rate: float, start=0, end=np.inf, seed=None) -> None:
         super().__init__(start, end)
         self.initial_probability = initial_probability
         self.decay_rate = decay_rate
         self.seed_value = seed
 
+    def _compile(self, tables, horizon):
+        return {"sched_kind": A.SCHED_DECAYING, "sched_p0": float(self.initial_probability),
+                "sched_p1": float(self.decay_rate), **self._seed_fields(), **self._range()}
+
 
 class MemorylessScheduler(_StochasticScheduler):
+    """Geometric inter-event times (ns_gym/schedulers.py:92-116)."""
+
     def __init__(self, p: float, start=0, end=np.inf, seed=None) -> None:
         super().__init__(start, end)
         self.p = p
         self.seed_value = seed
+
+    def _compile(self, tables, horizon):
+        if not (0.0 < float(self.p) <= 1.0):
+            raise ValueError("MemorylessScheduler: p must be in (0, 1]")
+        return {"sched_kind": A.SCHED_MEMORYLESS, "sched_p0": float(self.p), **self._seed_fields(), **self._range()}
 
 
 __all__ = [

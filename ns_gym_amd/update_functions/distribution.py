@@ -128,12 +128,19 @@ class _NotFusedYet(UpdateDistributionFn):
         raise NotImplementedError(f"{type(self).__name__} is not fused into the kernel yet (SURVEY §8(f) rank 3)")
 
 
-class RandomCategorical(_NotFusedYet):
-    """rng.dirichlet(ones(n)) (distribution.py:11-38)."""
+class RandomCategorical(UpdateDistributionFn):
+    """A fresh Dirichlet(1,…,1) sample on every fire: `list(rng.dirichlet(np.ones(n)))`
+    (distribution.py:11-38); owns a PCG64 stream like the reference's `self.rng`."""
 
     def __init__(self, scheduler: Scheduler, seed=None) -> None:
         super().__init__(scheduler)
         self.seed_value = seed
+
+    def _compile(self, tables):
+        d = {"upd_kind": A.UPD_D_RANDOMCAT, "uses_rng": 1}
+        if self.seed_value is not None:
+            d.update(has_fn_seed=1, fn_seed=int(self.seed_value))
+        return d
 
 
 class LCBoundedDistrubutionUpdate(_NotFusedYet):

@@ -137,6 +137,35 @@ static double pcg_std_normal(pcg64* g) {
 }
 static double pcg_normal(pcg64* g, double loc, double scale) { return loc + scale * pcg_std_normal(g); }
 
+/* numpy random_standard_exponential (256-layer ziggurat) [UPSTREAM distributions.c] */
+#define ZIGE_R 7.69711747013104972
+static double pcg_std_exponential(pcg64* g) {
+  for (;;) {
+    uint64_t ri = pcg_next64(g);
+    ri >>= 3;
+    int idx = (int)(ri & 0xFF);
+    ri >>= 8;
+    double x = (double)ri * u2d(NSG_ZIGE_WE_BITS[idx]);
+    if (ri < NSG_ZIGE_KE[idx]) return x; /* 98.9 % */
+    if (idx == 0) return ZIGE_R - log1p(-pcg_double(g));
+    double f1 = u2d(NSG_ZIGE_FE_BITS[idx - 1]), f0 = u2d(NSG_ZIGE_FE_BITS[idx]);
+    if ((f1 - f0) * pcg_double(g) + f0 < exp(-x)) return x;
+  }
+}
+/* numpy random_geometric: search for p >= 1/3, inversion otherwise */
+static int64_t pcg_geometric(pcg64* g, double p) {
+  if (p >= 0.333333333333333333333333) {
+    int64_t X = 1;
+    double sum = p, prod = p, q = 1.0 - p;
+    double U = pcg_double(g);
+    while (U > sum) { prod *= q; sum += prod; X++; }
+    return X;
+  }
+  double z = ceil(-pcg_std_exponential(g) / log1p(-p));
+  if (z >= 9.223372036854776e+18) return INT64_MAX;
+  return (int64_t)z;
+}
+
 /* streams are stored as 32-byte records [N][4]: state_hi, state_lo, inc_hi, inc_lo */
 static void rng_load(const uint64_t* base, int64_t N, int64_t i, pcg64* r) {
   (void)N;
@@ -168,6 +197,51 @@ static int sched_fire(const nsg_param_cfg* pc, const uint8_t* tables, int t) {
     }
     default: return 0;
   }
+}
+
+static int sched_is_stochastic(int k) { return k == NSG_SCHED_RANDOM || k == NSG_SCHED_DECAYING || k == NSG_SCHED_MEMORYLESS; }
+
+/* construction-time state of a stochastic scheduler: rng = default_rng(seed) (+ the ctor's first
+ * geometric draw for Memoryless, schedulers.py:107-108).  seed=None -> a fixed per-env stream. */
+static void sched_construct(const nsg_param_cfg* pc, int p, int64_t i, pcg64* r, int32_t* next) {
+  if (pc->has_sched_seed) pcg_seed(r, pc->sched_seed, -1);
+  else pcg_seed(r, (uint64_t)i, 2000 + p);
+  *next = 0;
+  if (pc->sched_kind == NSG_SCHED_MEMORYLESS) {
+    int64_t g = pcg_geometric(r, pc->sched_p0);
+    *next = g > 0x7fffffff ? 0x7fffffff : (int32_t)g;
+  }
+}
+
+/* Scheduler.__call__ for the stochastic kinds: draws only when start <= t <= end */
+static int sched_fire_stoch(const nsg_param_cfg* pc, int t, pcg64* r, int32_t* next) {
+  double td = (double)t;
+  if (!(pc->sched_start <= td && td <= pc->sched_end)) return 0;
+  switch (pc->sched_kind) {
+    case NSG_SCHED_RANDOM: return pcg_double(r) < pc->sched_p0;                               /* schedulers.py:27-28 */
+    case NSG_SCHED_DECAYING: return pcg_double(r) < pc->sched_p0 * exp(-pc->sched_p1 * td);   /* :175-177 */
+    case NSG_SCHED_MEMORYLESS:                                                               /* :110-116 */
+      if (t == *next) {
+        int64_t g = pcg_geometric(r, pc->sched_p0) + t;
+        *next = g > 0x7fffffff ? 0x7fffffff : (int32_t)g;
+        return 1;
+      }
+      return 0;
+    default: return 0;
+  }
+}
+
+/* fire predicate of param p of env i, advancing the scheduler's own state when it has one */
+static int fire_param(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N, int64_t i, int p, int t) {
+  const nsg_param_cfg* pc = &cfg->params[p];
+  if (!sched_is_stochastic(pc->sched_kind)) return sched_fire(pc, tables, t);
+  pcg64 r;
+  rng_load(b->rng_sched + (int64_t)p * 4 * N, N, i, &r);
+  int32_t next = b->sched_next[p * N + i];
+  int f = sched_fire_stoch(pc, t, &r, &next);
+  rng_store(b->rng_sched + (int64_t)p * 4 * N, N, i, &r);
+  b->sched_next[p * N + i] = next;
+  return f;
 }
 
 /* ------------------------------------------------------------------ scalar update fns */
@@ -259,7 +333,7 @@ static double w1_n(const double* a, const double* b, int n) {
 }
 
 static void upd_dist(const nsg_param_cfg* pc, const uint8_t* tables, const double* p, int n, int t, int32_t* cursor,
-                     double* q) {
+                     pcg64* rng, double* q) {
   const double* u = pc->u;
   double td = (double)t;
   for (int k = 0; k < n; k++) q[k] = p[k];
@@ -297,6 +371,14 @@ static void upd_dist(const nsg_param_cfg* pc, const uint8_t* tables, const doubl
     case NSG_UPD_D_TARGETREV:                          /* :289-293 */
       for (int k = 0; k < n; k++) q[k] = p[k] + u[n] * (u[k] - p[k]);
       break;
+    case NSG_UPD_D_RANDOMCAT: {                        /* :38  rng.dirichlet(np.ones(n)): numpy draws n
+         standard gammas of shape 1.0 (== standard exponentials), then val *= 1/acc [UPSTREAM _generator.pyx] */
+      double acc = 0.0;
+      for (int k = 0; k < n; k++) { q[k] = pcg_std_exponential(rng); acc = acc + q[k]; }
+      double invacc = 1.0 / acc;
+      for (int k = 0; k < n; k++) q[k] = q[k] * invacc;
+      break;
+    }
     case NSG_UPD_D_LERP: {                             /* :326-331 */
       double frac = td / u[2 * n];
       if (!(frac < 1.0)) frac = 1.0;
@@ -580,6 +662,13 @@ static void reset_one(const nsg_config* cfg, const uint8_t* tables, const nsg_bu
       } else
         b->theta[p * N + i] = cfg->base_theta[pc->theta_slot];
       if (b->cursor) b->cursor[p * N + i] = 0;
+      if (sched_is_stochastic(pc->sched_kind)) { /* the scheduler is rewound with the rest of init_initial_params */
+        pcg64 sr;
+        int32_t nx;
+        sched_construct(pc, p, i, &sr, &nx);
+        rng_store(b->rng_sched + (int64_t)p * 4 * N, N, i, &sr);
+        b->sched_next[p * N + i] = nx;
+      }
     }
     if (pc->uses_rng && has_seed) { /* base.py:386-388,412-421: SeedSequence(seed).spawn(P)[j] */
       pcg64 r;
@@ -615,6 +704,14 @@ int orc_init_streams(const nsg_config* cfg, const nsg_buffers* b, int64_t N, con
     }
   for (int p = 0; p < cfg->n_params; p++) {
     const nsg_param_cfg* pc = &cfg->params[p];
+    if (sched_is_stochastic(pc->sched_kind))
+      for (int64_t i = 0; i < N; i++) {
+        pcg64 sr;
+        int32_t nx;
+        sched_construct(pc, p, i, &sr, &nx);
+        rng_store(b->rng_sched + (int64_t)p * 4 * N, N, i, &sr);
+        b->sched_next[p * N + i] = nx;
+      }
     if (!pc->uses_rng) continue;
     for (int64_t i = 0; i < N; i++) {
       pcg64 r;
@@ -665,10 +762,13 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
       const nsg_param_cfg* pc = &cfg->params[p];
       double pp[NSG_ND_MAX], q[NSG_ND_MAX];
       for (int k = 0; k < nd; k++) pp[k] = b->theta[(p * nd + k) * N + i];
-      int fired = theta_live && sched_fire(pc, tables, t); /* frozen planning copy: toy_text.py:170-176,354-360,636-645 */
+      int fired = theta_live && fire_param(cfg, tables, b, N, i, p, t); /* frozen planning copy: toy_text.py:170-176,354-360,636-645 */
       double delta = 0.0;
       if (fired) {
-        upd_dist(pc, tables, pp, nd, t, b->cursor ? &b->cursor[p * N + i] : NULL, q);
+        pcg64 ur;
+        if (pc->uses_rng) rng_load(b->rng_upd + (int64_t)p * 4 * N, N, i, &ur);
+        upd_dist(pc, tables, pp, nd, t, b->cursor ? &b->cursor[p * N + i] : NULL, pc->uses_rng ? &ur : NULL, q);
+        if (pc->uses_rng) rng_store(b->rng_upd + (int64_t)p * 4 * N, N, i, &ur);
         delta = w1_n(pp, q, nd); /* base.py:192-203 */
         for (int k = 0; k < nd; k++) {
           b->theta[(p * nd + k) * N + i] = q[k];
@@ -768,7 +868,7 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
       const nsg_param_cfg* pc = &cfg->params[p];
       int k = pc->theta_slot;
       tuned |= 1u << k;
-      if (theta_live && sched_fire(pc, tables, t)) { /* frozen planning copy: classic_control.py:70-75 */
+      if (theta_live && fire_param(cfg, tables, b, N, i, p, t)) { /* frozen planning copy: classic_control.py:70-75 */
         pcg64 r;
         if (pc->uses_rng) rng_load(b->rng_upd + (int64_t)p * 4 * N, N, i, &r);
         nv[k] = upd_scalar(pc, tables, cur[k], t, pc->uses_rng ? &r : NULL, b->cursor ? &b->cursor[p * N + i] : NULL);
@@ -885,6 +985,10 @@ int orc_fork(const nsg_config* scfg, const nsg_buffers* sb, const nsg_config* dc
     }
     for (int p = 0; p < P; p++) {
       if (db->cursor && sb->cursor) db->cursor[p * N + i] = sb->cursor[p * N + i]; /* deepcopy(tunable_params) */
+      if (sched_is_stochastic(scfg->params[p].sched_kind)) { /* scheduler state is copied, not re-seeded */
+        for (int k = 0; k < 4; k++) db->rng_sched[((int64_t)p * N + i) * 4 + k] = sb->rng_sched[((int64_t)p * N + i) * 4 + k];
+        db->sched_next[p * N + i] = sb->sched_next[p * N + i];
+      }
       db->env_change[p * N + i] = sb->env_change[p * N + i];
       db->delta_change[p * N + i] = sb->delta_change[p * N + i];
       if (scfg->params[p].uses_rng) { /* _reseed_planning_env_rngs: fresh entropy */
@@ -953,19 +1057,21 @@ int orc_theta_trace(const nsg_config* cfg, const uint8_t* tables, int p, int n, 
   for (int i = 0; i < n; i++) {
     pcg64 r;
     if (pc->uses_rng && rng_state) rng_load(rng_state, n, i, &r);
-    int32_t cursor = 0;
+    int32_t cursor = 0, snext = 0;
+    pcg64 sr;
+    if (sched_is_stochastic(pc->sched_kind)) sched_construct(pc, p, i, &sr, &snext);
     const int nd = n_dist(cfg->env_type);
     double th[NSG_ND_MAX] = {0, 0, 0, 0};
     if (dist) for (int c = 0; c < nd; c++) th[c] = theta0[nd * i + c];
     else th[0] = theta0[i];
     for (int k = 0; k < T; k++) {
       int t = t0 + k;
-      int fired = sched_fire(pc, tables, t);
+      int fired = sched_is_stochastic(pc->sched_kind) ? sched_fire_stoch(pc, t, &sr, &snext) : sched_fire(pc, tables, t);
       double delta = 0.0;
       if (fired) {
         if (dist) {
           double q[NSG_ND_MAX];
-          upd_dist(pc, tables, th, nd, t, &cursor, q);
+          upd_dist(pc, tables, th, nd, t, &cursor, pc->uses_rng ? &r : NULL, q);
           delta = w1_n(th, q, nd);
           for (int c = 0; c < nd; c++) th[c] = q[c];
         } else {
@@ -995,6 +1101,31 @@ int orc_rng_fill(int kind, const uint64_t* seeds, int n, int spawn_key, int coun
       else if (kind == 1) ((double*)out)[(int64_t)k * n + i] = pcg_double(&r);
       else ((double*)out)[(int64_t)k * n + i] = pcg_std_normal(&r);
     }
+  }
+  return 0;
+}
+
+/* extra stream KATs: kind 3 = standard_exponential; orc_geometric / orc_dirichlet below */
+int orc_exponential(uint64_t seed, int count, double* out) {
+  pcg64 r;
+  pcg_seed(&r, seed, -1);
+  for (int k = 0; k < count; k++) out[k] = pcg_std_exponential(&r);
+  return 0;
+}
+int orc_geometric(uint64_t seed, double p, int count, int64_t* out) {
+  pcg64 r;
+  pcg_seed(&r, seed, -1);
+  for (int k = 0; k < count; k++) out[k] = pcg_geometric(&r, p);
+  return 0;
+}
+int orc_dirichlet_ones(uint64_t seed, int n, int count, double* out) {
+  pcg64 r;
+  pcg_seed(&r, seed, -1);
+  for (int c = 0; c < count; c++) {
+    double acc = 0.0;
+    for (int k = 0; k < n; k++) { out[c * n + k] = pcg_std_exponential(&r); acc = acc + out[c * n + k]; }
+    double inv = 1.0 / acc;
+    for (int k = 0; k < n; k++) out[c * n + k] = out[c * n + k] * inv;
   }
   return 0;
 }

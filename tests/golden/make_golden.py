@@ -125,6 +125,13 @@ SCHEDULER_SPECS = {
     "burst_1_4_s3": ["BurstScheduler", {"on_duration": 1, "off_duration": 4, "start": 3, "end": 40}],
     "window": ["WindowScheduler", {"windows": {"__tuples__": [[2, 4], [10, 10], [30, 35]]}}],
     "window_s3": ["WindowScheduler", {"windows": {"__tuples__": [[0, 5], [20, 60]]}, "start": 3, "end": 50}],
+    # stochastic schedulers (own PCG64 stream; schedulers.py:9-28,92-116,143-177)
+    "random_p3": ["RandomScheduler", {"probability": 0.3, "seed": 5}],
+    "random_p5_s3_e40": ["RandomScheduler", {"probability": 0.5, "start": 3, "end": 40, "seed": 1}],
+    "decaying": ["DecayingProbabilityScheduler", {"initial_probability": 0.9, "decay_rate": 0.05, "seed": 2}],
+    "memoryless_p5": ["MemorylessScheduler", {"p": 0.5, "seed": 3}],      # geometric: search branch (p >= 1/3)
+    "memoryless_p1": ["MemorylessScheduler", {"p": 0.1, "seed": 4}],      # geometric: inversion branch
+    "memoryless_p02_s5": ["MemorylessScheduler", {"p": 0.02, "start": 5, "seed": 6}],
 }
 
 SCALAR_UPDATE_SPECS = {
@@ -161,6 +168,7 @@ DIST_UPDATE_SPECS = {
     "d_targetrev": ["TargetReversion", {"target": [0.2, 0.5, 0.3], "theta": 0.1}],
     "d_lerp": ["DistributionLinearInterpolation",
                {"start_dist": [1.0, 0.0, 0.0], "end_dist": [0.4, 0.3, 0.3], "T": 25}],
+    "d_randomcat": ["RandomCategorical", {"seed": 9}],
 }
 
 
@@ -179,6 +187,9 @@ def gen_update_traces(S, U, T=64):
     for uname in SCALAR_UPDATE_SPECS:
         for sname in ("continuous", "periodic3", "burst_3_2", "discrete", "window_s3"):
             combos.append((uname, sname))
+    for uname in ("increment", "randomwalk", "cyclic"):
+        for sname in ("random_p3", "decaying", "memoryless_p5", "memoryless_p1"):
+            combos.append((uname, sname))
     for uname, sname in combos:
         fn = build_fn(S, U, {"scheduler": SCHEDULER_SPECS[sname], "update": SCALAR_UPDATE_SPECS[uname]})
         theta = 9.8
@@ -191,7 +202,7 @@ def gen_update_traces(S, U, T=64):
         out[key + "__fired"] = np.array(fl, dtype=np.uint8)
         out[key + "__delta"] = np.array(de, dtype=np.float64)
     for uname in DIST_UPDATE_SPECS:
-        for sname in ("continuous", "periodic3", "discrete50", "window"):
+        for sname in ("continuous", "periodic3", "discrete50", "window") + (("random_p3", "memoryless_p1") if uname == "d_randomcat" else ()):
             fn = build_fn(S, U, {"scheduler": SCHEDULER_SPECS[sname], "update": DIST_UPDATE_SPECS[uname]})
             p = [1.0, 0.0, 0.0] if uname != "d_increment" else [0.4, 0.3, 0.3]
             th, fl, de = [], [], []
@@ -202,6 +213,15 @@ def gen_update_traces(S, U, T=64):
             out[key + "__theta"] = np.array(th, dtype=np.float64)
             out[key + "__fired"] = np.array(fl, dtype=np.uint8)
             out[key + "__delta"] = np.array(de, dtype=np.float64)
+    # 4-point support (CliffWalking): Dirichlet(1,1,1,1) and W1 over 4 atoms
+    fn = build_fn(S, U, {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["RandomCategorical", {"seed": 21}]})
+    p = [1.0, 0.0, 0.0, 0.0]
+    th, fl, de = [], [], []
+    for t in range(T):
+        p, f, d = fn(p, t)
+        th.append([float(x) for x in p]); fl.append(int(f)); de.append(float(d))
+    out["d4_randomcat__periodic3__theta"] = np.array(th); out["d4_randomcat__periodic3__fired"] = np.array(fl, dtype=np.uint8)
+    out["d4_randomcat__periodic3__delta"] = np.array(de)
     return out
 
 
@@ -250,6 +270,27 @@ TRAJ_SPECS = {
         "params": {"masspole": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["IncrementUpdate", {"k": 0.02}]},
                    "gravity": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["RandomWalk", {"sigma": 0.3}]}},
         "flags": {"change_notification": True, "delta_change_notification": True, "persistent_params": True},
+    },
+    # stochastic schedulers under the wrapper: the scheduler (and its stream) is part of the deep-copied
+    # init_initial_params, so a non-persistent reset REWINDS it (base.py:381-384) while fn.rng continues
+    "cartpole_random_sched": {
+        "env_id": "CartPole-v1", "T": 220, "seeds": [60, 61, 62, 63],
+        "params": {"gravity": {"scheduler": SCHEDULER_SPECS["random_p3"], "update": ["IncrementUpdate", {"k": 0.3}]},
+                   "masspole": {"scheduler": SCHEDULER_SPECS["memoryless_p1"], "update": ["RandomWalk", {"sigma": 0.01}]},
+                   "length": {"scheduler": SCHEDULER_SPECS["decaying"], "update": ["IncrementUpdate", {"k": 0.01}]}},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "cartpole_random_sched_persistent": {
+        "env_id": "CartPole-v1", "T": 220, "seeds": [70, 71, 72],
+        "params": {"gravity": {"scheduler": SCHEDULER_SPECS["random_p3"], "update": ["IncrementUpdate", {"k": 0.3}]},
+                   "force_mag": {"scheduler": SCHEDULER_SPECS["memoryless_p5"], "update": ["IncrementUpdate", {"k": 0.2}]}},
+        "flags": {"change_notification": True, "delta_change_notification": True, "persistent_params": True},
+    },
+    "frozenlake_randomcat": {
+        "env_id": "FrozenLake-v1", "make_kwargs": {"map_name": "8x8", "is_slippery": False}, "T": 240, "seeds": [80, 81, 82, 83],
+        "params": {"P": {"scheduler": SCHEDULER_SPECS["memoryless_p1"], "update": ["RandomCategorical", {}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [1.0, 0.0, 0.0]},
+        "flags": {"change_notification": True, "delta_change_notification": True},
     },
     # C4 pieces
     "c4_pendulum_m_inc": {
@@ -721,6 +762,17 @@ def gen_numpy_streams():
     out["normal_long_sum"] = np.array([z.sum(), np.abs(z).max(), z[-1]], dtype=np.float64)
     out["normal_long_tail_idx"] = np.flatnonzero(np.abs(z) > 3.6541528853610088)[:64].astype(np.int64)
     out["normal_long_tail_val"] = z[out["normal_long_tail_idx"]]
+    # exponential ziggurat, geometric (both branches), Dirichlet(1,..,1)
+    out["exponential"] = np.array([np.random.default_rng(s).standard_exponential(400) for s in (0, 7, 99)])
+    g = np.random.default_rng(2025)
+    ex = g.standard_exponential(1_000_000)
+    out["exponential_long"] = np.array([ex.sum(), ex.max(), ex[-1]])
+    out["geometric_p5"] = np.array([np.random.default_rng(s).geometric(0.5, size=200) for s in (0, 7)], dtype=np.int64)
+    out["geometric_p1"] = np.array([np.random.default_rng(s).geometric(0.1, size=200) for s in (0, 7)], dtype=np.int64)
+    out["geometric_p001"] = np.array([np.random.default_rng(s).geometric(0.001, size=200) for s in (0, 7)], dtype=np.int64)
+    out["dirichlet3"] = np.array([np.random.default_rng(11).dirichlet(np.ones(3)) for _ in range(1)] +
+                                 [x for x in np.random.default_rng(12).dirichlet(np.ones(3), size=50)])
+    out["dirichlet4"] = np.random.default_rng(13).dirichlet(np.ones(4), size=50)
     # categorical draws (gymnasium categorical_sample over [.6,.2,.2]) from seed 0
     g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(0)))
     cs = np.cumsum(np.array([0.6, 0.2, 0.2]))

@@ -123,8 +123,12 @@ def test_value_list_update_fns_and_unsupported_kinds():
     p0, p1 = cfg.params[0], cfg.params[1]
     assert list(vals[p0.val_tab_off:p0.val_tab_off + p0.val_tab_len]) == [1.5, 0.7]
     assert list(vals[p1.val_tab_off:p1.val_tab_off + p1.val_tab_len]) == [0.01, 0.03]
+    cfg, _, _, _ = compile_config(make("CartPole-v1"), {"gravity": IncrementUpdate(RandomScheduler(0.5, start=2, seed=9), 1.0)})
+    pc = cfg.params[0]
+    assert (pc.sched_kind, pc.sched_p0, pc.has_sched_seed, pc.sched_seed, pc.sched_start) == (A.SCHED_RANDOM, 0.5, 1, 9, 2.0)
+    from ns_gym_amd.update_functions import LCBoundedDistrubutionUpdate
     with pytest.raises(NotImplementedError):
-        compile_config(make("CartPole-v1"), {"gravity": IncrementUpdate(RandomScheduler(0.5), 1.0)})
+        compile_config(make("FrozenLake-v1"), {"P": LCBoundedDistrubutionUpdate(ContinuousScheduler(), L=0.1)})
     assert isinstance(ContinuousScheduler(), Scheduler)
 
 

@@ -83,3 +83,27 @@ def test_categorical_seed0(g):
     idx = [int(np.argmax(cs > r)) for r in u[:, 0]]
     np.testing.assert_array_equal(idx, g["categorical_seed0"])
     assert idx[:10] == [1, 0, 0, 0, 2, 2, 1, 1, 0, 2]
+
+
+def test_exponential_geometric_dirichlet(g):
+    """Streams behind MemorylessScheduler (rng.geometric, schedulers.py:108,112) and RandomCategorical
+    (rng.dirichlet, distribution.py:38): bit-exact with NumPy incl. the ziggurat wedge/tail paths."""
+    import ctypes as C
+
+    L = O.lib()
+    for j, s in enumerate((0, 7, 99)):
+        out = np.zeros(400)
+        L.orc_exponential(C.c_uint64(s), 400, out.ctypes.data_as(C.c_void_p))
+        np.testing.assert_array_equal(out, g["exponential"][j])
+    out = np.zeros(1_000_000)
+    L.orc_exponential(C.c_uint64(2025), out.size, out.ctypes.data_as(C.c_void_p))
+    assert out.sum() == g["exponential_long"][0] and out.max() == g["exponential_long"][1] and out[-1] == g["exponential_long"][2]
+    for name, p in (("geometric_p5", 0.5), ("geometric_p1", 0.1), ("geometric_p001", 0.001)):
+        for j, s in enumerate((0, 7)):
+            o = np.zeros(200, dtype=np.int64)
+            L.orc_geometric(C.c_uint64(s), C.c_double(p), 200, o.ctypes.data_as(C.c_void_p))
+            np.testing.assert_array_equal(o, g[name][j])
+    for n, seed, key, sl in ((3, 12, "dirichlet3", slice(1, None)), (4, 13, "dirichlet4", slice(None))):
+        o = np.zeros((50, n))
+        L.orc_dirichlet_ones(C.c_uint64(seed), n, 50, o.ctypes.data_as(C.c_void_p))
+        np.testing.assert_array_equal(o, g[key][sl])

@@ -28,18 +28,19 @@ _TRACE_KEYS = sorted({k.rsplit("__", 1)[0] for k in load("update_traces.npz").fi
 def test_update_trace(key):
     g = load("update_traces.npz")
     uname, sname = key.split("__")
-    dist = uname in DIST
-    fn = build_fn({"scheduler": SCHED[sname], "update": (DIST if dist else SCALAR)[uname]})
+    dist = uname in DIST or uname == "d4_randomcat"
+    upd = ["RandomCategorical", {"seed": 21}] if uname == "d4_randomcat" else (DIST if dist else SCALAR)[uname]
+    fn = build_fn({"scheduler": SCHED[sname], "update": upd})
     T = g[key + "__fired"].shape[0]
     if dist:
-        th0 = [0.4, 0.3, 0.3] if uname == "d_increment" else [1.0, 0.0, 0.0]
+        th0 = [0.4, 0.3, 0.3] if uname == "d_increment" else [1.0, 0.0, 0.0, 0.0] if uname == "d4_randomcat" else [1.0, 0.0, 0.0]
     else:
         th0 = 9.8
     th, fired, delta = O.theta_trace(fn, th0, t0=0, T=T)
     np.testing.assert_array_equal(fired[:, 0], g[key + "__fired"])
     want = g[key + "__theta"]
     got = th[:, :, 0] if dist else th[:, 0]
-    transcendental = uname in ("expdecay", "oscillating", "sigmoid")
+    transcendental = uname in ("expdecay", "oscillating", "sigmoid") or sname == "decaying"
     if transcendental:   # libm vs NumPy's SIMD exp/sin may differ in the last ulp
         np.testing.assert_allclose(got, want, rtol=1e-13)
         np.testing.assert_allclose(delta[:, 0], g[key + "__delta"], rtol=1e-9, atol=1e-13)
