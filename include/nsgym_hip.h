@@ -96,7 +96,9 @@ enum {
   NSG_UPD_D_UNIFORMDRIFT = 37,/* :234-261 u0=rate                 */
   NSG_UPD_D_TARGETREV = 38,   /* :264-293 u[0..n)=target u[n]=theta */
   NSG_UPD_D_LERP = 39,        /* :296-331 u[0..n)=start u[n..2n)=end u[2n]=T */
-  NSG_UPD_D_RANDOMCAT = 40    /* :11-38   rng.dirichlet(ones(n)): n standard exponentials, normalised */
+  NSG_UPD_D_RANDOMCAT = 40,   /* :11-38   rng.dirichlet(ones(n)): n standard exponentials, normalised */
+  NSG_UPD_D_LCBOUNDED = 41    /* :133-183 rejection-sample the inner update (u1: 0 = RandomCategorical, 1 = NoUpdate)
+                                 until W1 <= u0 * |t - prev_time|, at most 1e5 tries; cursor row = prev_time + 1 */
 };
 
 /* flags of nsg_config.flags (constructor kwargs of NSWrapper, ns_gym/base.py:222-232) */

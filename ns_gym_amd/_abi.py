@@ -24,7 +24,7 @@ N_DIST = {ENV_FROZENLAKE: 3, ENV_CLIFFWALKING: 4, ENV_BRIDGE: 3}
  UPD_RW_DRIFT_TREND, UPD_OU, UPD_BOUNDED_RW) = range(17)
 # distribution update fns
 (UPD_D_INCREMENT, UPD_D_DECREMENT, UPD_D_STEPWISE, UPD_D_CYCLIC, UPD_D_NOUPDATE, UPD_D_UNIFORMDRIFT,
- UPD_D_TARGETREV, UPD_D_LERP, UPD_D_RANDOMCAT) = range(32, 41)
+ UPD_D_TARGETREV, UPD_D_LERP, UPD_D_RANDOMCAT, UPD_D_LCBOUNDED) = range(32, 42)
 
 F_CHANGE_NOTIFICATION = 0x1
 F_DELTA_NOTIFICATION = 0x2

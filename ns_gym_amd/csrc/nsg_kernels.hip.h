@@ -523,7 +523,7 @@ __device__ __forceinline__ void step_grid(const Segment& sg, const Tables& tb, c
       if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, i, ur);
       upd_dist<ND, FULL>(pc, tb, zg, pp, t, cursor, ur, q);
       if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, i, ur);
-      if (has_cur) b.cursor[(int64_t)p * N + i] = cursor;
+      if (has_cur && pc.upd_kind != NSG_UPD_D_LCBOUNDED) b.cursor[(int64_t)p * N + i] = cursor;
       delta = w1_n<ND>(pp, q);  // base.py:192-203
 #pragma unroll
       for (int k = 0; k < ND; k++) {
@@ -544,11 +544,19 @@ __device__ __forceinline__ void step_grid(const Segment& sg, const Tables& tb, c
         have_table = true;
       }
     }
+    if (pc.upd_kind == NSG_UPD_D_LCBOUNDED && do_step && theta_live)
+      b.cursor[(int64_t)p * N + i] = t + 1;  // UpdateFn.__call__ records prev_time = t, fired or not (base.py:143-148)
     if (do_reset && !persistent) {  // toy_text.py:206-209, 394-399, 657-666 (the P TABLE is not restored)
       const double* ini = grid_initial(cfg, p);
 #pragma unroll
       for (int k = 0; k < ND; k++) b.theta[(int64_t)(p * ND + k) * N + i] = ini[k];
       if (upd_uses_cursor(pc.upd_kind)) b.cursor[(int64_t)p * N + i] = 0;
+      if (FULL && pc.upd_kind == NSG_UPD_D_LCBOUNDED && pc.uses_rng) {  // inner sampler rewound with the deepcopy
+        Pcg r;
+        if (pc.has_fn_seed) pcg_seed(r, pc.fn_seed, -1);
+        else pcg_seed(r, (uint64_t)i, 1000 + p);
+        pcg_store_all(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
+      }
     }
     if (active) {
       out.env_change[(int64_t)p * N + i] = fired ? 1 : 0;
@@ -770,7 +778,14 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
           b.sched_next[(int64_t)p * N + i] = nx;
         }
       }
-      if (pc.uses_rng && seeds) {  // SeedSequence(seed).spawn(P)[rng_child], base.py:412-421
+      if (pc.upd_kind == NSG_UPD_D_LCBOUNDED) {  // inner sampler: rewound, never re-seeded by reset(seed)
+        if (pc.uses_rng && !persistent) {
+          Pcg r;
+          if (pc.has_fn_seed) pcg_seed(r, pc.fn_seed, -1);
+          else pcg_seed(r, (uint64_t)i, 1000 + p);
+          pcg_store_all(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
+        }
+      } else if (pc.uses_rng && seeds) {  // SeedSequence(seed).spawn(P)[rng_child], base.py:412-421
         Pcg r;
         pcg_seed(r, seeds[i], pc.rng_child);
         pcg_store_all(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
@@ -913,6 +928,7 @@ __global__ __launch_bounds__(kBlock) void theta_trace_kernel(const Segment* __re
         th[0] = nvv;
       }
     }
+    if (pc.upd_kind == NSG_UPD_D_LCBOUNDED) cursor = t + 1;
     if (dist) {
       for (int c = 0; c < nd; c++) theta_out[((int64_t)k * nd + c) * n + i] = th[c];
     } else {
@@ -1004,7 +1020,9 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
       }
       db.env_change[(int64_t)p * N + i] = sb.env_change[(int64_t)p * N + i];
       db.delta_change[(int64_t)p * N + i] = sb.delta_change[(int64_t)p * N + i];
-      if (cfg.params[p].uses_rng) {  // _reseed_planning_env_rngs (base.py:433-441): fresh entropy
+      if (cfg.params[p].uses_rng && cfg.params[p].upd_kind == NSG_UPD_D_LCBOUNDED) {  // inner rng: deep-copied
+        for (int k = 0; k < 4; k++) db.rng_upd[((int64_t)p * N + i) * 4 + k] = sb.rng_upd[((int64_t)p * N + i) * 4 + k];
+      } else if (cfg.params[p].uses_rng) {  // _reseed_planning_env_rngs (base.py:433-441): fresh entropy
         Pcg r;
         pcg_seed(r, entropy + (uint64_t)i, 7100 + p);
         pcg_store_all(db.rng_upd + (int64_t)p * 4 * N, N, i, r);

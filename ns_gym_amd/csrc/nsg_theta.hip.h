@@ -82,7 +82,7 @@ __device__ inline bool sched_fire_stoch(const nsg_param_cfg& pc, const ZigLds& z
 __host__ __device__ inline bool upd_kind_is_simple(int k) {
   return k == NSG_UPD_INCREMENT || k == NSG_UPD_DECREMENT || k == NSG_UPD_TREND || k == NSG_UPD_POLY ||
          k == NSG_UPD_GEOMETRIC || k == NSG_UPD_LERP || k == NSG_UPD_STEPWISE || k == NSG_UPD_CYCLIC ||
-         k == NSG_UPD_NOUPDATE || (k >= NSG_UPD_D_INCREMENT && k != NSG_UPD_D_RANDOMCAT);
+         k == NSG_UPD_NOUPDATE || (k >= NSG_UPD_D_INCREMENT && k != NSG_UPD_D_RANDOMCAT && k != NSG_UPD_D_LCBOUNDED);
 }
 
 // UpdateFn._update for the scalar classes.  `rng` is touched only by the stochastic kinds.
@@ -157,8 +157,9 @@ __device__ inline double upd_scalar(const nsg_param_cfg& pc, const Tables& tb, c
   return th;
 }
 
-__device__ __forceinline__ bool upd_uses_cursor(int kind) {
-  return kind == NSG_UPD_STEPWISE || kind == NSG_UPD_CYCLIC || kind == NSG_UPD_D_STEPWISE || kind == NSG_UPD_D_CYCLIC;
+__host__ __device__ __forceinline__ bool upd_uses_cursor(int kind) {
+  return kind == NSG_UPD_STEPWISE || kind == NSG_UPD_CYCLIC || kind == NSG_UPD_D_STEPWISE || kind == NSG_UPD_D_CYCLIC ||
+         kind == NSG_UPD_D_LCBOUNDED;  // LCBounded keeps prev_time + 1 in its cursor row
 }
 
 // 1-Wasserstein distance between two pmfs on {0..ND-1}: SciPy's _cdf_distance(p=1) with
@@ -235,6 +236,26 @@ __device__ inline void upd_dist(const nsg_param_cfg& pc, const Tables& tb, const
         const double invacc = 1.0 / acc;
 #pragma unroll
         for (int k = 0; k < ND; k++) q[k] = q[k] * invacc;
+      }
+      break;
+    }
+    case NSG_UPD_D_LCBOUNDED: {  // distribution.py:167-183; `cursor` holds prev_time + 1
+      if constexpr (FULL) {
+        const double d = u[0] * fabs(td - (double)(cursor - 1));
+        if (u[1] != 0.0) break;  // inner DistributionNoUpdate: W1 = 0 <= d, accepted at once
+        for (int tries = 0; tries < 100000; tries++) {  // max_trys = int(1e5); bounded, so the wave always drains
+          double cand[ND], acc = 0.0;
+#pragma unroll
+          for (int k = 0; k < ND; k++) { cand[k] = pcg_std_exponential(rng, zg); acc = acc + cand[k]; }
+          const double invacc = 1.0 / acc;
+#pragma unroll
+          for (int k = 0; k < ND; k++) cand[k] = cand[k] * invacc;
+          if (w1_n<ND>(p, cand) <= d) {
+#pragma unroll
+            for (int k = 0; k < ND; k++) q[k] = cand[k];
+            break;
+          }
+        }  // exhausted: the reference raises ValueError; here the distribution stays unchanged
       }
       break;
     }

@@ -67,7 +67,7 @@ int validate(const nsg_config* cfg, size_t table_bytes) {
     seen |= 1u << pc.theta_slot;
     const bool dist = pc.upd_kind >= NSG_UPD_D_INCREMENT;
     if (dist != fl) return fail(NSG_EINVAL, "param %d: update kind %d does not fit env type %d", p, pc.upd_kind, cfg->env_type);
-    if (dist ? pc.upd_kind > NSG_UPD_D_RANDOMCAT : (pc.upd_kind < 0 || pc.upd_kind > NSG_UPD_BOUNDED_RW))
+    if (dist ? pc.upd_kind > NSG_UPD_D_LCBOUNDED : (pc.upd_kind < 0 || pc.upd_kind > NSG_UPD_BOUNDED_RW))
       return fail(NSG_EINVAL, "param %d: unknown update kind %d", p, pc.upd_kind);
     switch (pc.sched_kind) {
       case NSG_SCHED_CONTINUOUS: break;
@@ -100,7 +100,7 @@ int validate(const nsg_config* cfg, size_t table_bytes) {
         return fail(NSG_EINVAL, "param %d: value table out of range", p);
       if ((k == NSG_UPD_CYCLIC || k == NSG_UPD_D_CYCLIC) && pc.val_tab_len == 0) return fail(NSG_EINVAL, "param %d: empty cyclic list", p);
     }
-    if (pc.uses_rng != ((upd_is_normal(k) || k == NSG_UPD_D_RANDOMCAT) ? 1 : 0)) return fail(NSG_EINVAL, "param %d: uses_rng does not match update kind %d", p, k);
+    if (k != NSG_UPD_D_LCBOUNDED && pc.uses_rng != ((upd_is_normal(k) || k == NSG_UPD_D_RANDOMCAT) ? 1 : 0)) return fail(NSG_EINVAL, "param %d: uses_rng does not match update kind %d", p, k);
   }
   return NSG_OK;
 }
@@ -137,7 +137,7 @@ int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
     any_rng |= cfg->params[p].uses_rng != 0;
     any_sched |= sched_is_stochastic(cfg->params[p].sched_kind);
     const int k = cfg->params[p].upd_kind;
-    any_cursor |= k == NSG_UPD_STEPWISE || k == NSG_UPD_CYCLIC || k == NSG_UPD_D_STEPWISE || k == NSG_UPD_D_CYCLIC;
+    any_cursor |= upd_uses_cursor(k);
   }
   out->n = n;
   out->phys_dim = kPhysDim[e];
@@ -214,7 +214,7 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
   for (int p = 0; p < cfg->n_params; p++) {
     const nsg_param_cfg& pc = cfg->params[p];
     if (upd_is_normal(pc.upd_kind)) h->host.uses_normal = 1;
-    if (pc.upd_kind == NSG_UPD_D_RANDOMCAT || pc.sched_kind == NSG_SCHED_MEMORYLESS) h->host.uses_exp = 1;
+    if (pc.upd_kind == NSG_UPD_D_RANDOMCAT || pc.upd_kind == NSG_UPD_D_LCBOUNDED || pc.sched_kind == NSG_SCHED_MEMORYLESS) h->host.uses_exp = 1;
     if (!upd_kind_is_simple(pc.upd_kind) || sched_is_stochastic(pc.sched_kind)) h->host.simple_theta = 0;
   }
   h->host.block_begin = 0;

@@ -150,7 +150,10 @@ def build_fn(fn_spec: dict):
     sname, skw = fn_spec["scheduler"]
     sched = getattr(S, sname)(**{k: _dec(v) for k, v in skw.items()})
     uname, ukw = fn_spec["update"]
-    return getattr(U, uname)(sched, **copy.deepcopy({k: _dec(v) for k, v in ukw.items()}))
+    kw = copy.deepcopy({k: _dec(v) for k, v in ukw.items()})
+    if "__inner_seed__" in kw:      # golden specs: the seed installed on LCBounded's inner sampler
+        kw["seed"] = kw.pop("__inner_seed__")
+    return getattr(U, uname)(sched, **kw)
 
 
 def build_tunable_params(params_spec: dict) -> dict:

@@ -143,13 +143,41 @@ class RandomCategorical(UpdateDistributionFn):
         return d
 
 
-class LCBoundedDistrubutionUpdate(_NotFusedYet):
-    """Rejection-sampled Lipschitz-bounded update (distribution.py:133-183)."""
+class LCBoundedDistrubutionUpdate(UpdateDistributionFn):
+    """Lipschitz-bounded update (distribution.py:133-183): the inner update is re-sampled until
+    W1(p, p') <= L * |t - prev_time| (at most 1e5 tries).  The inner fn is `RandomCategorical(scheduler)`
+    by default, or any UpdateDistributionFn class constructible from a scheduler alone
+    (`DistributionNoUpdate`).  `seed` (an extension: the reference leaves the inner sampler on OS
+    entropy) fixes the inner stream; it is rewound by a non-persistent reset and never re-seeded by
+    `reset(seed=...)`, because the wrapper only sees the outer fn, which has no `rng` (base.py:151-158)."""
 
-    def __init__(self, scheduler, L: float, update_fn=None) -> None:
+    def __init__(self, scheduler, L: float, update_fn=None, seed=None) -> None:
         super().__init__(scheduler)
         self.L = L
-        self.update_fn = update_fn
+        if update_fn is None:
+            self.update_fn = RandomCategorical(scheduler)
+        else:
+            assert isinstance(update_fn, type) and issubclass(update_fn, UpdateDistributionFn), (
+                "update_fn must be a subclass of base.UpdateDistributionFn"
+            )
+            self.update_fn = update_fn(scheduler)
+        self.inner_seed = seed
+
+    @property
+    def _uses_rng(self):
+        return isinstance(self.update_fn, RandomCategorical)
+
+    def _compile(self, tables):
+        if isinstance(self.update_fn, RandomCategorical):
+            inner = 0
+        elif isinstance(self.update_fn, DistributionNoUpdate):
+            inner = 1
+        else:
+            raise NotImplementedError(f"LCBounded over {type(self.update_fn).__name__} is not fused into the kernel")
+        d = {"upd_kind": A.UPD_D_LCBOUNDED, "u": _u(self.L, inner), "uses_rng": 1 if inner == 0 else 0}
+        if self.inner_seed is not None:
+            d.update(has_fn_seed=1, fn_seed=int(self.inner_seed))
+        return d
 
 
 __all__ = [

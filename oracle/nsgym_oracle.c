@@ -379,6 +379,21 @@ static void upd_dist(const nsg_param_cfg* pc, const uint8_t* tables, const doubl
       for (int k = 0; k < n; k++) q[k] = q[k] * invacc;
       break;
     }
+    case NSG_UPD_D_LCBOUNDED: {                        /* :167-183; *cursor holds prev_time + 1 */
+      double d = u[0] * fabs((double)t - (double)(*cursor - 1));
+      if (u[1] != 0.0) break; /* inner DistributionNoUpdate: W1 = 0 <= d, accepted at once */
+      for (int tries = 0; tries < 100000; tries++) {
+        double cand[NSG_ND_MAX], acc = 0.0;
+        for (int k = 0; k < n; k++) { cand[k] = pcg_std_exponential(rng); acc = acc + cand[k]; }
+        double invacc = 1.0 / acc;
+        for (int k = 0; k < n; k++) cand[k] = cand[k] * invacc;
+        if (w1_n(p, cand, n) <= d) {
+          for (int k = 0; k < n; k++) q[k] = cand[k];
+          break;
+        }
+      } /* exhausted: the reference raises ValueError; here the distribution stays unchanged */
+      break;
+    }
     case NSG_UPD_D_LERP: {                             /* :326-331 */
       double frac = td / u[2 * n];
       if (!(frac < 1.0)) frac = 1.0;
@@ -670,6 +685,15 @@ static void reset_one(const nsg_config* cfg, const uint8_t* tables, const nsg_bu
         b->sched_next[p * N + i] = nx;
       }
     }
+    if (pc->upd_kind == NSG_UPD_D_LCBOUNDED) { /* the wrapper cannot see the inner fn's rng: rewound with the deepcopy,
+         never re-seeded (base.py:151-158,381-391) */
+      if (pc->uses_rng && !persistent) {
+        pcg64 r;
+        if (pc->has_fn_seed) pcg_seed(&r, pc->fn_seed, -1);
+        else pcg_seed(&r, (uint64_t)i, 1000 + p);
+        rng_store(b->rng_upd + (int64_t)p * 4 * N, N, i, &r);
+      }
+    } else
     if (pc->uses_rng && has_seed) { /* base.py:386-388,412-421: SeedSequence(seed).spawn(P)[j] */
       pcg64 r;
       pcg_seed(&r, seed, pc->rng_child);
@@ -778,6 +802,7 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
       b->env_change[p * N + i] = (uint8_t)fired;
       b->delta_change[p * N + i] = (float)delta;
       if (fired) cnt[NSG_CNT_FIRED * NSG_CNT_SHARDS]++;
+      if (pc->upd_kind == NSG_UPD_D_LCBOUNDED && theta_live) b->cursor[p * N + i] = t + 1; /* prev_time = t, fired or not */
     }
     int a = ((const int32_t*)actions)[i];
     int s = b->cell[i];
@@ -991,7 +1016,9 @@ int orc_fork(const nsg_config* scfg, const nsg_buffers* sb, const nsg_config* dc
       }
       db->env_change[p * N + i] = sb->env_change[p * N + i];
       db->delta_change[p * N + i] = sb->delta_change[p * N + i];
-      if (scfg->params[p].uses_rng) { /* _reseed_planning_env_rngs: fresh entropy */
+      if (scfg->params[p].uses_rng && scfg->params[p].upd_kind == NSG_UPD_D_LCBOUNDED) { /* inner rng: deep-copied */
+        for (int k = 0; k < 4; k++) db->rng_upd[((int64_t)p * N + i) * 4 + k] = sb->rng_upd[((int64_t)p * N + i) * 4 + k];
+      } else if (scfg->params[p].uses_rng) { /* _reseed_planning_env_rngs: fresh entropy */
         pcg64 r;
         pcg_seed(&r, entropy + (uint64_t)i, 7100 + p);
         rng_store(db->rng_upd + (int64_t)p * 4 * N, N, i, &r);
@@ -1080,6 +1107,7 @@ int orc_theta_trace(const nsg_config* cfg, const uint8_t* tables, int p, int n, 
           th[0] = nvv;
         }
       }
+      if (pc->upd_kind == NSG_UPD_D_LCBOUNDED) cursor = t + 1;
       if (dist) for (int c = 0; c < nd; c++) theta_out[((int64_t)k * nd + c) * n + i] = th[c];
       else theta_out[(int64_t)k * n + i] = th[0];
       fired_out[(int64_t)k * n + i] = (uint8_t)fired;

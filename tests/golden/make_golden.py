@@ -111,7 +111,12 @@ def build_fn(S, U, fn_spec):
     uname, ukw = fn_spec["update"]
     import copy
 
-    return getattr(U, uname)(sched, **copy.deepcopy({k: _dec(v) for k, v in ukw.items()}))
+    kw = copy.deepcopy({k: _dec(v) for k, v in ukw.items()})
+    inner_seed = kw.pop("__inner_seed__", None)
+    fn = getattr(U, uname)(sched, **kw)
+    if inner_seed is not None:   # reference-side only: make LCBounded's inner sampler reproducible
+        fn.update_fn.rng = np.random.default_rng(inner_seed)
+    return fn
 
 
 SCHEDULER_SPECS = {
@@ -169,6 +174,9 @@ DIST_UPDATE_SPECS = {
     "d_lerp": ["DistributionLinearInterpolation",
                {"start_dist": [1.0, 0.0, 0.0], "end_dist": [0.4, 0.3, 0.3], "T": 25}],
     "d_randomcat": ["RandomCategorical", {"seed": 9}],
+    # the inner RandomCategorical of LCBounded has no seed argument in the reference (distribution.py:160);
+    # build_fn() installs default_rng(seed) on it after construction when "__inner_seed__" is given
+    "d_lcbounded": ["LCBoundedDistrubutionUpdate", {"L": 0.25, "__inner_seed__": 77}],
 }
 
 
@@ -284,6 +292,18 @@ TRAJ_SPECS = {
         "env_id": "CartPole-v1", "T": 220, "seeds": [70, 71, 72],
         "params": {"gravity": {"scheduler": SCHEDULER_SPECS["random_p3"], "update": ["IncrementUpdate", {"k": 0.3}]},
                    "force_mag": {"scheduler": SCHEDULER_SPECS["memoryless_p5"], "update": ["IncrementUpdate", {"k": 0.2}]}},
+        "flags": {"change_notification": True, "delta_change_notification": True, "persistent_params": True},
+    },
+    "frozenlake_lcbounded": {
+        "env_id": "FrozenLake-v1", "make_kwargs": {"map_name": "8x8", "is_slippery": False}, "T": 200, "seeds": [90, 91, 92],
+        "params": {"P": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["LCBoundedDistrubutionUpdate", {"L": 0.3, "__inner_seed__": 5}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [0.8, 0.1, 0.1]},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "frozenlake_lcbounded_persistent": {
+        "env_id": "FrozenLake-v1", "make_kwargs": {"map_name": "4x4", "is_slippery": False}, "T": 200, "seeds": [95, 96],
+        "params": {"P": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["LCBoundedDistrubutionUpdate", {"L": 0.05, "__inner_seed__": 6}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [0.8, 0.1, 0.1]},
         "flags": {"change_notification": True, "delta_change_notification": True, "persistent_params": True},
     },
     "frozenlake_randomcat": {
