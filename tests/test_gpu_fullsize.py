@@ -1,0 +1,83 @@
+"""BASELINE.json's full sizes (N = 2^20 per GPU) through size-independent properties:
+  * env independence: any subset of a 2^20-env batch equals the oracle run on those seeds alone
+    (same seeds, same per-env actions) — bit-exact integers / flags, 1e-5 on float32 state;
+  * determinism: two identical runs agree bit for bit;
+  * accounting: ballot-reduced counters == sums of the per-env outputs; FrozenLake slip
+    distributions stay normalised; done-mask compaction == nonzero(terminated | truncated)."""
+import numpy as np
+import pytest
+
+from tests.util import TRAJ_SPECS, OracleView, compare_views, make_env_from_spec
+
+pytestmark = pytest.mark.gpu
+
+N = 1 << 20
+
+
+def _vec(*a, **k):
+    from ns_gym_amd.vec_env import VecNSEnv
+
+    return VecNSEnv(*a, **k)
+
+
+@pytest.mark.parametrize("name,T", [("c1_cartpole_masspole_inc", 120), ("c3_frozenlake_step50", 130),
+                                    ("c2_cartpole_gravity_rw", 40)])
+def test_subset_of_full_batch_equals_oracle(name, T):
+    import torch
+
+    from oracle.oracle import OracleVecEnv
+
+    spec = TRAJ_SPECS[name]
+    is_fl = spec["env_id"] == "FrozenLake-v1"
+    env = make_env_from_spec(_vec, spec, n=N, track_returns=True)
+    env.reset(seed=1000)
+    pick = np.sort(np.random.default_rng(0).choice(N, size=2048, replace=False))
+    pick = np.unique(np.concatenate([pick, [0, 1, 63, 64, N - 1, N - 64, N - 65]]))
+    n_act = 4 if is_fl else 2
+    g = torch.Generator(device="cuda").manual_seed(5)
+    acts = torch.randint(0, n_act, (T, N), dtype=torch.int32, device="cuda", generator=g)
+    sub = acts[:, torch.from_numpy(pick).cuda()].cpu().numpy()
+    o = OracleView(make_env_from_spec(OracleVecEnv, spec, n=len(pick), track_returns=True))
+    ob = o.reset((pick + 1000).astype(np.uint64))
+    tot_done = tot_fired = 0
+    for k in range(T):
+        obs, rew, term, trunc, info = env.step(acts[k])
+        ob = o.step(sub[k])
+        tot_done += int((term | trunc).sum())
+        tot_fired += int(sum(v.sum() for v in info["Ground Truth Env Change"].values()))
+        if k % 10 == 0 or k == T - 1:
+            idx = torch.from_numpy(pick).cuda()
+            P = max(env.cfg.n_params, 1)
+            a = {"state": env.state[idx].cpu().numpy(), "reward": rew[idx].cpu().numpy(),
+                 "terminated": term[idx].cpu().numpy().astype(np.uint8), "truncated": trunc[idx].cpu().numpy().astype(np.uint8),
+                 "env_change": env.gt_env_change[:P, idx].cpu().numpy(), "delta_change": env.gt_delta_change[:P, idx].cpu().numpy(),
+                 "t": env.t[idx].cpu().numpy(), "theta": env.theta[:, idx].cpu().numpy()}
+            if is_fl:
+                a["prob"] = env.prob[idx].cpu().numpy()
+            compare_views(a, ob, is_fl, f"step {k}")
+    c = env.counters()
+    assert c["episodes"] == tot_done and c["updates_applied"] == tot_fired
+    assert c["env_steps"] + c["episodes"] - int((env.terminated | env.truncated).sum()) == N * T  # every call is a step or a reset
+    want = torch.nonzero(env.terminated | env.truncated).flatten().cpu().numpy()
+    np.testing.assert_array_equal(np.sort(env.done_indices().cpu().numpy()), want)
+    if is_fl:
+        s = env.theta.sum(dim=0)
+        assert float((s - 1).abs().max()) < 1e-12
+    env.close()
+
+
+def test_full_batch_is_deterministic():
+    import torch
+
+    spec = TRAJ_SPECS["c2_cartpole_gravity_rw"]
+    outs = []
+    for _ in range(2):
+        env = make_env_from_spec(_vec, spec, n=N)
+        env.reset(seed=7)
+        g = torch.Generator(device="cuda").manual_seed(11)
+        for k in range(30):
+            env.step(torch.randint(0, 2, (N,), dtype=torch.int32, device="cuda", generator=g))
+        outs.append((env.state.clone(), env.theta.clone(), env.t.clone()))
+        env.close()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
