@@ -113,6 +113,21 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms = e0.elapsed_time(e1) / args.steps   # average launch duration incl. back-to-back gap
 
+    # secondary figure (not `value`): the same env-steps through nsg_rollout, K = 64 fused steps per launch
+    # with the persistent rows held in registers (callers that supply K actions at once: planners' rollouts)
+    K = 64
+    acts64 = torch.stack([pool[k % 8] for k in range(K)])
+    env.rollout(acts64, record=("reward", "terminated", "truncated"))
+    torch.cuda.synchronize()
+    r0 = torch.cuda.Event(enable_timing=True)
+    r1 = torch.cuda.Event(enable_timing=True)
+    r0.record()
+    for _ in range(4):
+        env.rollout(acts64, record=("obs", "reward", "terminated", "truncated", "env_change", "delta_change"))
+    r1.record()
+    torch.cuda.synchronize()
+    rollout_rate = 4 * K * float(n) / (r0.elapsed_time(r1) * 1e-3)
+
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -143,6 +158,7 @@ def main():
                                if world > 1 else "single GPU",
                 "episodes_finished_rank0": env.counters()["episodes"],
                 "gathered_returns": int(gathered.numel()),
+                "rollout_k64_env_steps_per_sec_per_gpu": rollout_rate,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -173,6 +173,20 @@ template <int ENV> __device__ __forceinline__ bool own_constraint_violated(int s
   }
 }
 
+// Per-lane copy of an env's persistent rows.  nsg_step round-trips them through HBM on every launch
+// (load = store = true); nsg_rollout keeps them in registers between the K fused steps of a launch
+// and touches HBM only on the first / last step.
+template <int ENV> struct LaneState {
+  double s[EnvTraits<ENV>::PHYS];
+  double th0, th1;   // θ rows 0 and 1 (rows >= 2 always go through memory)
+  int t;
+  unsigned st;
+  float er;
+};
+struct IoMode {
+  bool load, store;  // wave-uniform
+};
+
 // Fire predicate of param p of env i.  Deterministic schedulers are pure functions of t; the
 // stochastic ones (FULL builds) advance their own PCG64 record and, for Memoryless, transition_time.
 // On a non-persistent reset the scheduler is rewound to its construction state together with the
@@ -216,7 +230,8 @@ __device__ __forceinline__ bool fire_param(const nsg_config& cfg, const nsg_buff
 // ============================================================================================
 template <int ENV, bool FULL>
 __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
-                                           const StepOut& out, int64_t base, int parity, LdsTables& lds, WaveCounts& wc) {
+                                           const StepOut& out, int64_t base, int parity, LdsTables& lds, WaveCounts& wc,
+                                           LaneState<ENV>& ls, const IoMode io) {
   using T = EnvTraits<ENV>;
   const nsg_config& cfg = sg.cfg;
   const nsg_buffers& b = sg.buf;
@@ -232,14 +247,14 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
   const bool active = i < N;
 
   const uint32_t o1 = (uint32_t)i, o4 = o1 * 4u, o8 = o1 * 8u;  // per-lane byte offsets (N <= 2^27)
-  const unsigned st = active ? ldg(b.status, o1) : 0u;
-  const int t = active ? ldg(b.t, o4) : 0;
+  const unsigned st = !active ? 0u : io.load ? ldg(b.status, o1) : ls.st;
+  const int t = !active ? 0 : io.load ? ldg(b.t, o4) : ls.t;
   const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);  // next-step autoreset == reset(seed=None)
   const bool do_step = active && !do_reset;
 
   double s[T::PHYS];
 #pragma unroll
-  for (int k = 0; k < T::PHYS; k++) s[k] = do_step ? ldg(b.phys + (int64_t)k * N, o8) : 0.0;
+  for (int k = 0; k < T::PHYS; k++) s[k] = !do_step ? 0.0 : io.load ? ldg(b.phys + (int64_t)k * N, o8) : ls.s[k];
   int ai = 0;
   float af = 0.f;
   if (do_step) {
@@ -248,19 +263,24 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
   }
   float er = 0.f;
   const bool track = (cfg.flags & NSG_F_TRACK_RETURNS) != 0;
-  if (track && do_step) er = ldg(b.ep_return, o4);
+  if (track && do_step) er = io.load ? ldg(b.ep_return, o4) : ls.er;
 
   double th[T::NTHETA + T::NDERIVED];
 #pragma unroll
   for (int k = 0; k < T::NTHETA; k++) th[k] = cfg.base_theta[k];
   unsigned n_fired = 0, n_viol = 0;
+  // the first two θ rows are fetched together with the state rows (one memory latency on the wave's
+  // critical path instead of two); further rows are fetched inside the loop
+  double pre0 = 0.0, pre1 = 0.0;
+  if (active && P > 0) pre0 = io.load ? ldg(b.theta, o8) : ls.th0;
+  if (active && P > 1) pre1 = io.load ? ldg(b.theta + N, o8) : ls.th1;
 
   if constexpr (ENV != NSG_ENV_ACROBOT) {
     // ---- single pass: propose, check, commit (classic_control.py:80-92) ----------------------
     for (int p = 0; p < P; p++) {
       const nsg_param_cfg& pc = cfg.params[p];
       const int slot = pc.theta_slot;
-      const double c = active ? ldg(b.theta + (int64_t)p * N, o8) : cfg.base_theta[slot];
+      const double c = !active ? cfg.base_theta[slot] : p == 0 ? pre0 : p == 1 ? pre1 : ldg(b.theta + (int64_t)p * N, o8);
       double n = c;
       bool fired = fire_param<FULL>(cfg, b, tb, zg, N, i, p, t, do_step && theta_live, do_reset && !persistent);
       if (fired) {
@@ -289,7 +309,11 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
         if (k == slot) th[k] = fin;
       });
       if (active) {
-        if (fin != c) stg(b.theta + (int64_t)p * N, o8, fin);
+        if (p == 0) ls.th0 = fin;
+        if (p == 1) ls.th1 = fin;
+        // rows 0/1 live in registers across fused steps: written when this step stores (always then,
+        // because earlier fused steps may have changed them without a store)
+        if (p > 1 ? fin != c : (io.store && (fin != c || !io.load))) stg(b.theta + (int64_t)p * N, o8, fin);
         stg(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
         stg(out.delta_change + (int64_t)p * N, o4, (float)delta);
       }
@@ -304,7 +328,7 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
     for (int p = 0; p < P; p++) {
       const nsg_param_cfg& pc = cfg.params[p];
       const int slot = pc.theta_slot;
-      const double c = active ? ldg(b.theta + (int64_t)p * N, o8) : cfg.base_theta[slot];
+      const double c = !active ? cfg.base_theta[slot] : p == 0 ? pre0 : p == 1 ? pre1 : ldg(b.theta + (int64_t)p * N, o8);
       double n = c;
       if (fire_param<FULL>(cfg, b, tb, zg, N, i, p, t, do_step && theta_live, do_reset && !persistent)) {
         Pcg r = {0, 0, 0, 0};
@@ -349,7 +373,11 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
         if (k == slot) th[k] = fin;
       });
       if (active) {
-        if (fin != c) stg(b.theta + (int64_t)p * N, o8, fin);
+        if (p == 0) ls.th0 = fin;
+        if (p == 1) ls.th1 = fin;
+        // rows 0/1 live in registers across fused steps: written when this step stores (always then,
+        // because earlier fused steps may have changed them without a store)
+        if (p > 1 ? fin != c : (io.store && (fin != c || !io.load))) stg(b.theta + (int64_t)p * N, o8, fin);
         stg(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
         stg(out.delta_change + (int64_t)p * N, o4, (float)delta);
       }
@@ -406,17 +434,23 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
     for (int k = 0; k < T::PHYS; k++) s[k] = lds.reset_state[tid * 4 + k];
   }
 
-  if (active) {  // every row is written by its owner lane: fully coalesced stores
 #pragma unroll
-    for (int k = 0; k < T::PHYS; k++) stg(b.phys + (int64_t)k * N, o8, s[k]);
+  for (int k = 0; k < T::PHYS; k++) ls.s[k] = s[k];
+  ls.t = tnew;
+  ls.st = done ? NSG_ST_NEEDS_RESET : 0u;
+  if (active) {  // every row is written by its owner lane: fully coalesced stores
+    if (io.store) {
+#pragma unroll
+      for (int k = 0; k < T::PHYS; k++) stg(b.phys + (int64_t)k * N, o8, s[k]);
+    }
     float o[T::OBS];
     env_obs<ENV>(s, o);
     store_obs<ENV>(out.obs, i, o);
-    stg(b.t, o4, tnew);
+    if (io.store) stg(b.t, o4, tnew);
     stg(out.reward, o4, (float)reward);
     stg(out.terminated, o1, (uint8_t)(term ? 1 : 0));
     stg(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
-    stg(b.status, o1, (uint8_t)(done ? NSG_ST_NEEDS_RESET : 0));
+    if (io.store) stg(b.status, o1, (uint8_t)(done ? NSG_ST_NEEDS_RESET : 0));
     if (track) {  // the episode length is the wrapper time t: only the return needs a running row
       er += (float)reward;
       if (done) {
@@ -424,7 +458,8 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
         stg(b.last_length, o4, tnew);
         er = 0.f;
       }
-      stg(b.ep_return, o4, er);
+      ls.er = er;
+      if (io.store) stg(b.ep_return, o4, er);
     }
   }
 
@@ -660,11 +695,13 @@ __device__ __forceinline__ void step_grid(const Segment& sg, const Tables& tb, c
 template <int ENV, bool FULL>
 __device__ __forceinline__ void step_block(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
                                            const StepOut& out, int64_t base, int parity, LdsTables& lds, WaveCounts& wc) {
+  // single step: every persistent row round-trips through memory
   if constexpr (ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE) {
     const int64_t i = base + threadIdx.x;
     step_grid<ENV, FULL>(sg, tb, zg, actions, out, i, i < sg.N, wc);
   } else {
-    step_chunk<ENV, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc);
+    LaneState<ENV> ls;
+    step_chunk<ENV, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc, ls, IoMode{true, true});
   }
 }
 

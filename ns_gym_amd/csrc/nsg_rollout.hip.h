@@ -2,8 +2,10 @@
 //
 // Every lane owns one env for the whole launch, so consecutive steps of an env are ordered by
 // program order and no inter-workgroup synchronisation is needed.  Per-step outputs go to the
-// k-th slice of the caller's trajectory buffers; the persistent state round-trips through the
-// env's own SoA rows (L2-resident between consecutive steps of the same workgroup).
+// k-th slice of the caller's trajectory buffers.  For the classic-control envs the persistent rows
+// (integrator state, t, status, θ rows 0-1, episode return) stay in REGISTERS between the K steps
+// (LaneState): HBM sees them once per launch, so a step costs the action (4 B) plus its outputs
+// (~31 B for CartPole) instead of ~140 B.  Grid envs round-trip through their (L2-resident) rows.
 #pragma once
 #include "nsg_kernels.hip.h"
 
@@ -27,16 +29,29 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const Segment* __restri
   const int64_t chunks = (N + kBlock - 1) / kBlock;
   int parity = 0;
   for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    [[maybe_unused]] LaneState<GRID ? NSG_ENV_CARTPOLE : ENV> ls;
     for (int k = 0; k < k_steps; k++) {
       StepOut out;
+      // the LAST step writes into the env's own output rows (so the handle's buffers describe the env
+      // after the rollout exactly as after nsg_step); nsg_rollout then copies them into the last slice
+      const bool last = k == k_steps - 1;
+      if (last) {
+        out = dflt;
+        if (GRID) out.obs = nullptr;
+      } else {
       out.obs = ro.obs ? ro.obs + (int64_t)k * N * D : (GRID ? nullptr : dflt.obs);
       out.reward = ro.reward ? ro.reward + (int64_t)k * N : dflt.reward;
       out.terminated = ro.terminated ? ro.terminated + (int64_t)k * N : dflt.terminated;
       out.truncated = ro.truncated ? ro.truncated + (int64_t)k * N : dflt.truncated;
       out.env_change = ro.env_change ? ro.env_change + (int64_t)k * P * N : dflt.env_change;
       out.delta_change = ro.delta_change ? ro.delta_change + (int64_t)k * P * N : dflt.delta_change;
+      }
       const void* act = FA ? (const void*)((const float*)actions + (int64_t)k * N) : (const void*)((const int32_t*)actions + (int64_t)k * N);
-      step_block<ENV, FULL>(sg, tb, zg, act, out, c * kBlock, parity, lds, wc);
+      if constexpr (GRID) {
+        step_block<ENV, FULL>(sg, tb, zg, act, out, c * kBlock, parity, lds, wc);
+      } else {
+        step_chunk<ENV, FULL>(sg, tb, zg, act, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, k == k_steps - 1});
+      }
       parity ^= 1;
     }
   }

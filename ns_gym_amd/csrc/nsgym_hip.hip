@@ -313,6 +313,20 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
                  hipLaunchKernelGGL((rollout_kernel<E, true>), dim3(grid_for(h->n)), dim3(kBlock), (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp), s, h->dev, actions_dev, k_steps, o));
   }
   HIP_TRY(hipGetLastError());
+  // the last step landed in the handle's own output rows: mirror them into the last trajectory slice
+  const nsg_buffers& bb = h->host.buf;
+  const int64_t n = h->n, K1 = k_steps - 1;
+  const int e = h->host.cfg.env_type;
+  const int P = h->host.cfg.n_params > 0 ? h->host.cfg.n_params : 1;
+  if (o.obs) {
+    if (is_grid_env(e)) HIP_TRY(hipMemcpyAsync((int32_t*)o.obs + K1 * n, bb.cell, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    else HIP_TRY(hipMemcpyAsync(o.obs + K1 * n * kObsDim[e], bb.obs, n * kObsDim[e] * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  if (o.reward) HIP_TRY(hipMemcpyAsync(o.reward + K1 * n, bb.reward, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (o.terminated) HIP_TRY(hipMemcpyAsync(o.terminated + K1 * n, bb.terminated, n, hipMemcpyDeviceToDevice, s));
+  if (o.truncated) HIP_TRY(hipMemcpyAsync(o.truncated + K1 * n, bb.truncated, n, hipMemcpyDeviceToDevice, s));
+  if (o.env_change) HIP_TRY(hipMemcpyAsync(o.env_change + K1 * P * n, bb.env_change, (size_t)P * n, hipMemcpyDeviceToDevice, s));
+  if (o.delta_change) HIP_TRY(hipMemcpyAsync(o.delta_change + K1 * P * n, bb.delta_change, (size_t)P * n * sizeof(float), hipMemcpyDeviceToDevice, s));
   return NSG_OK;
 }
 

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--iters", type=int, default=300)
     ap.add_argument("--work", default="c1,c2,c3,pend,acro")
     ap.add_argument("--no-track", action="store_true")
+    ap.add_argument("--rollout", type=int, default=0, help="K fused steps per launch (nsg_rollout) instead of nsg_step")
     args = ap.parse_args()
     res = {}
     for name in args.work.split(","):
@@ -56,7 +57,25 @@ def main():
         for _ in range(30):
             e.step(a)
         torch.cuda.synchronize()
-        ms = min(e.time_steps(a, args.iters) for _ in range(3))
+        if args.rollout:
+            K = args.rollout
+            acts = torch.stack([actions(e, n) for _ in range(K)])
+            for _ in range(2):
+                e.rollout(acts)
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                reps = max(args.iters // K, 2)
+                for _ in range(reps):
+                    e.rollout(acts)
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / (reps * K))
+            ms = best
+        else:
+            ms = min(e.time_steps(a, args.iters) for _ in range(3))
         gbs = WORK[name][3] * n / (ms * 1e-3) / 1e9
         res[name] = {"us": ms * 1e3, "GB/s": gbs, "frac": gbs / 8000, "Gsteps/s": n / (ms * 1e-3) / 1e9}
         print(name, json.dumps(res[name]), flush=True)
