@@ -64,14 +64,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    # NSG_BENCH_SINGLE_DEVICE=1 + NSG_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a one-GPU box
+    # (every rank on cuda:0, collectives through gloo); the driver's real runs use one GPU per rank + RCCL
+    single = os.environ.get("NSG_BENCH_SINGLE_DEVICE") == "1"
+    backend = os.environ.get("NSG_BENCH_BACKEND", "nccl")
+    dev_index = 0 if single else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ns_gym_amd import make
     from ns_gym_amd.distributed import all_gather_returns
@@ -167,7 +175,7 @@ def main():
                 "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported on rank 0 at N = 1 only
             # the GPU box exposes 256 logical CPUs but one GPU's share is 16 cores
             threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
             cpu_baseline(1 << 14, 8, threads)  # warm the OpenMP pool / page in the oracle
@@ -184,6 +192,7 @@ def main():
             }
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

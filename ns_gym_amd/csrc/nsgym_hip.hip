@@ -20,6 +20,7 @@ using namespace nsg;
 namespace {
 
 thread_local char g_err[512] = "";
+thread_local unsigned long long g_generation = 0;  // bumped by nsg_destroy: invalidates cached group tables
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -337,10 +338,11 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
   static thread_local Segment* d_group = nullptr;
   static thread_local nsg_handle* members[NSG_MAX_SEGMENTS];
   static thread_local int n_members = 0;
+  static thread_local unsigned long long built_at = ~0ULL;
   static thread_local int total_blocks = 0;
   static thread_local int all_simple = 0;
   static thread_local int group_lds = 0;
-  bool same = n_members == n_handles;
+  bool same = n_members == n_handles && built_at == g_generation;
   for (int k = 0; same && k < n_handles; k++) same = members[k] == hs[k];
   if (!same) {
     Segment tmp[NSG_MAX_SEGMENTS];
@@ -356,6 +358,7 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
     HIP_TRY(hipMemcpy(d_group, tmp, sizeof(Segment) * n_handles, hipMemcpyHostToDevice));
     for (int k = 0; k < n_handles; k++) members[k] = hs[k];
     n_members = n_handles;
+    built_at = g_generation;
     total_blocks = begin;
     all_simple = 1;
     group_lds = 0;
@@ -475,6 +478,7 @@ int nsg_calib_copy_f64(const double* src_dev, double* dst_dev, int64_t n, void* 
 
 int nsg_destroy(nsg_handle* h) {
   if (!h) return NSG_OK;
+  g_generation++;
   if (h->d_tables) (void)hipFree(h->d_tables);
   if (h->d_zig) (void)hipFree(h->d_zig);
   if (h->dev) (void)hipFree(h->dev);

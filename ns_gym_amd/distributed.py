@@ -39,12 +39,19 @@ def all_gather_returns(env, group=None) -> torch.Tensor:
     sizes = [int(x.item()) for x in all_n]
     if len(set(sizes)) == 1:
         out = torch.empty(world * sizes[0], dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        if dist.get_backend(group) == "gloo":   # gloo has no all_gather_into_tensor for device tensors
+            parts = list(out.view(world, sizes[0]).unbind(0))
+            dist.all_gather(parts, local.contiguous(), group=group)
+        else:
+            dist.all_gather_into_tensor(out, local.contiguous(), group=group)
         return out
     # ragged shards (total_envs % world != 0): pad to the largest shard, gather, drop the padding
     m = max(sizes)
     padded = torch.zeros(m, dtype=local.dtype, device=local.device)
     padded[: local.numel()] = local
     out = torch.empty(world * m, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, padded, group=group)
+    if dist.get_backend(group) == "gloo":
+        dist.all_gather(list(out.view(world, m).unbind(0)), padded, group=group)
+    else:
+        dist.all_gather_into_tensor(out, padded, group=group)
     return torch.cat([out[r * m: r * m + sizes[r]] for r in range(world)])

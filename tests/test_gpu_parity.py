@@ -171,3 +171,29 @@ def test_hip_matches_oracle_at_scale(name):
     got = np.sort(g.env.done_indices().cpu().numpy())
     np.testing.assert_array_equal(got, want)
     g.env.close()
+
+
+def test_heterogeneous_group_launch_matches_oracle():
+    """BASELINE config C4: Pendulum + Acrobot stepped by ONE launch (per-env-type dispatch per
+    workgroup), plus a FrozenLake segment; each segment equals its oracle."""
+    import torch
+
+    from ns_gym_amd.vec_env import step_group
+    from oracle.oracle import OracleVecEnv
+    from tests.golden.make_golden import make_actions
+
+    names = ["c4_pendulum_m_inc", "c4_acrobot_mass2_inc", "c3_frozenlake_step50", "c2_cartpole_gravity_rw"]
+    ns = [5000, 3000, 4096, 2500]
+    T = 90
+    gs = [GpuView(make_env_from_spec(_vec, TRAJ_SPECS[nm], n=n)) for nm, n in zip(names, ns)]
+    os_ = [OracleView(make_env_from_spec(OracleVecEnv, TRAJ_SPECS[nm], n=n)) for nm, n in zip(names, ns)]
+    acts = [make_actions(TRAJ_SPECS[nm]["env_id"], T, n) for nm, n in zip(names, ns)]
+    for g, o, n in zip(gs, os_, ns):
+        seeds = np.arange(n, dtype=np.uint64) + np.uint64(5)
+        g.reset(seeds); o.reset(seeds)
+    for k in range(T):
+        step_group([g.env for g in gs], [torch.from_numpy(a[k]) for a in acts])
+        for g, o, a, nm in zip(gs, os_, acts, names):
+            compare_views(g._out(), o.step(a[k]), TRAJ_SPECS[nm]["env_id"] == "FrozenLake-v1", f"{nm} step {k}")
+    for g in gs:
+        g.env.close()
