@@ -107,6 +107,7 @@ enum {
 #define NSG_F_PERSISTENT_PARAMS 0x4u
 #define NSG_F_TRACK_RETURNS 0x8u   /* keep per-env episode return / length accumulators   */
 #define NSG_F_MODIFIED_REWARDS 0x10u /* FrozenLake modified_rewards (toy_text.py:465-468)  */
+#define NSG_F_VIOLATION_MASK 0x200u /* also write the per-(env,param) constraint-violation mask (buffers.violation) */
 #define NSG_F_TERMINAL_CLIFF 0x100u /* CliffWalking terminal_cliff (toy_text.py:39,126-128)              */
 #define NSG_F_SIM_ENV 0x40u        /* planning copy: is_sim_env (base.py:270, classic_control.py:184)   */
 #define NSG_F_IN_SIM_CHANGE 0x80u  /* in_sim_change: θ keeps evolving inside planning copies            */
@@ -203,6 +204,8 @@ typedef struct nsg_buffers {
   uint8_t* truncated;    /* [N]                                                           */
   uint8_t* env_change;   /* [P][N] ground-truth flags (info["Ground Truth Env Change"])   */
   float* delta_change;   /* [P][N] ground-truth deltas (info["Ground Truth Delta Change"]) */
+  uint8_t* violation;    /* [P][N] 1 where this step's proposal was rejected by the constraint checker
+                            (classic_control.py:87-92; the reference warns instead).  NSG_F_VIOLATION_MASK */
   float* prob;           /* [N]    FrozenLake info["prob"]                                */
   float* ep_return;      /* [N]    running episode return      (NSG_F_TRACK_RETURNS)      */
   int32_t* ep_length;    /* [N]    running episode length                                 */
@@ -219,7 +222,7 @@ typedef struct nsg_layout {
   int32_t phys_dim, obs_dim, n_params, n_theta_rows, action_is_float;
   int32_t n_actions;           /* discrete action count, 0 for continuous                  */
   int64_t phys, cell, theta, table_prob, derived, t, t_fork, status, rng_env, rng_upd, rng_sched, sched_next, cursor, obs, reward, terminated,
-      truncated, env_change, delta_change, prob, ep_return, ep_length, last_return, last_length,
+      truncated, env_change, delta_change, violation, prob, ep_return, ep_length, last_return, last_length,
       counters, done_bits;
 } nsg_layout;
 

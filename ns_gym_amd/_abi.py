@@ -31,6 +31,7 @@ F_DELTA_NOTIFICATION = 0x2
 F_PERSISTENT_PARAMS = 0x4
 F_TRACK_RETURNS = 0x8
 F_MODIFIED_REWARDS = 0x10
+F_VIOLATION_MASK = 0x200
 F_TERMINAL_CLIFF = 0x100
 F_SIM_ENV = 0x40
 F_IN_SIM_CHANGE = 0x80
@@ -89,7 +90,7 @@ BUFFER_FIELDS = [
     ("phys", C.c_double), ("cell", C.c_int32), ("theta", C.c_double), ("table_prob", C.c_double), ("derived", C.c_double), ("t", C.c_int32), ("t_fork", C.c_int32),
     ("status", C.c_uint8), ("rng_env", C.c_uint64), ("rng_upd", C.c_uint64), ("rng_sched", C.c_uint64), ("sched_next", C.c_int32), ("cursor", C.c_int32),
     ("obs", C.c_float), ("reward", C.c_float), ("terminated", C.c_uint8), ("truncated", C.c_uint8),
-    ("env_change", C.c_uint8), ("delta_change", C.c_float), ("prob", C.c_float),
+    ("env_change", C.c_uint8), ("delta_change", C.c_float), ("violation", C.c_uint8), ("prob", C.c_float),
     ("ep_return", C.c_float), ("ep_length", C.c_int32), ("last_return", C.c_float),
     ("last_length", C.c_int32), ("counters", C.c_uint64), ("done_bits", C.c_uint64),
 ]

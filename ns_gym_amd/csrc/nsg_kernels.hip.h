@@ -316,6 +316,7 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
         if (p > 1 ? fin != c : (io.store && (fin != c || !io.load))) stg(b.theta + (int64_t)p * N, o8, fin);
         stg(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
         stg(out.delta_change + (int64_t)p * N, o4, (float)delta);
+        if (b.violation) stg(b.violation + (int64_t)p * N, o1, (uint8_t)(rejected && do_step ? 1 : 0));
       }
       n_fired += fired ? 1u : 0u;
     }
@@ -380,6 +381,7 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
         if (p > 1 ? fin != c : (io.store && (fin != c || !io.load))) stg(b.theta + (int64_t)p * N, o8, fin);
         stg(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
         stg(out.delta_change + (int64_t)p * N, o4, (float)delta);
+        if (b.violation) stg(b.violation + (int64_t)p * N, o1, (uint8_t)(rejected && do_step ? 1 : 0));
       }
       n_fired += fired ? 1u : 0u;
     }

@@ -168,6 +168,7 @@ int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
   out->env_change = (int64_t)(P > 0 ? P : 1) * n;
   out->delta_change = (int64_t)(P > 0 ? P : 1) * n;
   out->prob = fl ? n : 0;
+  out->violation = ((cfg->flags & NSG_F_VIOLATION_MASK) && !fl) ? (int64_t)(P > 0 ? P : 1) * n : 0;
   const bool tr = (cfg->flags & NSG_F_TRACK_RETURNS) != 0;
   out->ep_return = tr ? n : 0;
   out->ep_length = tr ? n : 0;
@@ -246,7 +247,7 @@ int nsg_bind(nsg_handle* h, const nsg_buffers* bufs) {
 #define NEED(field) \
   if (lay.field > 0 && !bufs->field) return fail(NSG_EINVAL, "buffer '%s' is required (%lld elements)", #field, (long long)lay.field)
   NEED(phys); NEED(cell); NEED(theta); NEED(table_prob); NEED(derived); NEED(t); NEED(t_fork); NEED(status); NEED(rng_env); NEED(rng_upd); NEED(rng_sched); NEED(sched_next); NEED(cursor);
-  NEED(obs); NEED(reward); NEED(terminated); NEED(truncated); NEED(env_change); NEED(delta_change);
+  NEED(obs); NEED(reward); NEED(terminated); NEED(truncated); NEED(env_change); NEED(delta_change); NEED(violation);
   NEED(ep_return); NEED(ep_length); NEED(last_return); NEED(last_length);
 #undef NEED
   h->host.buf = *bufs;

@@ -20,7 +20,7 @@ _INF = "inf"
 
 
 def compile_config(env, tunable_params: dict, *, change_notification=False, delta_change_notification=False,
-                   in_sim_change=False, scalar_reward=True, persistent_params=False, track_returns=False, initial_prob_dist=None, modified_rewards=None, is_sim_env=False, terminal_cliff=False):
+                   in_sim_change=False, scalar_reward=True, persistent_params=False, track_returns=False, initial_prob_dist=None, modified_rewards=None, is_sim_env=False, terminal_cliff=False, violation_mask=False):
     """Returns (Config, tables_blob: bytes, BaseEnvSpec, param_names)."""
     spec: BaseEnvSpec = from_gym_env(env)
     et = spec.env_type
@@ -55,6 +55,8 @@ def compile_config(env, tunable_params: dict, *, change_notification=False, delt
         flags |= A.F_IN_SIM_CHANGE
     if is_sim_env:
         flags |= A.F_SIM_ENV
+    if violation_mask:
+        flags |= A.F_VIOLATION_MASK
     tables = TableBuilder()
     tables.nd = nd
     if is_fl:

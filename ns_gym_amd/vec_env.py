@@ -40,6 +40,7 @@ class VecNSEnv:
     def __init__(self, env, tunable_params: dict, num_envs: int, change_notification: bool = False,
                  delta_change_notification: bool = False, in_sim_change: bool = False, scalar_reward: bool = True,
                  persistent_params: bool = False, track_returns: bool = False, device=None, is_sim_env: bool = False,
+                 violation_mask: bool = False,
                  **kwargs):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -49,11 +50,11 @@ class VecNSEnv:
             env, tunable_params, change_notification=change_notification,
             delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
             scalar_reward=scalar_reward, persistent_params=persistent_params, track_returns=track_returns,
-            is_sim_env=is_sim_env, **kwargs)
+            is_sim_env=is_sim_env, violation_mask=violation_mask, **kwargs)
         self._ctor = dict(env=env, tunable_params=tunable_params, num_envs=num_envs, change_notification=change_notification,
                           delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
                           scalar_reward=scalar_reward, persistent_params=persistent_params, track_returns=track_returns,
-                          device=device, **kwargs)
+                          device=device, violation_mask=violation_mask, **kwargs)
         self.tunable_params = tunable_params
         self.change_notification = change_notification
         self.delta_change_notification = delta_change_notification
@@ -86,6 +87,12 @@ class VecNSEnv:
             self._h = h
             _lib.check(self.lib.nsg_bind(self._h, C.byref(self._bufs)), "nsg_bind")
         self._make_views()
+        from . import spaces
+
+        # per-env spaces (gymnasium.vector naming) and the NS observation Dict of base.py:275-292
+        self.single_state_space, self.single_action_space = spaces.base_spaces(self.spec.class_name, self.spec.desc)
+        self.single_observation_space = spaces.ns_observation_space(self.single_state_space, self.param_names)
+        self.observation_space, self.action_space = self.single_observation_space, self.single_action_space
         self._zero_flags = None
         self._viol_seen = 0
 
@@ -98,6 +105,8 @@ class VecNSEnv:
         self.truncated = b["truncated"].view(torch.bool)
         self.gt_env_change = b["env_change"].view(P, N)
         self.gt_delta_change = b["delta_change"].view(P, N)
+        # [P, N] 1 where this step's update was rejected by the physical-constraint checker (violation_mask=True)
+        self.violation = b["violation"].view(P, N) if b["violation"] is not None else None
         rows = self.n_dist * P if self.is_grid else P
         self.theta = b["theta"].view(rows, N)     # grid envs: param p occupies rows [p*n, (p+1)*n)
         if self.is_grid:

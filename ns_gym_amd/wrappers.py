@@ -26,22 +26,6 @@ __all__ = ["NSClassicControlWrapper", "NSFrozenLakeWrapper", "NSCliffWalkingWrap
            "ConstraintViolationWarning"]
 
 
-class _Space:
-    """Minimal stand-in for gymnasium.spaces (gymnasium is optional at run time)."""
-
-    def __init__(self, n=None, low=None, high=None, shape=(), dtype=np.float32, seed=None):
-        self.n, self.low, self.high, self.shape, self.dtype = n, low, high, shape, dtype
-        self._rng = np.random.default_rng(seed)
-
-    def sample(self):
-        if self.n is not None:
-            return int(self._rng.integers(self.n))
-        return self._rng.uniform(self.low, self.high, size=self.shape).astype(self.dtype)
-
-    def seed(self, seed=None):
-        self._rng = np.random.default_rng(seed)
-
-
 class _Unwrapped:
     """`env.unwrapped.<attr>` of the reference: live view of the base env's attributes."""
 
@@ -98,11 +82,8 @@ class _NSSingle:
         self.persistent_params = v.persistent_params
         self.unwrapped = _Unwrapped(self)
         self.delta_t = 1
-        et = self.spec.env_type
-        if et.n_actions:
-            self.action_space = _Space(n=et.n_actions)
-        else:
-            self.action_space = _Space(low=et.action_low, high=et.action_high, shape=(1,))
+        self.action_space = v.single_action_space
+        self.observation_space = v.single_observation_space   # Dict(state, env_change, delta_change, relative_time)
         self._done = False
 
     # state mirrored from the vector env

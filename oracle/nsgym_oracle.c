@@ -914,6 +914,7 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
       } else {
         th[k] = nv[k];
       }
+      if (b->violation) b->violation[p * N + i] = (uint8_t)((viol >> k) & 1u);
       b->theta[p * N + i] = th[k];
       b->env_change[p * N + i] = (uint8_t)fired;
       b->delta_change[p * N + i] = (float)delta;

@@ -77,7 +77,7 @@ class OracleVecEnv:
             "cursor": z((max(P, 1), N), np.int32), "obs": z((N, OBS_DIM[et]), np.float32),
             "reward": z(N, np.float32), "terminated": z(N, np.uint8), "truncated": z(N, np.uint8),
             "env_change": z((max(P, 1), N), np.uint8), "delta_change": z((max(P, 1), N), np.float32),
-            "prob": z(N, np.float32), "ep_return": z(N, np.float32), "ep_length": z(N, np.int32),
+            "violation": z((max(P, 1), N), np.uint8), "prob": z(N, np.float32), "ep_return": z(N, np.float32), "ep_length": z(N, np.int32),
             "last_return": z(N, np.float32), "last_length": z(N, np.int32),
             "counters": z((A.CNT_COUNT, A.CNT_SHARDS), np.uint64), "done_bits": z((N + 63) // 64, np.uint64),
         }

@@ -197,3 +197,31 @@ def test_heterogeneous_group_launch_matches_oracle():
             compare_views(g._out(), o.step(a[k]), TRAJ_SPECS[nm]["env_id"] == "FrozenLake-v1", f"{nm} step {k}")
     for g in gs:
         g.env.close()
+
+
+def test_constraint_violation_mask():
+    """Optional per-(env, param) violation mask (the boundary's counterpart of the reference's
+    ConstraintViolationWarning, classic_control.py:87-92,212-234) against the oracle."""
+    import torch
+
+    from oracle.oracle import OracleVecEnv
+    from tests.golden.make_golden import make_actions
+
+    n = 4096
+    # Acrobot: short horizon — its LINK_MOI random walk soon reaches ill-conditioned dynamics (MOI -> 0) where
+    # last-ulp differences flip terminations; the mask itself depends only on θ, which stays bit-exact
+    for name, T in (("cartpole_constraint", 60), ("acrobot_constraints", 20)):
+        spec = TRAJ_SPECS[name]
+        g = make_env_from_spec(_vec, spec, n=n, violation_mask=True)
+        o = make_env_from_spec(OracleVecEnv, spec, n=n, violation_mask=True)
+        g.reset(seed=3); o.reset(seed=3)
+        acts = make_actions(spec["env_id"], T, n)
+        seen = 0
+        for k in range(T):
+            g.step(torch.from_numpy(acts[k])); o.step(acts[k])
+            P = g.cfg.n_params
+            stepped = (o.a["t"] > 0) & (g.t.cpu().numpy() == o.a["t"])
+            np.testing.assert_array_equal(g.violation.cpu().numpy()[:, stepped], o.a["violation"][:P][:, stepped])
+            seen += int(o.a["violation"][:P][:, stepped].sum())
+        assert seen > 0 and g.counters()["constraint_violations"] > 0
+        g.close()
