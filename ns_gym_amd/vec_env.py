@@ -103,12 +103,14 @@ class VecNSEnv:
         self.reward = b["reward"]
         self.terminated = b["terminated"].view(torch.bool)
         self.truncated = b["truncated"].view(torch.bool)
-        self.gt_env_change = b["env_change"].view(P, N)
-        self.gt_delta_change = b["delta_change"].view(P, N)
+        self.gt_env_change = b["env_change"].view(P, N)[: self.cfg.n_params]
+        self.gt_delta_change = b["delta_change"].view(P, N)[: self.cfg.n_params]
         # [P, N] 1 where this step's update was rejected by the physical-constraint checker (violation_mask=True)
         self.violation = b["violation"].view(P, N) if b["violation"] is not None else None
         rows = self.n_dist * P if self.is_grid else P
-        self.theta = b["theta"].view(rows, N)     # grid envs: param p occupies rows [p*n, (p+1)*n)
+        # grid envs: param p occupies rows [p*n, (p+1)*n); no tunable params -> an empty [0, N] view
+        self.theta = (b["theta"].view(rows, N) if b["theta"] is not None
+                      else torch.zeros((0, N), dtype=torch.float64, device=self.device))
         if self.is_grid:
             self.state = b["cell"]
             self.prob = b["prob"]

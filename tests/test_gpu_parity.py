@@ -225,3 +225,55 @@ def test_constraint_violation_mask():
             seen += int(o.a["violation"][:P][:, stepped].sum())
         assert seen > 0 and g.counters()["constraint_violations"] > 0
         g.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 257, 1000, 4097])
+def test_ragged_batch_sizes_match_oracle(n):
+    """Batch sizes that are not multiples of the wavefront (64) or workgroup (256) size: partial waves,
+    partial workgroups, single env."""
+    import torch
+
+    from oracle.oracle import OracleVecEnv
+    from tests.golden.make_golden import make_actions
+
+    for name in ("cartpole_two_params", "c3_frozenlake_step50"):
+        spec = TRAJ_SPECS[name]
+        is_fl = spec["env_id"] == "FrozenLake-v1"
+        g = GpuView(make_env_from_spec(_vec, spec, n=n, track_returns=True))
+        o = OracleView(make_env_from_spec(OracleVecEnv, spec, n=n, track_returns=True))
+        seeds = np.arange(n, dtype=np.uint64) + np.uint64(31)
+        acts = make_actions(spec["env_id"], 70, n)
+        compare_views(g.reset(seeds), o.reset(seeds), is_fl, "reset")
+        for k in range(70):
+            compare_views(g.step(acts[k]), o.step(acts[k]), is_fl, f"n={n} step {k}")
+        want = np.flatnonzero(o.env.a["terminated"] | o.env.a["truncated"])
+        np.testing.assert_array_equal(np.sort(g.env.done_indices().cpu().numpy()), want)
+        c = g.env.counters()
+        assert [c["episodes"], c["updates_applied"], c["env_steps"]] == [int(x) for x in o.env.a["counters"].sum(axis=1)[[0, 1, 3]]]
+        g.env.close()
+
+
+def test_no_tunable_params_is_the_stationary_env():
+    """tunable_params = {} is legal in the reference (base.py:257-261): the wrapper then only adds the NS
+    observation dict around the stationary base env."""
+    import torch
+
+    from ns_gym_amd import make
+    from oracle.oracle import OracleVecEnv
+    from tests.golden.make_golden import make_actions
+
+    n = 777
+    for env_id in ("CartPole-v1", "Pendulum-v1", "MountainCar-v0"):
+        g = GpuView(_vec(make(env_id), {}, n))
+        o = OracleView(OracleVecEnv(make(env_id), {}, n))
+        seeds = np.arange(n, dtype=np.uint64)
+        acts = make_actions(env_id, 60, n)
+        a, b = g.reset(seeds), o.reset(seeds)
+        np.testing.assert_allclose(a["state"], b["state"], atol=1e-6)
+        for k in range(60):
+            a, b = g.step(acts[k]), o.step(acts[k])
+            np.testing.assert_allclose(a["state"], b["state"], rtol=1e-5, atol=1e-5)
+            np.testing.assert_array_equal(a["terminated"], b["terminated"])
+            np.testing.assert_array_equal(a["t"], b["t"])
+        assert g.env._obs()["env_change"] == {} and g.env.counters()["updates_applied"] == 0
+        g.env.close()
