@@ -21,8 +21,10 @@
 #ifndef NSGYM_HIP_H
 #define NSGYM_HIP_H
 
+#ifndef __HIPCC_RTC__  /* hiprtc (config-specialised builds) predefines the fixed-width types */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -39,6 +41,7 @@ extern "C" {
 #define NSG_ENOMEM (-12)
 #define NSG_EHIP (-5)
 #define NSG_ENOTBOUND (-77)
+#define NSG_EUNSUPPORTED (-95) /* config specialisation unavailable (no hiprtc) or its compilation failed */
 
 /* ---- env types; θ slot order = ATTRIBUTE_MAP order (ns_gym/base.py:611-635) ---------- */
 enum {
@@ -115,9 +118,12 @@ enum {
 /* per-env status byte (buffers.status) */
 #define NSG_ST_NEEDS_RESET 0x1u
 
-/* device-side counters: uint64 running totals, sharded to keep atomics off one address.
+/* device-side counters: uint64 running totals, one shard per wavefront slot of a launch.
  * buffers.counters is [NSG_CNT_COUNT][NSG_CNT_SHARDS]; a total is the sum over its shards.
- * Produced by wavefront ballots + popcounts, reduced per workgroup in LDS. */
+ * Produced by wavefront ballots + popcounts; every wavefront adds its counts to ITS OWN shard
+ * (workgroup index within the handle's launch range x 4 + wavefront index) with a plain
+ * read-modify-write: no atomics, no workgroup barrier.  Launch grids are capped at
+ * NSG_CNT_SHARDS / 4 workgroups so that a shard has exactly one owner per launch. */
 enum {
   NSG_CNT_DONE = 0,       /* episodes finished (terminated or truncated)                */
   NSG_CNT_FIRED = 1,      /* (env,param) updates applied (notification flags raised)    */
@@ -125,7 +131,7 @@ enum {
   NSG_CNT_STEPS = 3,      /* env transitions executed (autoreset lanes excluded)        */
   NSG_CNT_COUNT = 4
 };
-#define NSG_CNT_SHARDS 64
+#define NSG_CNT_SHARDS 16384
 
 /* One tunable parameter = (Scheduler, UpdateFn) pair: UpdateFn.__call__ (ns_gym/base.py:124-149). */
 typedef struct nsg_param_cfg {
@@ -319,6 +325,21 @@ int nsg_time_steps(nsg_handle* h, const void* actions_dev, int32_t iters, void* 
  * on a known byte count in the kernel's own access width): streams n float64 from src to dst
  * with one 8-byte access per lane, the access shape of the step kernels' state rows. */
 int nsg_calib_copy_f64(const double* src_dev, double* dst_dev, int64_t n, void* stream);
+
+/* Config-specialised kernels.  The generic kernels read nsg_config through scalar loads and branch
+ * on it at run time — the device-side equivalent of the reference's per-step Python dispatch over
+ * Scheduler / UpdateFn objects (ns_gym/base.py:124-149, classic_control.py:60-100).  nsg_specialize()
+ * compiles the SAME kernel bodies with the handle's nsg_config as a compile-time constant (hiprtc,
+ * sources embedded in the library, ~2-3 s once per distinct config per process; NSG_SPEC_CACHE=<dir>
+ * keeps the code objects on disk) and routes nsg_step / nsg_rollout of this handle through them.
+ * Results are bit-identical to the generic kernels.  Returns NSG_EUNSUPPORTED (generic path stays in
+ * force) when libhiprtc is missing or the compilation fails.
+ * nsg_spec_build compiles only (no GPU needed; arch e.g. "gfx950"): *code_out is a malloc'ed code
+ * object to be released with nsg_spec_free. */
+int nsg_specialize(nsg_handle* h);
+int nsg_is_specialized(const nsg_handle* h);
+int nsg_spec_build(const nsg_config* cfg, const char* arch, void** code_out, size_t* size_out);
+void nsg_spec_free(void* code);
 
 int nsg_destroy(nsg_handle* h);
 

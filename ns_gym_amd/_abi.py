@@ -40,7 +40,7 @@ ST_NEEDS_RESET = 0x1
 
 CNT_DONE, CNT_FIRED, CNT_VIOLATION, CNT_STEPS = 0, 1, 2, 3
 CNT_COUNT = 4
-CNT_SHARDS = 64
+CNT_SHARDS = 16384
 
 
 class ParamCfg(C.Structure):

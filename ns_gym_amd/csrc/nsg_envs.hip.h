@@ -10,7 +10,7 @@
 // like gymnasium); θ arrives as a fixed-size register array indexed only by compile-time
 // constants (slot order = ATTRIBUTE_MAP, ns_gym/base.py:611-635).
 #pragma once
-#include "../../include/nsgym_hip.h"
+#include "nsgym_hip.h"
 #include "nsg_math.hip.h"
 #include "nsg_rng.hip.h"
 

@@ -3,7 +3,7 @@
 // One launch = one wrapper step for every env instance:
 //   θ-schedule (schedulers + update fns)  ->  constraint checker  ->  dependency resolver
 //   ->  base-MDP transition  ->  t += 1 / TimeLimit  ->  notification ground truth  ->
-//   autoreset bookkeeping  ->  wave-ballot done mask + block-reduced counters,
+//   autoreset bookkeeping  ->  wave-ballot done mask + per-wavefront counters,
 // i.e. NSClassicControlWrapper.step (ns_gym/wrappers/classic_control.py:60-100) /
 // NSFrozenLakeWrapper.step (ns_gym/wrappers/toy_text.py:342-380) -> NSWrapper.step
 // (ns_gym/base.py:296-363) -> gymnasium step, for N envs at once.
@@ -15,7 +15,7 @@
 // map) are staged in LDS once per workgroup.  Workgroups touch disjoint env ranges, so the
 // blockIdx -> XCD mapping has no L2-sharing consequence and is left as dispatched.
 #pragma once
-#include "../../include/nsgym_hip.h"
+#include "nsgym_hip.h"
 #include "nsg_envs.hip.h"
 #include "nsg_rng.hip.h"
 #include "nsg_theta.hip.h"
@@ -25,6 +25,20 @@ namespace nsg {
 constexpr int kBlock = 256;
 constexpr int kMaxTableBytes = 16384;
 constexpr int kCntShards = NSG_CNT_SHARDS;
+// Where the helper lanes request the PCG64 records of the resetting envs: ahead of the θ-engine +
+// integrator work (the request's latency overlaps it, at the price of 8-10 live VGPRs) or after it.
+// Measured on MI355X (tools/ab.py): ahead wins for the generic plain-arithmetic kernels (C1 32.6 vs
+// 34.4 us); after wins for the full θ-engine (C2 50.4 vs 56.1 us: 122 instead of 133 VGPRs is one more
+// wavefront per SIMD) and for the config-specialised kernels (C1 28.4 vs 30.4 us: their compute
+// phase is too short to hide anything behind).
+#ifndef NSG_EARLY_DRAW
+#ifdef NSG_SPEC_BUILD
+#define NSG_EARLY_DRAW 0
+#else
+#define NSG_EARLY_DRAW 1
+#endif
+#endif
+template <bool FULL> constexpr bool kEarlyDraw = (NSG_EARLY_DRAW != 0) && !FULL;
 #ifndef NSG_MIN_WAVES
 #define NSG_MIN_WAVES 1
 #endif
@@ -50,10 +64,9 @@ struct ActionPtrs {
 
 // Dynamic LDS layout (sized per handle at launch: a batch with tiny tables must not pay 22 KB of
 // LDS per workgroup, which would cap residency at 6-7 workgroups per CU):
-//   [ cnt[4] | reset_n[2] | pad | reset_list[kBlock] (short) | reset_state[kBlock][4] (f64) |
+//   [ pad | reset_n[2] | pad | reset_list[kBlock] (short) | reset_state[kBlock][4] (f64) |
 //     table blob | ziggurat ki/wi/fi ]
 struct LdsTables {
-  unsigned* cnt;        // NSG_CNT_COUNT block-level counters
   int* reset_n;         // [2] workgroup-level compaction of the autoreset lanes (double-buffered)
   short* reset_list;    // [kBlock] lanes whose env resets in this chunk
   double* reset_state;  // [kBlock][4] initial states drawn by the helper lanes, read back by the owners
@@ -70,7 +83,6 @@ __host__ __device__ inline int lds_bytes_for(int table_bytes, int uses_normal, i
 __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, Tables& tb, ZigLds& zg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char nsg_dyn_lds[];
   unsigned char* base = nsg_dyn_lds;
-  lds.cnt = (unsigned*)base;
   lds.reset_n = (int*)(base + 16);
   lds.reset_list = (short*)(base + 32);
   lds.reset_state = (double*)(base + 32 + kBlock * 2);
@@ -87,7 +99,6 @@ __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, 
   const int words = (sg.table_bytes + 7) >> 3;
   const uint64_t* src = (const uint64_t*)sg.tables;
   for (int k = tid; k < words; k += kBlock) lds.blob[k] = src[k];
-  if (tid < NSG_CNT_COUNT) lds.cnt[tid] = 0;
   if (tid == 0) lds.reset_n[0] = lds.reset_n[1] = 0;
   __syncthreads();
   tb.base = (const uint8_t*)lds.blob;
@@ -113,23 +124,17 @@ __device__ __forceinline__ StepOut default_out(const nsg_buffers& b) {
   return StepOut{b.obs, b.reward, b.terminated, b.truncated, b.env_change, b.delta_change};
 }
 
-// Per-wave running counts (lane-uniform), flushed once per workgroup.
+// Per-wavefront running counts (lane-uniform), added to the wavefront's own counter shard when it retires.
 struct WaveCounts {
   unsigned done = 0, fired = 0, viol = 0, steps = 0;
 };
 
-__device__ __forceinline__ void flush_counts(const Segment& sg, LdsTables& lds, const WaveCounts& wc) {
-  if ((threadIdx.x & 63) == 0) {
-    if (wc.done) atomicAdd(&lds.cnt[NSG_CNT_DONE], wc.done);
-    if (wc.fired) atomicAdd(&lds.cnt[NSG_CNT_FIRED], wc.fired);
-    if (wc.viol) atomicAdd(&lds.cnt[NSG_CNT_VIOLATION], wc.viol);
-    if (wc.steps) atomicAdd(&lds.cnt[NSG_CNT_STEPS], wc.steps);
-  }
-  __syncthreads();
-  if (threadIdx.x < NSG_CNT_COUNT && sg.buf.counters) {
-    unsigned v = lds.cnt[threadIdx.x];
-    if (v) atomicAdd((unsigned long long*)&sg.buf.counters[threadIdx.x * kCntShards + (blockIdx.x % kCntShards)],
-                     (unsigned long long)v);
+// `block_rel` = workgroup index within the handle's launch range (< NSG_CNT_SHARDS / 4).
+__device__ __forceinline__ void flush_counts(uint64_t* counters, int block_rel, const WaveCounts& wc) {
+  const int lane = threadIdx.x & 63;
+  if (counters && lane < NSG_CNT_COUNT) {
+    const unsigned v = lane == NSG_CNT_DONE ? wc.done : lane == NSG_CNT_FIRED ? wc.fired : lane == NSG_CNT_VIOLATION ? wc.viol : wc.steps;
+    if (v) counters[(int64_t)lane * kCntShards + block_rel * (kBlock / 64) + (threadIdx.x >> 6)] += v;
   }
 }
 
@@ -177,11 +182,11 @@ template <int ENV> __device__ __forceinline__ bool own_constraint_violated(int s
 // (load = store = true); nsg_rollout keeps them in registers between the K fused steps of a launch
 // and touches HBM only on the first / last step.
 template <int ENV> struct LaneState {
-  double s[EnvTraits<ENV>::PHYS];
-  double th0, th1;   // θ rows 0 and 1 (rows >= 2 always go through memory)
-  int t;
-  unsigned st;
-  float er;
+  double s[EnvTraits<ENV>::PHYS] = {};
+  double th0 = 0.0, th1 = 0.0;   // θ rows 0 and 1 (rows >= 2 always go through memory)
+  int t = 0;
+  unsigned st = 0;
+  float er = 0.f;
 };
 struct IoMode {
   bool load, store;  // wave-uniform
@@ -229,13 +234,10 @@ __device__ __forceinline__ bool fire_param(const nsg_config& cfg, const nsg_buff
 //            instead of all of them.
 // ============================================================================================
 template <int ENV, bool FULL>
-__device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
+__device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buffers& b, const int64_t N, const Tables& tb, const ZigLds& zg, const void* actions,
                                            const StepOut& out, int64_t base, int parity, LdsTables& lds, WaveCounts& wc,
                                            LaneState<ENV>& ls, const IoMode io) {
   using T = EnvTraits<ENV>;
-  const nsg_config& cfg = sg.cfg;
-  const nsg_buffers& b = sg.buf;
-  const int64_t N = sg.N;
   const int P = cfg.n_params;
   const bool persistent = (cfg.flags & NSG_F_PERSISTENT_PARAMS) != 0;
   // planning copies (get_planning_env / __deepcopy__): θ frozen unless in_sim_change
@@ -247,11 +249,11 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
   const bool active = i < N;
 
   const uint32_t o1 = (uint32_t)i, o4 = o1 * 4u, o8 = o1 * 8u;  // per-lane byte offsets (N <= 2^27)
+  const bool track = (cfg.flags & NSG_F_TRACK_RETURNS) != 0;
   const unsigned st = !active ? 0u : io.load ? ldg(b.status, o1) : ls.st;
   const int t = !active ? 0 : io.load ? ldg(b.t, o4) : ls.t;
-  const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);  // next-step autoreset == reset(seed=None)
+  const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);
   const bool do_step = active && !do_reset;
-
   double s[T::PHYS];
 #pragma unroll
   for (int k = 0; k < T::PHYS; k++) s[k] = !do_step ? 0.0 : io.load ? ldg(b.phys + (int64_t)k * N, o8) : ls.s[k];
@@ -262,18 +264,38 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
     else ai = ldg((const int32_t*)actions, o4);
   }
   float er = 0.f;
-  const bool track = (cfg.flags & NSG_F_TRACK_RETURNS) != 0;
   if (track && do_step) er = io.load ? ldg(b.ep_return, o4) : ls.er;
+  double pre0 = 0.0, pre1 = 0.0;
+  if (active && P > 0) pre0 = io.load ? ldg(b.theta, o8) : ls.th0;
+  if (active && P > 1) pre1 = io.load ? ldg(b.theta + N, o8) : ls.th1;
+
+  // ---- compacted resets, part 1: queue the resetting envs; the helper lanes request their PCG64
+  // records.  Placed ahead of the θ-engine + integrator work (kEarlyDraw: the request's latency
+  // overlaps that work instead of sitting behind it on the workgroup's critical path) or after it.
+  int n_reset = 0, owner = 0;
+  bool helper = false;
+  Pcg g = {0, 0, 0, 0};
+  auto queue_resets = [&]() {
+    int* rn = lds.reset_n + (parity & 1);
+    if (do_reset) {
+      const int q = atomicAdd(rn, 1);
+      lds.reset_list[q] = (short)tid;
+    }
+    __syncthreads();
+    n_reset = *rn;
+    if (tid == 0) lds.reset_n[(parity + 1) & 1] = 0;  // the other buffer is idle until the next chunk
+    helper = tid < n_reset;
+    if (helper) {
+      owner = lds.reset_list[tid];
+      pcg_load(b.rng_env, N, base + owner, g);
+    }
+  };
+  if constexpr (kEarlyDraw<FULL>) queue_resets();
 
   double th[T::NTHETA + T::NDERIVED];
 #pragma unroll
   for (int k = 0; k < T::NTHETA; k++) th[k] = cfg.base_theta[k];
   unsigned n_fired = 0, n_viol = 0;
-  // the first two θ rows are fetched together with the state rows (one memory latency on the wave's
-  // critical path instead of two); further rows are fetched inside the loop
-  double pre0 = 0.0, pre1 = 0.0;
-  if (active && P > 0) pre0 = io.load ? ldg(b.theta, o8) : ls.th0;
-  if (active && P > 1) pre1 = io.load ? ldg(b.theta + N, o8) : ls.th1;
 
   if constexpr (ENV != NSG_ENV_ACROBOT) {
     // ---- single pass: propose, check, commit (classic_control.py:80-92) ----------------------
@@ -316,7 +338,7 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
         if (p > 1 ? fin != c : (io.store && (fin != c || !io.load))) stg(b.theta + (int64_t)p * N, o8, fin);
         stg(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
         stg(out.delta_change + (int64_t)p * N, o4, (float)delta);
-        if (b.violation) stg(b.violation + (int64_t)p * N, o1, (uint8_t)(rejected && do_step ? 1 : 0));
+        if (cfg.flags & NSG_F_VIOLATION_MASK) stg(b.violation + (int64_t)p * N, o1, (uint8_t)(rejected && do_step ? 1 : 0));
       }
       n_fired += fired ? 1u : 0u;
     }
@@ -381,7 +403,7 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
         if (p > 1 ? fin != c : (io.store && (fin != c || !io.load))) stg(b.theta + (int64_t)p * N, o8, fin);
         stg(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
         stg(out.delta_change + (int64_t)p * N, o4, (float)delta);
-        if (b.violation) stg(b.violation + (int64_t)p * N, o1, (uint8_t)(rejected && do_step ? 1 : 0));
+        if (cfg.flags & NSG_F_VIOLATION_MASK) stg(b.violation + (int64_t)p * N, o1, (uint8_t)(rejected && do_step ? 1 : 0));
       }
       n_fired += fired ? 1u : 0u;
     }
@@ -411,22 +433,11 @@ __device__ __forceinline__ void step_chunk(const Segment& sg, const Tables& tb, 
   const bool done = term || trunc;
 
   // ---- compacted resets: queue -> helper lanes draw -> owners read back ----------------------
-  int* rn = lds.reset_n + (parity & 1);
-  if (do_reset) {
-    const int q = atomicAdd(rn, 1);
-    lds.reset_list[q] = (short)tid;
-  }
-  __syncthreads();
-  const int n_reset = *rn;
-  if (tid == 0) lds.reset_n[(parity + 1) & 1] = 0;  // the other buffer is idle until the next chunk
-  if (tid < n_reset) {  // gymnasium reset(): np_random draws of the initial state [UPSTREAM]
-    const int owner = lds.reset_list[tid];
-    const int64_t j = base + owner;
-    Pcg g;
-    pcg_load(b.rng_env, N, j, g);
+  if constexpr (!kEarlyDraw<FULL>) queue_resets();
+  if (helper) {  // gymnasium reset(): np_random draws of the initial state [UPSTREAM]
     double r0[T::PHYS];
     env_reset_draw<ENV>(g, r0);
-    pcg_store_state(b.rng_env, N, j, g);
+    pcg_store_state(b.rng_env, N, base + owner, g);
 #pragma unroll
     for (int k = 0; k < T::PHYS; k++) lds.reset_state[owner * 4 + k] = r0[k];
   }
@@ -495,12 +506,9 @@ __device__ __forceinline__ int grid_start_state(const nsg_config& cfg, const uin
 }
 
 template <int ENV, bool FULL>
-__device__ __forceinline__ void step_grid(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
+__device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffers& b, const int64_t N, const Tables& tb, const ZigLds& zg, const void* actions,
                                           const StepOut& out, int64_t i, bool active, WaveCounts& wc) {
   constexpr int ND = ENV == NSG_ENV_CLIFFWALKING ? 4 : 3;
-  const nsg_config& cfg = sg.cfg;
-  const nsg_buffers& b = sg.buf;
-  const int64_t N = sg.N;
   const int P = cfg.n_params;
   const bool persistent = (cfg.flags & NSG_F_PERSISTENT_PARAMS) != 0;
   const bool sim = (cfg.flags & NSG_F_SIM_ENV) != 0;
@@ -695,33 +703,40 @@ __device__ __forceinline__ void step_grid(const Segment& sg, const Tables& tb, c
 
 // One chunk of kBlock envs of any env type (block-level call: contains workgroup barriers).
 template <int ENV, bool FULL>
-__device__ __forceinline__ void step_block(const Segment& sg, const Tables& tb, const ZigLds& zg, const void* actions,
+__device__ __forceinline__ void step_block(const nsg_config& cfg, const nsg_buffers& b, const int64_t N, const Tables& tb, const ZigLds& zg, const void* actions,
                                            const StepOut& out, int64_t base, int parity, LdsTables& lds, WaveCounts& wc) {
   // single step: every persistent row round-trips through memory
   if constexpr (ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE) {
     const int64_t i = base + threadIdx.x;
-    step_grid<ENV, FULL>(sg, tb, zg, actions, out, i, i < sg.N, wc);
+    step_grid<ENV, FULL>(cfg, b, N, tb, zg, actions, out, i, i < N, wc);
   } else {
     LaneState<ENV> ls;
-    step_chunk<ENV, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc, ls, IoMode{true, true});
+    step_chunk<ENV, FULL>(cfg, b, N, tb, zg, actions, out, base, parity, lds, wc, ls, IoMode{true, true});
   }
 }
 
-// Homogeneous launch: grid-stride over 256-env chunks.
+// Homogeneous launch: grid-stride over 256-env chunks.  `cfg` is the segment's own copy (generic
+// kernels, scalar loads) or a compile-time constant of a config-specialised build (nsg_spec.hip.h).
 template <int ENV, bool FULL>
-__global__ __launch_bounds__(kBlock, NSG_MIN_WAVES) void step_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions) {
+__device__ __forceinline__ void step_body(const nsg_config& cfg, const Segment& sg, const void* __restrict__ actions) {
   LdsTables lds;
-  const Segment& sg = *seg;
   Tables tb;
   ZigLds zg;
   stage_tables(sg, lds, tb, zg);
   WaveCounts wc;
-  const StepOut out = default_out(sg.buf);
-  const int64_t chunks = (sg.N + kBlock - 1) / kBlock;
+  const nsg_buffers& b = sg.buf;
+  const int64_t N = sg.N;
+  const StepOut out = default_out(b);
+  const int64_t chunks = (N + kBlock - 1) / kBlock;
   int parity = 0;
   for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x, parity ^= 1)
-    step_block<ENV, FULL>(sg, tb, zg, actions, out, c * kBlock, parity, lds, wc);
-  flush_counts(sg, lds, wc);
+    step_block<ENV, FULL>(cfg, b, N, tb, zg, actions, out, c * kBlock, parity, lds, wc);
+  flush_counts(b.counters, (int)blockIdx.x, wc);
+}
+
+template <int ENV, bool FULL>
+__global__ __launch_bounds__(kBlock, NSG_MIN_WAVES) void step_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions) {
+  step_body<ENV, FULL>(seg->cfg, *seg, actions);
 }
 
 // Heterogeneous launch: block ranges are assigned to env-type segments, so the env-type switch
@@ -744,17 +759,17 @@ __global__ __launch_bounds__(kBlock) void step_group_kernel(const Segment* __res
   for (int64_t c = (int)blockIdx.x - sg.block_begin; c < chunks; c += sg.block_count, parity ^= 1) {
     const int64_t base = c * kBlock;
     switch (sg.cfg.env_type) {
-      case NSG_ENV_CARTPOLE: step_block<NSG_ENV_CARTPOLE, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
-      case NSG_ENV_PENDULUM: step_block<NSG_ENV_PENDULUM, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
-      case NSG_ENV_ACROBOT: step_block<NSG_ENV_ACROBOT, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
-      case NSG_ENV_MOUNTAINCAR: step_block<NSG_ENV_MOUNTAINCAR, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
-      case NSG_ENV_MOUNTAINCAR_CONT: step_block<NSG_ENV_MOUNTAINCAR_CONT, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
-      case NSG_ENV_FROZENLAKE: step_block<NSG_ENV_FROZENLAKE, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
-      case NSG_ENV_CLIFFWALKING: step_block<NSG_ENV_CLIFFWALKING, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
-      default: step_block<NSG_ENV_BRIDGE, FULL>(sg, tb, zg, actions, out, base, parity, lds, wc); break;
+      case NSG_ENV_CARTPOLE: step_block<NSG_ENV_CARTPOLE, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
+      case NSG_ENV_PENDULUM: step_block<NSG_ENV_PENDULUM, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
+      case NSG_ENV_ACROBOT: step_block<NSG_ENV_ACROBOT, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
+      case NSG_ENV_MOUNTAINCAR: step_block<NSG_ENV_MOUNTAINCAR, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
+      case NSG_ENV_MOUNTAINCAR_CONT: step_block<NSG_ENV_MOUNTAINCAR_CONT, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
+      case NSG_ENV_FROZENLAKE: step_block<NSG_ENV_FROZENLAKE, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
+      case NSG_ENV_CLIFFWALKING: step_block<NSG_ENV_CLIFFWALKING, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
+      default: step_block<NSG_ENV_BRIDGE, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
     }
   }
-  flush_counts(sg, lds, wc);
+  flush_counts(sg.buf.counters, (int)blockIdx.x - sg.block_begin, wc);
 }
 
 // ============================================================================================
@@ -844,6 +859,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
   }
 }
 
+#ifndef NSG_SPEC_BUILD  // a config-specialised unit carries only its step / rollout kernels
 // Construction-time state (what the wrapper constructors set up): θ = construction values,
 // fresh cursors, FrozenLake P table from initial_prob_dist, update-fn streams
 // default_rng(fn.seed) (single_param.py:76,108,146,342,444), zeroed outputs / counters.
@@ -1107,5 +1123,7 @@ __global__ __launch_bounds__(kBlock) void seed_streams_kernel(const Segment* __r
 __global__ __launch_bounds__(kBlock) void calib_copy_f64_kernel(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) dst[i] = src[i] + 1.0;
 }
+
+#endif  // NSG_SPEC_BUILD
 
 }  // namespace nsg

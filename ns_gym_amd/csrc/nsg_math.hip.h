@@ -14,7 +14,9 @@
 #else
 #define NSG_HD inline
 #endif
+#ifndef __HIPCC_RTC__
 #include <math.h>
+#endif
 
 namespace nsg {
 
@@ -97,7 +99,7 @@ NSG_HD double nsg_exp(double x) {
                P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
                P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
   if (x != x) return x;
-  if (x > 7.09782712893383973096e+02) return INFINITY;
+  if (x > 7.09782712893383973096e+02) return __builtin_inf();
   if (x < -7.45133219101941108420e+02) return 0.0;
   const double kf = rint(x * invln2);
   const int k = (int)kf;
@@ -116,9 +118,9 @@ NSG_HD double nsg_log1p(double x) {
                Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
                Lp7 = 1.479819860511658591e-01;
   if (x != x) return x;
-  if (x < -1.0) return NAN;
-  if (x == -1.0) return -INFINITY;
-  if (x == INFINITY) return x;
+  if (x < -1.0) return __builtin_nan("");
+  if (x == -1.0) return -__builtin_inf();
+  if (x == __builtin_inf()) return x;
   const double ax = fabs(x);
   if (ax < 5.55111512312578270212e-17) return x;  // |x| < 2^-54
   int k = 1;

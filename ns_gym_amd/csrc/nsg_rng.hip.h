@@ -12,8 +12,10 @@
 // The ziggurat tables (6 KiB) are staged in LDS once per workgroup: lookups are per-lane
 // random indices, which LDS serves at full rate and HBM/L2 would not.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "nsg_math.hip.h"
 

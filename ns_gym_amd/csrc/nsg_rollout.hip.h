@@ -12,17 +12,17 @@
 namespace nsg {
 
 template <int ENV, bool FULL>
-__global__ __launch_bounds__(kBlock) void rollout_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions,
-                                                         int k_steps, nsg_rollout_out ro) {
+__device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segment& sg, const void* __restrict__ actions,
+                                             int k_steps, const nsg_rollout_out& ro) {
   LdsTables lds;
-  const Segment& sg = *seg;
   Tables tb;
   ZigLds zg;
   stage_tables(sg, lds, tb, zg);
   WaveCounts wc;
+  const nsg_buffers& b = sg.buf;
   const int64_t N = sg.N;
-  const int P = sg.cfg.n_params > 0 ? sg.cfg.n_params : 1;
-  const StepOut dflt = default_out(sg.buf);
+  const int P = cfg.n_params > 0 ? cfg.n_params : 1;
+  const StepOut dflt = default_out(b);
   constexpr bool GRID = ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE;
   constexpr int D = GRID ? 1 : EnvTraits<GRID ? NSG_ENV_CARTPOLE : ENV>::OBS;
   constexpr bool FA = ENV == NSG_ENV_PENDULUM || ENV == NSG_ENV_MOUNTAINCAR_CONT;
@@ -48,14 +48,20 @@ __global__ __launch_bounds__(kBlock) void rollout_kernel(const Segment* __restri
       }
       const void* act = FA ? (const void*)((const float*)actions + (int64_t)k * N) : (const void*)((const int32_t*)actions + (int64_t)k * N);
       if constexpr (GRID) {
-        step_block<ENV, FULL>(sg, tb, zg, act, out, c * kBlock, parity, lds, wc);
+        step_block<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc);
       } else {
-        step_chunk<ENV, FULL>(sg, tb, zg, act, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, k == k_steps - 1});
+        step_chunk<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, k == k_steps - 1});
       }
       parity ^= 1;
     }
   }
-  flush_counts(sg, lds, wc);
+  flush_counts(b.counters, (int)blockIdx.x, wc);
+}
+
+template <int ENV, bool FULL>
+__global__ __launch_bounds__(kBlock) void rollout_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions,
+                                                         int k_steps, nsg_rollout_out ro) {
+  rollout_body<ENV, FULL>(seg->cfg, *seg, actions, k_steps, ro);
 }
 
 }  // namespace nsg

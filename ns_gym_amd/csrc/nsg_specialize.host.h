@@ -1,0 +1,201 @@
+// nsg_specialize.host.h — config-specialised code objects (host side only).
+//
+// The generic kernels read the wrapper configuration (nsg_config: scheduler / update-fn kinds, θ slots,
+// flags, TimeLimit …) through scalar loads and branch on it; for a batch whose configuration is fixed for
+// millions of steps that is ~45 % of the scalar + vector instructions of a CartPole step.  nsg_specialize()
+// re-compiles THE SAME kernel bodies (step_body / rollout_body, nsg_kernels.hip.h / nsg_rollout.hip.h)
+// with the handle's nsg_config as a compile-time constant, through hiprtc, into a gfx950 code object:
+// the per-param loop unrolls, every kind switch folds, the config loads disappear.  Results are
+// bit-identical to the generic kernels (same source, same -ffp-contract=off), tests/test_gpu_specialized.py.
+//
+// The kernel sources travel inside libnsgym_hip.so (.incbin below), so the library stays a
+// self-contained drop-in; libhiprtc is dlopen'ed on first use (the generic path never needs it).
+#pragma once
+
+#include <dlfcn.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+#define NSG_EMBED(sym, file)                                                                      \
+  __asm__(".pushsection .rodata\n.global " #sym "\n.type " #sym ", @object\n" #sym ":\n.incbin \"" file \
+          "\"\n.byte 0\n.size " #sym ", .-" #sym "\n.popsection\n")
+NSG_EMBED(nsg_src_abi, "../../include/nsgym_hip.h");
+NSG_EMBED(nsg_src_math, "nsg_math.hip.h");
+NSG_EMBED(nsg_src_rng, "nsg_rng.hip.h");
+NSG_EMBED(nsg_src_theta, "nsg_theta.hip.h");
+NSG_EMBED(nsg_src_envs, "nsg_envs.hip.h");
+NSG_EMBED(nsg_src_kernels, "nsg_kernels.hip.h");
+NSG_EMBED(nsg_src_rollout, "nsg_rollout.hip.h");
+#endif
+extern "C" {
+extern const char nsg_src_abi[], nsg_src_math[], nsg_src_rng[], nsg_src_theta[], nsg_src_envs[], nsg_src_kernels[],
+    nsg_src_rollout[];
+}
+
+namespace nsg_spec {
+
+// ---- hiprtc through dlopen ---------------------------------------------------------------------
+typedef struct _hiprtcProgram* rtcProgram;
+struct Rtc {
+  void* lib = nullptr;
+  int (*create)(rtcProgram*, const char*, const char*, int, const char* const*, const char* const*) = nullptr;
+  int (*compile)(rtcProgram, int, const char* const*) = nullptr;
+  int (*log_size)(rtcProgram, size_t*) = nullptr;
+  int (*log)(rtcProgram, char*) = nullptr;
+  int (*code_size)(rtcProgram, size_t*) = nullptr;
+  int (*code)(rtcProgram, char*) = nullptr;
+  int (*destroy)(rtcProgram*) = nullptr;
+};
+
+inline const Rtc* rtc() {
+  static Rtc r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7"};
+    for (const char* n : names) {
+      r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return;
+#define NSG_SYM(field, name) r.field = (decltype(r.field))dlsym(r.lib, name)
+    NSG_SYM(create, "hiprtcCreateProgram");
+    NSG_SYM(compile, "hiprtcCompileProgram");
+    NSG_SYM(log_size, "hiprtcGetProgramLogSize");
+    NSG_SYM(log, "hiprtcGetProgramLog");
+    NSG_SYM(code_size, "hiprtcGetCodeSize");
+    NSG_SYM(code, "hiprtcGetCode");
+    NSG_SYM(destroy, "hiprtcDestroyProgram");
+#undef NSG_SYM
+    if (!r.create || !r.compile || !r.log_size || !r.log || !r.code_size || !r.code || !r.destroy) {
+      dlclose(r.lib);
+      r.lib = nullptr;
+    }
+  });
+  return r.lib ? &r : nullptr;
+}
+
+// ---- the specialised translation unit ----------------------------------------------------------
+// The config is emitted as its raw 64-bit words (independent of the struct's field list) and viewed
+// as nsg_config; after inlining every access is a load from a constant at a constant offset.
+inline std::string spec_source(const nsg_config& cfg, bool full) {
+  static_assert(sizeof(nsg_config) % 8 == 0, "nsg_config is emitted as 64-bit words");
+  std::string s;
+  s.reserve(16384);
+  s +=
+      "typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
+      "typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t;\n"
+      "typedef unsigned long size_t;\n"
+      "#define NSG_SPEC_BUILD 1\n"
+      "#include \"nsg_rollout.hip.h\"\n"
+      "namespace nsg {\n"
+      "__device__ const uint64_t kCfgWords[] = {\n";
+  const uint64_t* w = reinterpret_cast<const uint64_t*>(&cfg);
+  char buf[40];
+  for (size_t k = 0; k < sizeof(nsg_config) / 8; k++) {
+    snprintf(buf, sizeof(buf), "0x%016llxull,%s", (unsigned long long)w[k], (k % 4 == 3) ? "\n" : " ");
+    s += buf;
+  }
+  s += "};\n}  // namespace nsg\n";
+  snprintf(buf, sizeof(buf), "%d, %s", (int)cfg.env_type, full ? "true" : "false");
+  const std::string targs = buf;
+  s += "#define NSG_SPEC_CFG (*reinterpret_cast<const nsg_config*>(nsg::kCfgWords))\n"
+       "extern \"C\" __global__ __launch_bounds__(256) void nsg_spec_step(const nsg::Segment* __restrict__ seg,\n"
+       "                                                                const void* __restrict__ actions) {\n"
+       "  nsg::step_body<" + targs + ">(NSG_SPEC_CFG, *seg, actions);\n"
+       "}\n"
+       "extern \"C\" __global__ __launch_bounds__(256) void nsg_spec_rollout(const nsg::Segment* __restrict__ seg,\n"
+       "                                                                   const void* __restrict__ actions, int k_steps,\n"
+       "                                                                   nsg_rollout_out ro) {\n"
+       "  nsg::rollout_body<" + targs + ">(NSG_SPEC_CFG, *seg, actions, k_steps, ro);\n"
+       "}\n";
+  return s;
+}
+
+// Compile the specialised unit for `arch` (e.g. "gfx950"); no GPU needed.  Returns "" and fills `err` on failure.
+inline std::vector<char> spec_compile(const nsg_config& cfg, bool full, const char* arch, std::string& err) {
+  std::vector<char> code;
+  const Rtc* r = rtc();
+  if (!r) {
+    err = "libhiprtc.so could not be loaded (config specialisation needs the ROCm runtime compiler)";
+    return code;
+  }
+  const std::string src = spec_source(cfg, full);
+  const char* headers[] = {nsg_src_abi, nsg_src_math, nsg_src_rng, nsg_src_theta, nsg_src_envs, nsg_src_kernels, nsg_src_rollout};
+  const char* names[] = {"nsgym_hip.h",    "nsg_math.hip.h",    "nsg_rng.hip.h",    "nsg_theta.hip.h",
+                         "nsg_envs.hip.h", "nsg_kernels.hip.h", "nsg_rollout.hip.h"};
+  rtcProgram prog = nullptr;
+  if (r->create(&prog, src.c_str(), "nsg_spec.hip", 7, headers, names) != 0) {
+    err = "hiprtcCreateProgram failed";
+    return code;
+  }
+  const std::string archopt = std::string("--offload-arch=") + arch;
+  // the same flags as the library build (csrc/Makefile): contraction off keeps the float64 rounding sequence
+  std::vector<const char*> opts = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function"};
+  // tuning knob (tools/ab.py): extra -D / -m options for the specialised unit, space-separated
+  std::vector<std::string> extra;
+  if (const char* e = getenv("NSG_SPEC_FLAGS")) {
+    std::string cur;
+    for (const char* c = e;; c++) {
+      if (*c == ' ' || *c == '\0') {
+        if (!cur.empty()) extra.push_back(cur);
+        cur.clear();
+        if (!*c) break;
+      } else {
+        cur += *c;
+      }
+    }
+  }
+  for (const std::string& x : extra) opts.push_back(x.c_str());
+  const int rc = r->compile(prog, (int)opts.size(), opts.data());
+  if (rc != 0) {
+    size_t n = 0;
+    r->log_size(prog, &n);
+    std::string log(n + 1, '\0');
+    if (n) r->log(prog, &log[0]);
+    err = "hiprtc compilation failed:\n" + log.substr(0, 1500);
+    r->destroy(&prog);
+    return code;
+  }
+  size_t n = 0;
+  r->code_size(prog, &n);
+  code.resize(n);
+  if (n) r->code(prog, code.data());
+  r->destroy(&prog);
+  if (code.empty()) err = "hiprtc produced an empty code object";
+  return code;
+}
+
+inline uint64_t fnv1a(const void* p, size_t n, uint64_t h = 0xcbf29ce484222325ull) {
+  const unsigned char* b = (const unsigned char*)p;
+  for (size_t k = 0; k < n; k++) h = (h ^ b[k]) * 0x100000001b3ull;
+  return h;
+}
+
+// One loaded code object per (device, config): shared by every handle with the same configuration.
+struct Module {
+  hipModule_t mod = nullptr;
+  hipFunction_t step = nullptr, rollout = nullptr;
+};
+
+struct Key {
+  int device;
+  uint64_t h0, h1;
+  bool operator<(const Key& o) const {
+    return device != o.device ? device < o.device : h0 != o.h0 ? h0 < o.h0 : h1 < o.h1;
+  }
+};
+
+inline std::map<Key, Module>& cache() {
+  static std::map<Key, Module> m;
+  return m;
+}
+inline std::mutex& cache_mutex() {
+  static std::mutex m;
+  return m;
+}
+
+}  // namespace nsg_spec

@@ -13,7 +13,7 @@
 // order; the translation unit is compiled with -ffp-contract=off so a*b+c rounds twice like
 // Python floats (Increment/Decrement/W1 results are bit-identical to the reference).
 #pragma once
-#include "../../include/nsgym_hip.h"
+#include "nsgym_hip.h"
 #include "nsg_rng.hip.h"
 
 namespace nsg {

@@ -8,11 +8,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <unistd.h>
 
-#include "../../include/nsg_zig_tables.inc"
-#include "../../include/nsgym_hip.h"
+#include "nsg_zig_tables.inc"
+#include "nsgym_hip.h"
 #include "nsg_kernels.hip.h"
 #include "nsg_rollout.hip.h"
+#include "nsg_specialize.host.h"
 
 using namespace nsg;
 
@@ -116,6 +118,7 @@ struct nsg_handle {
   int64_t n;
   bool bound;
   int device;
+  const nsg_spec::Module* spec;  // config-specialised step / rollout kernels (nsg_specialize), or NULL
 };
 
 extern "C" {
@@ -230,7 +233,7 @@ static int grid_cap() {  // tuning knob (tools/kbench.py sweeps it); default fro
   if (!cap) {
     const char* e = getenv("NSG_GRID_CAP");
     cap = e ? atoi(e) : 4096;
-    if (cap < 1) cap = 4096;
+    if (cap < 1 || cap > NSG_CNT_SHARDS / (kBlock / 64)) cap = NSG_CNT_SHARDS / (kBlock / 64);  // one counter shard per wavefront slot
   }
   return cap;
 }
@@ -288,7 +291,10 @@ int nsg_step(nsg_handle* h, const void* actions_dev, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int grid = grid_for(h->n);
   const size_t lds = (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp);
-  if (h->host.simple_theta) {
+  if (h->spec) {
+    void* args[] = {(void*)&h->dev, (void*)&actions_dev};
+    HIP_TRY(hipModuleLaunchKernel(h->spec->step, grid, 1, 1, kBlock, 1, 1, (unsigned)lds, s, args, nullptr));
+  } else if (h->host.simple_theta) {
     DISPATCH_ENV(h->host.cfg.env_type,
                  hipLaunchKernelGGL((step_kernel<E, false>), dim3(grid), dim3(kBlock), lds, s, h->dev, actions_dev));
   } else {
@@ -307,7 +313,11 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
   memset(&o, 0, sizeof(o));
   if (out) o = *out;
   hipStream_t s = (hipStream_t)stream;
-  if (h->host.simple_theta) {
+  if (h->spec) {
+    void* args[] = {(void*)&h->dev, (void*)&actions_dev, (void*)&k_steps, (void*)&o};
+    HIP_TRY(hipModuleLaunchKernel(h->spec->rollout, grid_for(h->n), 1, 1, kBlock, 1, 1,
+                                  (unsigned)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp), s, args, nullptr));
+  } else if (h->host.simple_theta) {
     DISPATCH_ENV(h->host.cfg.env_type,
                  hipLaunchKernelGGL((rollout_kernel<E, false>), dim3(grid_for(h->n)), dim3(kBlock), (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp), s, h->dev, actions_dev, k_steps, o));
   } else {
@@ -476,6 +486,91 @@ int nsg_calib_copy_f64(const double* src_dev, double* dst_dev, int64_t n, void* 
   HIP_TRY(hipGetLastError());
   return NSG_OK;
 }
+
+/* ---- config-specialised code objects (nsg_specialize.host.h) ---------------------------------- */
+int nsg_spec_build(const nsg_config* cfg, const char* arch, void** code_out, size_t* size_out) {
+  if (!code_out || !size_out) return fail(NSG_EINVAL, "NULL output argument");
+  *code_out = nullptr;
+  *size_out = 0;
+  int rc = validate(cfg, 0);
+  if (rc) return rc;
+  bool full = false;
+  for (int p = 0; p < cfg->n_params; p++)
+    if (!upd_kind_is_simple(cfg->params[p].upd_kind) || sched_is_stochastic(cfg->params[p].sched_kind)) full = true;
+  std::string err;
+  std::vector<char> code = nsg_spec::spec_compile(*cfg, full, arch && *arch ? arch : "gfx950", err);
+  if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
+  void* p = malloc(code.size());
+  if (!p) return fail(NSG_ENOMEM, "out of host memory");
+  memcpy(p, code.data(), code.size());
+  *code_out = p;
+  *size_out = code.size();
+  return NSG_OK;
+}
+
+void nsg_spec_free(void* code) { free(code); }
+
+int nsg_specialize(nsg_handle* h) {
+  if (!h) return fail(NSG_EINVAL, "handle is NULL");
+  if (h->spec) return NSG_OK;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+  const bool full = !h->host.simple_theta;
+  // key: config bytes + engine variant + target + the kernel sources this library was built from
+  uint64_t h0 = nsg_spec::fnv1a(&h->host.cfg, sizeof(nsg_config));
+  h0 = nsg_spec::fnv1a(&full, sizeof(full), h0);
+  h0 = nsg_spec::fnv1a(prop.gcnArchName, strlen(prop.gcnArchName), h0);
+  if (const char* e = getenv("NSG_SPEC_FLAGS")) h0 = nsg_spec::fnv1a(e, strlen(e), h0);
+  uint64_t h1 = 0x9e3779b97f4a7c15ull;
+  for (const char* src : {nsg_src_abi, nsg_src_math, nsg_src_rng, nsg_src_theta, nsg_src_envs, nsg_src_kernels, nsg_src_rollout})
+    h1 = nsg_spec::fnv1a(src, strlen(src), h1);
+  const nsg_spec::Key key{h->device, h0, h1};
+  std::lock_guard<std::mutex> lock(nsg_spec::cache_mutex());
+  auto& cache = nsg_spec::cache();
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    std::vector<char> code;
+    // optional on-disk cache of code objects: NSG_SPEC_CACHE=<dir>
+    std::string path;
+    if (const char* dir = getenv("NSG_SPEC_CACHE")) {
+      char name[64];
+      snprintf(name, sizeof(name), "/nsg_%016llx_%016llx.hsaco", (unsigned long long)h0, (unsigned long long)h1);
+      path = std::string(dir) + name;
+      if (FILE* f = fopen(path.c_str(), "rb")) {
+        fseek(f, 0, SEEK_END);
+        const long n = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        if (n > 0) {
+          code.resize((size_t)n);
+          if (fread(code.data(), 1, (size_t)n, f) != (size_t)n) code.clear();
+        }
+        fclose(f);
+      }
+    }
+    if (code.empty()) {
+      std::string err;
+      code = nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err);
+      if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
+      if (!path.empty()) {
+        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+        if (FILE* f = fopen(tmp.c_str(), "wb")) {
+          const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+          fclose(f);
+          if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
+        }
+      }
+    }
+    nsg_spec::Module m;
+    HIP_TRY(hipModuleLoadData(&m.mod, code.data()));
+    HIP_TRY(hipModuleGetFunction(&m.step, m.mod, "nsg_spec_step"));
+    HIP_TRY(hipModuleGetFunction(&m.rollout, m.mod, "nsg_spec_rollout"));
+    it = cache.emplace(key, m).first;
+  }
+  h->spec = &it->second;
+  return NSG_OK;
+}
+
+int nsg_is_specialized(const nsg_handle* h) { return h && h->spec ? 1 : 0; }
 
 int nsg_destroy(nsg_handle* h) {
   if (!h) return NSG_OK;

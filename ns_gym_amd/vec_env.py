@@ -40,8 +40,11 @@ class VecNSEnv:
     def __init__(self, env, tunable_params: dict, num_envs: int, change_notification: bool = False,
                  delta_change_notification: bool = False, in_sim_change: bool = False, scalar_reward: bool = True,
                  persistent_params: bool = False, track_returns: bool = False, device=None, is_sim_env: bool = False,
-                 violation_mask: bool = False,
+                 violation_mask: bool = False, specialize: bool = False,
                  **kwargs):
+        """`specialize=True` compiles config-specialised step / rollout kernels for this batch (hiprtc, once per
+        distinct configuration per process, ~1 s; `NSG_SPEC_CACHE=<dir>` keeps them on disk): same results,
+        ~10-20 % less time per step.  Worth it for long runs; the generic kernels need no compilation."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.NsgError("VecNSEnv needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
@@ -54,7 +57,7 @@ class VecNSEnv:
         self._ctor = dict(env=env, tunable_params=tunable_params, num_envs=num_envs, change_notification=change_notification,
                           delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
                           scalar_reward=scalar_reward, persistent_params=persistent_params, track_returns=track_returns,
-                          device=device, violation_mask=violation_mask, **kwargs)
+                          device=device, violation_mask=violation_mask, specialize=specialize, **kwargs)
         self.tunable_params = tunable_params
         self.change_notification = change_notification
         self.delta_change_notification = delta_change_notification
@@ -86,6 +89,8 @@ class VecNSEnv:
                        "nsg_create")
             self._h = h
             _lib.check(self.lib.nsg_bind(self._h, C.byref(self._bufs)), "nsg_bind")
+            if specialize:
+                self.specialize()
         self._make_views()
         from . import spaces
 
@@ -95,6 +100,16 @@ class VecNSEnv:
         self.observation_space, self.action_space = self.single_observation_space, self.single_action_space
         self._zero_flags = None
         self._viol_seen = 0
+
+    def specialize(self):
+        """Route this batch's step()/rollout() through kernels compiled for ITS configuration (nsg_specialize)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nsg_specialize(self._h), "nsg_specialize")
+        return self
+
+    @property
+    def specialized(self) -> bool:
+        return bool(self.lib.nsg_is_specialized(self._h))
 
     # ------------------------------------------------------------------ tensor views
     def _make_views(self):

@@ -1066,13 +1066,13 @@ int orc_step_mt(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers*
   uint64_t* total = b->counters;
 #pragma omp parallel for num_threads(nthreads) schedule(static)
   for (int th = 0; th < nthreads; th++) {
-    uint64_t cnt[NSG_CNT_COUNT * NSG_CNT_SHARDS];
-    memset(cnt, 0, sizeof(cnt));
+    uint64_t* cnt = (uint64_t*)calloc((size_t)NSG_CNT_COUNT * NSG_CNT_SHARDS, sizeof(uint64_t));
     int64_t per = ((N + nthreads - 1) / nthreads + 63) & ~63LL; /* 64-aligned: done_bits words stay thread-private */
     int64_t lo = th * per, hi = lo + per < N ? lo + per : N;
     for (int64_t i = lo; i < hi; i++) step_one(cfg, tables, b, N, i, actions, cnt);
     for (int c = 0; c < NSG_CNT_COUNT; c++)
       __atomic_fetch_add(&total[c * NSG_CNT_SHARDS], cnt[c * NSG_CNT_SHARDS], __ATOMIC_RELAXED);
+    free(cnt);
   }
   return 0;
 }

@@ -1,19 +1,31 @@
 #!/usr/bin/env python3
-"""Interleaved A/B timing of library builds (one subprocess per build per round, same box)."""
+"""Interleaved A/B timing of library builds (one subprocess per variant per round, same box).
+
+    tools/ab.py VARIANTS [WORK] [ROUNDS]
+    VARIANT = <build>[:spec[:<hiprtc flags>]]   build = tools/exp_<build>.so ("lib" = the in-tree library)
+e.g.  tools/ab.py lib,lib:spec,lib:spec:-DNSG_BATCH_LOADS=0 c1 3
+"""
 import json, os, subprocess, sys
-builds = sys.argv[1].split(",")
+variants = sys.argv[1].split(",")
 work = sys.argv[2] if len(sys.argv) > 2 else "c1"
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-res = {b: [] for b in builds}
+res = {b: [] for b in variants}
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for r in range(rounds):
-    for b in builds:
-        env = dict(os.environ, NSG_LIB=os.path.join(root, "tools", f"exp_{b}.so"))
-        out = subprocess.run([sys.executable, os.path.join(root, "tools", "kbench.py"), "--work", work, "--iters", "300"],
-                             env=env, capture_output=True, text=True).stdout
+    for v in variants:
+        parts = v.split(":", 2)
+        env = dict(os.environ)
+        if parts[0] != "lib":
+            env["NSG_LIB"] = os.path.join(root, "tools", f"exp_{parts[0]}.so")
+        cmd = [sys.executable, os.path.join(root, "tools", "kbench.py"), "--work", work, "--iters", "300"]
+        if len(parts) > 1 and parts[1] == "spec":
+            cmd.append("--spec")
+            if len(parts) > 2:
+                env["NSG_SPEC_FLAGS"] = parts[2]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True).stdout
         for line in out.splitlines():
             if line.startswith(work.split(",")[0] + " "):
-                res[b].append(json.loads(line.split(" ", 1)[1])["us"])
-for b in builds:
-    v = sorted(res[b])
-    print(b, "min %.2f med %.2f" % (v[0], v[len(v) // 2]), ["%.1f" % x for x in res[b]])
+                res[v].append(json.loads(line.split(" ", 1)[1])["us"])
+for v in variants:
+    x = sorted(res[v])
+    print(v, "min %.2f med %.2f" % (x[0], x[len(x) // 2]) if x else "no result", ["%.1f" % y for y in res[v]])

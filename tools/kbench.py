@@ -25,12 +25,12 @@ WORK = {
 }
 
 
-def mk(name, n, track=True):
+def mk(name, n, track=True, spec=False):
     env_id, tp, mkw, _ = WORK[name]
     kw = dict(change_notification=True, delta_change_notification=True, track_returns=track)
     if env_id == "FrozenLake-v1":
         kw["initial_prob_dist"] = [1.0, 0.0, 0.0]
-    e = VecNSEnv(make(env_id, **mkw), tp(), n, **kw)
+    e = VecNSEnv(make(env_id, **mkw), tp(), n, specialize=spec, **kw)
     e.reset(seed=0)
     return e
 
@@ -47,12 +47,13 @@ def main():
     ap.add_argument("--iters", type=int, default=300)
     ap.add_argument("--work", default="c1,c2,c3,pend,acro")
     ap.add_argument("--no-track", action="store_true")
+    ap.add_argument("--spec", action="store_true", help="config-specialised kernels (nsg_specialize)")
     ap.add_argument("--rollout", type=int, default=0, help="K fused steps per launch (nsg_rollout) instead of nsg_step")
     args = ap.parse_args()
     res = {}
     for name in args.work.split(","):
         n = args.n
-        e = mk(name, n, track=not args.no_track)
+        e = mk(name, n, track=not args.no_track, spec=args.spec)
         a = actions(e, n)
         for _ in range(30):
             e.step(a)

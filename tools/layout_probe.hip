@@ -1,0 +1,236 @@
+// layout_probe.hip — memory skeleton of the C1 CartPole step under different state layouts.
+// Build: hipcc --offload-arch=gfx950 -O3 -o layout_probe layout_probe.hip ; run on the GPU box.
+// Every variant moves the same 120 B per env-step (the algorithmic bytes of DESIGN.md §4) with a
+// trivial amount of arithmetic, so the numbers bound what a layout can give the real kernel.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                 \
+  do {                                                                           \
+    hipError_t e = (x);                                                          \
+    if (e != hipSuccess) {                                                       \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));                     \
+      exit(1);                                                                   \
+    }                                                                            \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Rows {
+  double* phys;   // [4][N]
+  double* theta;  // [N]
+  int32_t* t;
+  float* er;
+  uint8_t* status;
+  const int32_t* action;
+  f32x4* obs;
+  float* reward;
+  uint8_t* term;
+  uint8_t* trunc;
+  uint8_t* flag;
+  float* delta;
+  unsigned char* blocked;  // [chunk][12544 B] state rows of one 256-env chunk, contiguous
+  unsigned char* blocked_out;  // [chunk][7424 B] outputs of one chunk, contiguous
+};
+
+__device__ __forceinline__ void compute(double s[4], double& th, int& t, float& er, unsigned& st, int a, f32x4& o, float& rew,
+                                        unsigned& term, unsigned& trunc, unsigned& flag, float& delta) {
+  th += 0.1;
+  const double f = a ? 10.0 : -10.0;
+  s[1] += 0.02 * (f + th * s[2]);
+  s[0] += 0.02 * s[1];
+  s[3] += 0.02 * (s[2] * 9.8 - f * 0.05);
+  s[2] += 0.02 * s[3];
+  t += 1;
+  rew = 1.f;
+  er += rew;
+  term = (s[0] > 2.4 || s[0] < -2.4 || s[2] > 0.21 || s[2] < -0.21) ? 1u : 0u;
+  trunc = t >= 500 ? 1u : 0u;
+  st = (term | trunc) ? 1u : 0u;
+  if (st) { s[0] = 0.01; s[1] = -0.02; s[2] = 0.03; s[3] = 0.01; t = 0; er = 0.f; }
+  o = f32x4{(float)s[0], (float)s[1], (float)s[2], (float)s[3]};
+  flag = 1u;
+  delta = 0.1f;
+}
+
+// A: plain SoA rows (the library's layout)
+__global__ __launch_bounds__(256) void soa_kernel(Rows r, int64_t N) {
+  const int64_t chunks = (N + 255) / 256;
+  for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const int64_t i = c * 256 + threadIdx.x;
+    if (i >= N) continue;
+    unsigned st = r.status[i];
+    int t = r.t[i];
+    double s[4];
+    for (int k = 0; k < 4; k++) s[k] = r.phys[k * N + i];
+    const int a = r.action[i];
+    float er = r.er[i];
+    double th = r.theta[i];
+    f32x4 o;
+    float rew, delta;
+    unsigned term, trunc, flag;
+    compute(s, th, t, er, st, a, o, rew, term, trunc, flag, delta);
+    r.theta[i] = th;
+    r.flag[i] = flag;
+    r.delta[i] = delta;
+    for (int k = 0; k < 4; k++) r.phys[k * N + i] = s[k];
+    r.obs[i] = o;
+    r.t[i] = t;
+    r.reward[i] = rew;
+    r.term[i] = term;
+    r.trunc[i] = trunc;
+    r.status[i] = st;
+    r.er[i] = er;
+  }
+}
+
+// B: state rows blocked per chunk (one contiguous 12.25 KB region per workgroup), outputs dense SoA
+// C: outputs blocked per chunk as well
+template <bool OUT_BLOCKED>
+__global__ __launch_bounds__(256) void blocked_kernel(Rows r, int64_t N) {
+  const int64_t chunks = (N + 255) / 256;
+  const int l = threadIdx.x;
+  for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const int64_t i = c * 256 + l;
+    if (i >= N) continue;
+    unsigned char* blk = r.blocked + c * 12544;
+    double* bp = (double*)blk;                    // [4][256]
+    double* bth = (double*)(blk + 8192);          // [256]
+    int32_t* bt = (int32_t*)(blk + 10240);
+    float* ber = (float*)(blk + 11264);
+    uint8_t* bst = blk + 12288;
+    unsigned st = bst[l];
+    int t = bt[l];
+    double s[4];
+    for (int k = 0; k < 4; k++) s[k] = bp[k * 256 + l];
+    const int a = r.action[i];
+    float er = ber[l];
+    double th = bth[l];
+    f32x4 o;
+    float rew, delta;
+    unsigned term, trunc, flag;
+    compute(s, th, t, er, st, a, o, rew, term, trunc, flag, delta);
+    bth[l] = th;
+    for (int k = 0; k < 4; k++) bp[k * 256 + l] = s[k];
+    bt[l] = t;
+    bst[l] = st;
+    ber[l] = er;
+    if (OUT_BLOCKED) {
+      unsigned char* ob = r.blocked_out + c * 7168;  // obs 4096 | reward 1024 | delta 1024 | term 256 | trunc 256 | flag 256 | pad 256
+      ((f32x4*)ob)[l] = o;
+      ((float*)(ob + 4096))[l] = rew;
+      ((float*)(ob + 5120))[l] = delta;
+      (ob + 6144)[l] = term;
+      (ob + 6400)[l] = trunc;
+      (ob + 6656)[l] = flag;
+    } else {
+      r.flag[i] = flag;
+      r.delta[i] = delta;
+      r.obs[i] = o;
+      r.reward[i] = rew;
+      r.term[i] = term;
+      r.trunc[i] = trunc;
+    }
+  }
+}
+
+// D: SoA rows, flag bytes packed into ONE byte row (term | trunc<<1 | flag<<2), status folded into t's sign
+__global__ __launch_bounds__(256) void soa_packed_kernel(Rows r, int64_t N) {
+  const int64_t chunks = (N + 255) / 256;
+  for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const int64_t i = c * 256 + threadIdx.x;
+    if (i >= N) continue;
+    int tt = r.t[i];
+    unsigned st = tt < 0;
+    int t = tt & 0x7fffffff;
+    double s[4];
+    for (int k = 0; k < 4; k++) s[k] = r.phys[k * N + i];
+    const int a = r.action[i];
+    float er = r.er[i];
+    double th = r.theta[i];
+    f32x4 o;
+    float rew, delta;
+    unsigned term, trunc, flag;
+    compute(s, th, t, er, st, a, o, rew, term, trunc, flag, delta);
+    r.theta[i] = th;
+    r.delta[i] = delta;
+    for (int k = 0; k < 4; k++) r.phys[k * N + i] = s[k];
+    r.obs[i] = o;
+    r.t[i] = t | (st << 31);
+    r.reward[i] = rew;
+    r.term[i] = term | (trunc << 1) | (flag << 2);
+    r.er[i] = er;
+  }
+}
+
+// E: pure copy of the same byte count with 16-B accesses (upper bound of the memory system for this footprint)
+__global__ __launch_bounds__(256) void copy16_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+    f32x4 v = src[i];
+    v.x += 1.f;
+    dst[i] = v;
+  }
+}
+
+template <typename F> float time_it(F&& launch, int iters) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int k = 0; k < 20; k++) launch();
+  CHECK(hipEventRecord(e0));
+  for (int k = 0; k < iters; k++) launch();
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1000.f / iters;
+}
+
+int main(int argc, char** argv) {
+  const int64_t N = argc > 1 ? atoll(argv[1]) : (1 << 20);
+  const int iters = 300;
+  const int64_t chunks = (N + 255) / 256;
+  Rows r;
+  CHECK(hipMalloc(&r.phys, 4 * N * 8));
+  CHECK(hipMalloc(&r.theta, N * 8));
+  CHECK(hipMalloc(&r.t, N * 4));
+  CHECK(hipMalloc(&r.er, N * 4));
+  CHECK(hipMalloc(&r.status, N));
+  CHECK(hipMalloc((void**)&r.action, N * 4));
+  CHECK(hipMalloc(&r.obs, N * 16));
+  CHECK(hipMalloc(&r.reward, N * 4));
+  CHECK(hipMalloc(&r.term, N));
+  CHECK(hipMalloc(&r.trunc, N));
+  CHECK(hipMalloc(&r.flag, N));
+  CHECK(hipMalloc(&r.delta, N * 4));
+  CHECK(hipMalloc(&r.blocked, chunks * 12544));
+  CHECK(hipMalloc(&r.blocked_out, chunks * 7168));
+  CHECK(hipMemset(r.phys, 0, 4 * N * 8));
+  CHECK(hipMemset(r.theta, 0, N * 8));
+  CHECK(hipMemset(r.t, 0, N * 4));
+  CHECK(hipMemset(r.er, 0, N * 4));
+  CHECK(hipMemset(r.status, 0, N));
+  CHECK(hipMemset((void*)r.action, 0, N * 4));
+  CHECK(hipMemset(r.blocked, 0, chunks * 12544));
+  const int64_t copy_bytes = 60 * N;  // 60 B read + 60 B written per env = 120 B
+  f32x4 *src, *dst;
+  CHECK(hipMalloc(&src, copy_bytes));
+  CHECK(hipMalloc(&dst, copy_bytes));
+  CHECK(hipMemset(src, 0, copy_bytes));
+  for (int grid : {4096, 2048, 1024}) {
+    const int g = (int)(chunks < grid ? chunks : grid);
+    float a = time_it([&] { hipLaunchKernelGGL(soa_kernel, dim3(g), dim3(256), 0, 0, r, N); }, iters);
+    float b = time_it([&] { hipLaunchKernelGGL(blocked_kernel<false>, dim3(g), dim3(256), 0, 0, r, N); }, iters);
+    float c = time_it([&] { hipLaunchKernelGGL(blocked_kernel<true>, dim3(g), dim3(256), 0, 0, r, N); }, iters);
+    float d = time_it([&] { hipLaunchKernelGGL(soa_packed_kernel, dim3(g), dim3(256), 0, 0, r, N); }, iters);
+    float e = time_it([&] { hipLaunchKernelGGL(copy16_kernel, dim3(g), dim3(256), 0, 0, src, dst, copy_bytes / 16); }, iters);
+    printf("N=%lld grid=%d  soa %.2f us | state-blocked %.2f | all-blocked %.2f | soa-packed-flags %.2f | copy16(120B/env) %.2f   [120 B/env-step: %.0f %.0f %.0f %.0f %.0f GB/s]\n",
+           (long long)N, g, a, b, c, d, e, 120.0 * N / a / 1e3, 120.0 * N / b / 1e3, 120.0 * N / c / 1e3, 120.0 * N / d / 1e3,
+           120.0 * N / e / 1e3);
+  }
+  return 0;
+}
