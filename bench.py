@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs-per-gpu", type=int, default=N_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--generic", action="store_true",
+                    help="time the generic kernels instead of the config-specialised ones (nsg_specialize)")
     args = ap.parse_args()
 
     import torch
@@ -88,8 +90,14 @@ def main():
     from ns_gym_amd.vec_env import VecNSEnv
 
     n = args.envs_per_gpu
-    env = VecNSEnv(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)}, n,
-                   change_notification=True, delta_change_notification=True, track_returns=True, device=dev)
+    def make_env(specialize):
+        return VecNSEnv(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)}, n,
+                        change_notification=True, delta_change_notification=True, track_returns=True, device=dev,
+                        specialize=specialize)
+
+    # the product path for a long run: kernels compiled for THIS wrapper configuration (hiprtc, ~1 s, same
+    # results bit for bit - tests/test_gpu_specialized.py); --generic times the precompiled generic kernels
+    env = make_env(not args.generic)
     # env i of the whole job is seeded base_seed + global index: results do not depend on the sharding
     env.reset(seed=torch.arange(rank * n, (rank + 1) * n, dtype=torch.int64).numpy().astype("uint64"))
     g = torch.Generator(device=dev)
@@ -136,6 +144,14 @@ def main():
     torch.cuda.synchronize()
     rollout_rate = 4 * K * float(n) / (r0.elapsed_time(r1) * 1e-3)
 
+    # for the record (not `value`): the other kernel flavour on the same workload, 300 launches
+    other = make_env(args.generic)
+    other.reset(seed=torch.arange(rank * n, (rank + 1) * n, dtype=torch.int64).numpy().astype("uint64"))
+    for k in range(30):
+        other.step(pool[k % 8])
+    other_us = other.time_steps(pool[0], 300) * 1e3
+    other.close()
+
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -167,11 +183,14 @@ def main():
                 "episodes_finished_rank0": env.counters()["episodes"],
                 "gathered_returns": int(gathered.numel()),
                 "rollout_k64_env_steps_per_sec_per_gpu": rollout_rate,
+                "kernels": "generic (precompiled)" if args.generic else "config-specialised (nsg_specialize, hiprtc)",
+                ("specialised_kernel_avg_launch_us" if args.generic else "generic_kernel_avg_launch_us"): other_us,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(),
-                "kernel": "nsg::step_kernel<CARTPOLE>", "avg_launch_us": kern_ms * 1e3,
+                "kernel": "nsg::step_kernel<CARTPOLE,false>" if args.generic else "nsg_spec_step (nsg::step_body<CARTPOLE,false>, config folded)",
+                "avg_launch_us": kern_ms * 1e3,
                 "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
             },
         }

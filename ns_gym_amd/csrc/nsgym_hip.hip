@@ -492,7 +492,7 @@ int nsg_spec_build(const nsg_config* cfg, const char* arch, void** code_out, siz
   if (!code_out || !size_out) return fail(NSG_EINVAL, "NULL output argument");
   *code_out = nullptr;
   *size_out = 0;
-  int rc = validate(cfg, 0);
+  int rc = validate(cfg, (size_t)kMaxTableBytes);  // the table blob is not part of the code object: offsets checked against the limit
   if (rc) return rc;
   bool full = false;
   for (int p = 0; p < cfg->n_params; p++)

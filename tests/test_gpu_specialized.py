@@ -1,0 +1,130 @@
+"""nsg_specialize: kernels compiled for one configuration (hiprtc, the config a compile-time constant)
+must be indistinguishable from the generic kernels - bit for bit, every row - and therefore satisfy
+the same golden-trajectory parity.  Also covers rollouts, planning copies and the code-object cache."""
+import numpy as np
+import pytest
+
+from tests.test_oracle_grid import grid_spec
+from tests.util import TRAJ_SPECS, GpuView, check_trajectory, load, make_env_from_spec
+
+pytestmark = pytest.mark.gpu
+
+ROWS = ("phys", "cell", "theta", "table_prob", "t", "status", "rng_env", "rng_upd", "rng_sched", "sched_next", "cursor", "obs",
+        "reward", "terminated", "truncated", "env_change", "delta_change", "prob", "ep_return", "last_return", "last_length",
+        "done_bits")
+
+
+def _vec(*a, **k):
+    from ns_gym_amd.vec_env import VecNSEnv
+
+    return VecNSEnv(*a, **k)
+
+
+def _same_rows(a, b, where):
+    import torch
+
+    for r in ROWS:
+        x, y = a.buf[r], b.buf[r]
+        assert (x is None) == (y is None), r
+        if x is not None:
+            assert torch.equal(x, y), f"{where}: row {r} differs between the generic and the specialised kernels"
+    assert a.counters() == b.counters(), where
+
+
+SPECS = [("c1_cartpole_masspole_inc", 5000, 120), ("c2_cartpole_gravity_rw", 4099, 60), ("cartpole_two_params", 2048, 60),
+         ("cartpole_constraint", 2048, 60), ("cartpole_persistent", 1000, 80), ("cartpole_random_sched", 1024, 60),
+         ("c4_pendulum_m_inc", 4096, 230), ("pendulum_all_params", 1024, 60), ("acrobot_constraints", 1024, 40),
+         ("mountaincar", 1024, 210), ("mountaincar_continuous", 1024, 60), ("c3_frozenlake_step50", 8192, 120),
+         ("frozenlake_randomcat", 1024, 60), ("frozenlake_lcbounded", 1024, 60)]
+
+
+@pytest.mark.parametrize("name,n,T", SPECS)
+def test_specialised_equals_generic_bitwise(name, n, T):
+    import torch
+
+    from tests.golden.make_golden import make_actions
+
+    spec = TRAJ_SPECS[name]
+    a = make_env_from_spec(_vec, spec, n=n, track_returns=True)
+    b = make_env_from_spec(_vec, spec, n=n, track_returns=True, specialize=True)
+    assert b.specialized and not a.specialized
+    a.reset(seed=7)
+    b.reset(seed=7)
+    acts = torch.from_numpy(make_actions(spec["env_id"], T, n)).cuda()
+    for k in range(T // 2):
+        a.step(acts[k])
+        b.step(acts[k])
+        if k % 16 == 0:
+            _same_rows(a, b, f"{name} step {k}")
+    _same_rows(a, b, f"{name} after {T // 2} steps")
+    # the fused rollout of the specialised unit against single generic steps
+    rec = ("obs", "reward", "terminated", "truncated")
+    out = b.rollout(acts[T // 2:], record=rec)
+    for j, k in enumerate(range(T // 2, T)):
+        obs, r, te, tr, _ = a.step(acts[k])
+        assert torch.equal(out["reward"][j], r) and torch.equal(out["terminated"][j], te) and torch.equal(out["truncated"][j], tr)
+        assert torch.equal(out["obs"][j].reshape(a.state.shape), a.state), f"{name} rollout step {k}"
+    _same_rows(a, b, f"{name} after the rollout")
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("name", ["c1_cartpole_masspole_inc", "c2_cartpole_gravity_rw", "c3_frozenlake_step50", "c4_acrobot_mass2_inc"])
+def test_specialised_kernels_reproduce_the_reference_trajectories(name):
+    spec = TRAJ_SPECS[name]
+    rec = load(f"traj_{name}.npz")
+    env = make_env_from_spec(_vec, spec, specialize=True)
+    assert env.specialized
+    check_trajectory(GpuView(env), spec, rec)
+    env.close()
+
+
+def test_grid_variants_and_planning_copies():
+    import torch
+
+    from tests.golden.make_golden import make_actions
+
+    for name in ("cliff_terminal_stepwise_rewards", "bridge_split_onehot"):
+        spec = grid_spec(name)
+        a = make_env_from_spec(_vec, spec, n=777)
+        b = make_env_from_spec(_vec, spec, n=777, specialize=True)
+        a.reset(seed=3); b.reset(seed=3)
+        acts = torch.from_numpy(make_actions(spec["env_id"], 40, 777)).cuda()
+        for k in range(40):
+            a.step(acts[k]); b.step(acts[k])
+        _same_rows(a, b, name)
+        a.close(); b.close()
+    # a frozen planning copy of a specialised batch is itself specialised (its own config: is_sim_env)
+    spec = TRAJ_SPECS["c1_cartpole_masspole_inc"]
+    a = make_env_from_spec(_vec, spec, n=1000)
+    b = make_env_from_spec(_vec, spec, n=1000, specialize=True)
+    a.reset(seed=5); b.reset(seed=5)
+    acts = torch.from_numpy(make_actions(spec["env_id"], 30, 1000)).cuda()
+    for k in range(10):
+        a.step(acts[k]); b.step(acts[k])
+    fa, fb = a.fork(theta_mode=0, entropy=1234), b.fork(theta_mode=0, entropy=1234)
+    assert fb.specialized and not fa.specialized
+    for k in range(10, 30):
+        fa.step(acts[k]); fb.step(acts[k])
+    _same_rows(fa, fb, "planning copy")
+    for e in (a, b, fa, fb):
+        e.close()
+
+
+def test_code_objects_are_shared_and_cached_on_disk(tmp_path, monkeypatch):
+    import time
+
+    spec = TRAJ_SPECS["c4_pendulum_m_inc"]
+    monkeypatch.setenv("NSG_SPEC_CACHE", str(tmp_path))
+    # NSG_SPEC_FLAGS is part of the key: a distinct value forces a fresh compilation in this process
+    monkeypatch.setenv("NSG_SPEC_FLAGS", "-DNSG_TEST_CACHE_KEY=1")
+    t0 = time.time()
+    a = make_env_from_spec(_vec, spec, n=256, specialize=True)
+    t_first = time.time() - t0
+    files = list(tmp_path.glob("nsg_*.hsaco"))
+    assert len(files) == 1 and files[0].stat().st_size > 4096
+    t0 = time.time()
+    b = make_env_from_spec(_vec, spec, n=512, specialize=True)   # same config, other batch size: same module
+    t_second = time.time() - t0
+    assert b.specialized and t_second < max(0.5 * t_first, 0.2)
+    assert len(list(tmp_path.glob("nsg_*.hsaco"))) == 1
+    a.close(); b.close()

@@ -1,0 +1,56 @@
+"""Config-specialised code objects (nsg_spec_build): the hiprtc unit compiles for gfx950 WITHOUT a
+GPU and exports the two kernels nsg_specialize() looks up.  Runs the compiler only - no compute."""
+import ctypes as C
+
+import pytest
+
+from tests.test_oracle_grid import grid_spec
+from tests.util import TRAJ_SPECS
+
+NAMES = ["c1_cartpole_masspole_inc", "c2_cartpole_gravity_rw", "c3_frozenlake_step50", "c4_pendulum_m_inc",
+         "c4_acrobot_mass2_inc", "cartpole_random_sched", "frozenlake_randomcat"]
+
+
+def _build(spec, **flags):
+    from ns_gym_amd import _lib
+    from ns_gym_amd.envs import make
+    from ns_gym_amd.spec import build_tunable_params, compile_config
+
+    lib = _lib.load()
+    cfg = compile_config(make(spec["env_id"], **spec.get("make_kwargs", {})), build_tunable_params(spec["params"]),
+                         **{**spec["flags"], **spec.get("wrapper_kwargs", {}), **flags})[0]
+    code, size = C.c_void_p(), C.c_size_t()
+    rc = lib.nsg_spec_build(C.byref(cfg), b"gfx950", C.byref(code), C.byref(size))
+    if rc == -95 and b"libhiprtc" in lib.nsg_last_error():
+        pytest.skip("libhiprtc.so not available in this environment")
+    assert rc == 0, lib.nsg_last_error().decode()
+    data = C.string_at(code, size.value)
+    lib.nsg_spec_free(code)
+    return data
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_specialised_unit_compiles_for_gfx950(name):
+    data = _build(TRAJ_SPECS[name])
+    assert data[:4] == b"\x7fELF" and len(data) > 4096
+    assert b"nsg_spec_step" in data and b"nsg_spec_rollout" in data
+    # a specialised unit carries only its own two kernels
+    assert b"init_kernel" not in data and b"fork_kernel" not in data
+
+
+def test_planning_copy_and_grid_variants_compile():
+    _build(TRAJ_SPECS["c1_cartpole_masspole_inc"], is_sim_env=True)          # frozen planning copy (derived rows, t_fork)
+    _build(TRAJ_SPECS["cartpole_constraint"], violation_mask=True)
+    _build(grid_spec("cliff_terminal_stepwise_rewards"))
+    _build(grid_spec("bridge_split_onehot"))
+
+
+def test_bad_config_is_rejected_not_compiled():
+    from ns_gym_amd import _abi as A, _lib
+
+    lib = _lib.load()
+    cfg = A.Config()
+    cfg.abi_version = 0
+    code, size = C.c_void_p(), C.c_size_t()
+    assert lib.nsg_spec_build(C.byref(cfg), b"gfx950", C.byref(code), C.byref(size)) == -22
+    assert not code.value and size.value == 0
