@@ -134,7 +134,10 @@ __device__ __forceinline__ void flush_counts(uint64_t* counters, int block_rel, 
   const int lane = threadIdx.x & 63;
   if (counters && lane < NSG_CNT_COUNT) {
     const unsigned v = lane == NSG_CNT_DONE ? wc.done : lane == NSG_CNT_FIRED ? wc.fired : lane == NSG_CNT_VIOLATION ? wc.viol : wc.steps;
-    if (v) counters[(int64_t)lane * kCntShards + block_rel * (kBlock / 64) + (threadIdx.x >> 6)] += v;
+    // fire-and-forget add (no return value requested): the wavefront retires without waiting for a
+    // read-modify-write round trip; the shard has a single owner per launch, so there is no contention
+    if (v) atomicAdd((unsigned long long*)&counters[(int64_t)lane * kCntShards + block_rel * (kBlock / 64) + (threadIdx.x >> 6)],
+                     (unsigned long long)v);
   }
 }
 
@@ -188,8 +191,10 @@ template <int ENV> struct LaneState {
   unsigned st = 0;
   float er = 0.f;
 };
-struct IoMode {
-  bool load, store;  // wave-uniform
+struct IoMode {  // wave-uniform
+  bool load;   // fetch the persistent rows from memory (else: they are in the LaneState)
+  bool store;  // write them back
+  bool dirty;  // the LaneState's θ rows 0/1 may differ from memory (earlier fused steps did not store)
 };
 
 // Fire predicate of param p of env i.  Deterministic schedulers are pure functions of t; the
@@ -335,7 +340,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
         if (p == 1) ls.th1 = fin;
         // rows 0/1 live in registers across fused steps: written when this step stores (always then,
         // because earlier fused steps may have changed them without a store)
-        if (p > 1 ? fin != c : (io.store && (fin != c || !io.load))) stg(b.theta + (int64_t)p * N, o8, fin);
+        if (p > 1 ? fin != c : (io.store && (fin != c || io.dirty))) stg(b.theta + (int64_t)p * N, o8, fin);
         stg(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
         stg(out.delta_change + (int64_t)p * N, o4, (float)delta);
         if (cfg.flags & NSG_F_VIOLATION_MASK) stg(b.violation + (int64_t)p * N, o1, (uint8_t)(rejected && do_step ? 1 : 0));
@@ -400,7 +405,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
         if (p == 1) ls.th1 = fin;
         // rows 0/1 live in registers across fused steps: written when this step stores (always then,
         // because earlier fused steps may have changed them without a store)
-        if (p > 1 ? fin != c : (io.store && (fin != c || !io.load))) stg(b.theta + (int64_t)p * N, o8, fin);
+        if (p > 1 ? fin != c : (io.store && (fin != c || io.dirty))) stg(b.theta + (int64_t)p * N, o8, fin);
         stg(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
         stg(out.delta_change + (int64_t)p * N, o4, (float)delta);
         if (cfg.flags & NSG_F_VIOLATION_MASK) stg(b.violation + (int64_t)p * N, o1, (uint8_t)(rejected && do_step ? 1 : 0));
@@ -711,7 +716,7 @@ __device__ __forceinline__ void step_block(const nsg_config& cfg, const nsg_buff
     step_grid<ENV, FULL>(cfg, b, N, tb, zg, actions, out, i, i < N, wc);
   } else {
     LaneState<ENV> ls;
-    step_chunk<ENV, FULL>(cfg, b, N, tb, zg, actions, out, base, parity, lds, wc, ls, IoMode{true, true});
+    step_chunk<ENV, FULL>(cfg, b, N, tb, zg, actions, out, base, parity, lds, wc, ls, IoMode{true, true, false});
   }
 }
 

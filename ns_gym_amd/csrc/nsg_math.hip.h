@@ -29,20 +29,36 @@ NSG_HD void nsg_sincos(double x, double* sn, double* cs) {
   // in 33-bit pieces, so fn*pio2_k is exact for |fn| < 2^20; the two rounded subtractions are
   // compensated with TwoSum error terms (branch-free equivalent of fdlibm's 3-iteration scheme).
   const double fn = rint(x * invpio2);
-  const double r1 = x - fn * pio2_1;  // exact (Sterbenz)
-  const double c2 = -(fn * pio2_2);
-  const double r2 = r1 + c2;
-  const double b2 = r2 - r1;
-  const double e2 = (r1 - (r2 - b2)) + (c2 - b2);
-  const double c3 = -(fn * pio2_3);
-  const double r3 = r2 + c3;
-  const double b3 = r3 - r2;
-  const double e3 = (r2 - (r3 - b3)) + (c3 - b3);
-  const double tail = (e2 + e3) - fn * pio2_3t;
-  const double y0 = r3 + tail;
-  const double y1 = (r3 - y0) + tail;
+  // fdlibm's first branch (|x| <= π/4: no reduction), taken when it holds for EVERY lane of the
+  // wavefront so the branch is uniform.  CartPole's pole angle never leaves it while an episode runs.
+  // With fn == 0 the general path below yields y0 = x, y1 = 0, n = 0 exactly, so both paths agree bit for bit.
+#if defined(__HIP_DEVICE_COMPILE__)
+  const bool no_reduction = __all(fn == 0.0);
+#else
+  const bool no_reduction = fn == 0.0;
+#endif
+  double y0, y1;
+  int n;
+  if (no_reduction) {
+    y0 = x;
+    y1 = 0.0;
+    n = 0;
+  } else {
+    const double r1 = x - fn * pio2_1;  // exact (Sterbenz)
+    const double c2 = -(fn * pio2_2);
+    const double r2 = r1 + c2;
+    const double b2 = r2 - r1;
+    const double e2 = (r1 - (r2 - b2)) + (c2 - b2);
+    const double c3 = -(fn * pio2_3);
+    const double r3 = r2 + c3;
+    const double b3 = r3 - r2;
+    const double e3 = (r2 - (r3 - b3)) + (c3 - b3);
+    const double tail = (e2 + e3) - fn * pio2_3t;
+    y0 = r3 + tail;
+    y1 = (r3 - y0) + tail;
+    n = (int)fn;
+  }
   (void)pio2_1t; (void)pio2_2t;
-  const int n = (int)fn;
   // fdlibm __kernel_sin / __kernel_cos on (y0, y1)
   const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;

@@ -50,7 +50,7 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
       if constexpr (GRID) {
         step_block<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc);
       } else {
-        step_chunk<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, k == k_steps - 1});
+        step_chunk<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, k == k_steps - 1, k > 0});
       }
       parity ^= 1;
     }
