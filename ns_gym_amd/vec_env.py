@@ -46,9 +46,13 @@ class VecNSEnv:
         distinct configuration per process, ~1 s; `NSG_SPEC_CACHE=<dir>` keeps them on disk): same results,
         ~10-20 % less time per step.  Worth it for long runs; the generic kernels need no compilation."""
         self.lib = _lib.load()
+        self._row_cache = {}
         if not torch.cuda.is_available():
             raise _lib.NsgError("VecNSEnv needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.index is None:
+            self.device = torch.device(f"cuda:{torch.cuda.current_device()}")
+        self._dev_index = self.device.index
         self.cfg, self.tables, self.spec, self.param_names = compile_config(
             env, tunable_params, change_notification=change_notification,
             delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
@@ -163,8 +167,13 @@ class VecNSEnv:
         """One fused wrapper step for all envs.  `actions`: int32[N] (discrete) or float32[N] /
         float32[N,1] (continuous) device tensor."""
         act = self._as_actions(actions)
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.nsg_step(self._h, act.data_ptr(), self._stream), "nsg_step")
+        if torch.cuda.current_device() == self._dev_index:   # the common case: no device-guard round trip
+            rc = self.lib.nsg_step(self._h, act.data_ptr(), self._stream)
+        else:
+            with torch.cuda.device(self.device):
+                rc = self.lib.nsg_step(self._h, act.data_ptr(), self._stream)
+        if rc:
+            _lib.check(rc, "nsg_step")
         return self._obs(), self.reward, self.terminated, self.truncated, self._info()
 
     def rollout(self, actions, record=("obs", "reward", "terminated", "truncated")):
@@ -190,6 +199,9 @@ class VecNSEnv:
 
     def _as_actions(self, actions):
         dt = torch.float32 if self.action_is_float else torch.int32
+        if (type(actions) is torch.Tensor and actions.dtype == dt and actions.dim() == 1 and actions.shape[0] == self.N
+                and actions.device == self.device and actions.is_contiguous()):
+            return actions   # already what the kernel reads: no views, no copies
         act = torch.as_tensor(actions, device=self.device)
         if act.dtype != dt:
             act = act.to(dt)
@@ -206,20 +218,28 @@ class VecNSEnv:
         dc = self.gt_delta_change if (self.delta_change_notification and not hide) else self._zero_flags[1]
         return ec, dc
 
+    def _rows(self, key, mat):
+        """Per-param row views of a [P, N] buffer view, made once (the buffers never move)."""
+        c = self._row_cache.get(key)
+        if c is None or c[0] is not mat:
+            c = (mat, {p: mat[j] for j, p in enumerate(self.param_names)})
+            self._row_cache[key] = c
+        return c[1]
+
     def _obs(self):
         """NS observation dict (ns_gym/base.py:343-348), batched: values are [N]-tensors per param."""
         ec, dc = self._masked()
         return {
             "state": self.state,
-            "env_change": {p: ec[j] for j, p in enumerate(self.param_names)},
-            "delta_change": {p: dc[j] for j, p in enumerate(self.param_names)},
+            "env_change": dict(self._rows("ec", ec)),
+            "delta_change": dict(self._rows("dc", dc)),
             "relative_time": self.t,
         }
 
     def _info(self):
         info = {
-            "Ground Truth Env Change": {p: self.gt_env_change[j] for j, p in enumerate(self.param_names)},
-            "Ground Truth Delta Change": {p: self.gt_delta_change[j] for j, p in enumerate(self.param_names)},
+            "Ground Truth Env Change": dict(self._rows("gt_ec", self.gt_env_change)),
+            "Ground Truth Delta Change": dict(self._rows("gt_dc", self.gt_delta_change)),
         }
         if self.is_grid:
             info["prob"] = self.prob
