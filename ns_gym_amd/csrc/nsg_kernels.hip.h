@@ -43,6 +43,7 @@ template <bool FULL> constexpr bool kEarlyDraw = (NSG_EARLY_DRAW != 0) && !FULL;
 #define NSG_MIN_WAVES 1
 #endif
 
+
 // Device-resident description of one homogeneous env segment (read through scalar loads).
 struct Segment {
   nsg_config cfg;
