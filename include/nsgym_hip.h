@@ -195,8 +195,9 @@ typedef struct nsg_buffers {
                             gym.make() env, so TimeLimit's elapsed count restarts at 0 while the
                             wrapper's t is preserved (classic_control.py:168-180)              */
   uint8_t* status;       /* [N]    NSG_ST_* bits                                          */
-  uint64_t* rng_env;     /* [N][4] env np_random PCG64 records: state_hi,state_lo,inc_hi,inc_lo
-                            (32-byte record per env: streams are touched by few scattered lanes) */
+  uint64_t* rng_env;     /* env np_random PCG64 streams: state_hi,state_lo,inc_hi,inc_lo.  Classic-control envs:
+                            [N][4], one 32-byte record per env (touched by the few lanes that reset);
+                            grid envs: [4][N] rows (every lane draws one uniform per step)                 */
   uint64_t* rng_upd;     /* [P][N][4] update-fn PCG64 streams (only rows with uses_rng)   */
   uint64_t* rng_sched;   /* [P][N][4] PCG64 records of stochastic schedulers (Random, DecayingProbability,
                             Memoryless).  A scheduler lives inside the deep-copied init_initial_params, so a

@@ -521,22 +521,23 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
   const bool theta_live = !(sim && !(cfg.flags & NSG_F_IN_SIM_CHANGE));  // toy_text.py:170-176,354-360,636-645
   const uint8_t* desc = tb.base + cfg.desc_tab_off;
 
-  const unsigned st = active ? b.status[i] : 0u;
-  const int t = active ? b.t[i] : 0;
+  const uint32_t o1 = (uint32_t)i, o4 = o1 * 4u, o8 = o1 * 8u;  // per-lane byte offsets into [N] rows
+  const unsigned st = active ? ldg(b.status, o1) : 0u;
+  const int t = active ? ldg(b.t, o4) : 0;
   const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);
   const bool do_step = active && !do_reset;
 
-  int cell = do_step ? b.cell[i] : 0;
-  const int a = do_step ? ((const int32_t*)actions)[i] : 0;
+  int cell = do_step ? ldg(b.cell, o4) : 0;
+  const int a = do_step ? ldg((const int32_t*)actions, o4) : 0;
   // one uniform per step from the env stream (categorical_sample / np.random.choice); FrozenLakeEnv
   // and CliffWalkingEnv.reset also draw one (categorical_sample over the one-hot start distribution),
   // Bridge.reset draws nothing (envs/Bridge.py:103-111)
   double r = 0.0;
   if (do_step || (do_reset && ENV != NSG_ENV_BRIDGE)) {
     Pcg g;
-    pcg_load(b.rng_env, N, i, g);
+    pcg_load<true>(b.rng_env, N, i, g);
     r = pcg_double(g);
-    pcg_store_state(b.rng_env, N, i, g);
+    pcg_store_state<true>(b.rng_env, N, i, g);
   }
 
   // ---- θ: every distribution parameter (toy_text.py:178-185, 362-366, 605-631) ---------------
@@ -566,27 +567,27 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
     if (fired) {
       double pp[ND];
 #pragma unroll
-      for (int k = 0; k < ND; k++) pp[k] = b.theta[(int64_t)(p * ND + k) * N + i];
+      for (int k = 0; k < ND; k++) pp[k] = ldg(b.theta + (int64_t)(p * ND + k) * N, o8);
       int cursor = 0;
       const bool has_cur = upd_uses_cursor(pc.upd_kind);
-      if (has_cur) cursor = b.cursor[(int64_t)p * N + i];
+      if (has_cur) cursor = ldg(b.cursor + (int64_t)p * N, o4);
       Pcg ur = {0, 0, 0, 0};
       if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, i, ur);
       upd_dist<ND, FULL>(pc, tb, zg, pp, t, cursor, ur, q);
       if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, i, ur);
-      if (has_cur && pc.upd_kind != NSG_UPD_D_LCBOUNDED) b.cursor[(int64_t)p * N + i] = cursor;
+      if (has_cur && pc.upd_kind != NSG_UPD_D_LCBOUNDED) stg(b.cursor + (int64_t)p * N, o4, cursor);
       delta = w1_n<ND>(pp, q);  // base.py:192-203
 #pragma unroll
       for (int k = 0; k < ND; k++) {
-        b.theta[(int64_t)(p * ND + k) * N + i] = q[k];
-        if constexpr (ENV != NSG_ENV_BRIDGE) b.table_prob[(int64_t)k * N + i] = q[k];  // P re-weighted on a fire only
+        stg(b.theta + (int64_t)(p * ND + k) * N, o8, q[k]);
+        if constexpr (ENV != NSG_ENV_BRIDGE) stg(b.table_prob + (int64_t)k * N, o8, q[k]);  // P re-weighted on a fire only
       }
       have_q = true;
     }
     if constexpr (ENV == NSG_ENV_BRIDGE) {
       if (do_step && pc.theta_slot == want) {  // Bridge reads the live attribute every step (toy_text.py:626-630)
 #pragma unroll
-        for (int k = 0; k < ND; k++) pt[k] = have_q ? q[k] : b.theta[(int64_t)(p * ND + k) * N + i];
+        for (int k = 0; k < ND; k++) pt[k] = have_q ? q[k] : ldg(b.theta + (int64_t)(p * ND + k) * N, o8);
       }
     } else {
       if (have_q) {
@@ -596,12 +597,12 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       }
     }
     if (pc.upd_kind == NSG_UPD_D_LCBOUNDED && do_step && theta_live)
-      b.cursor[(int64_t)p * N + i] = t + 1;  // UpdateFn.__call__ records prev_time = t, fired or not (base.py:143-148)
+      stg(b.cursor + (int64_t)p * N, o4, t + 1);  // UpdateFn.__call__ records prev_time = t, fired or not (base.py:143-148)
     if (do_reset && !persistent) {  // toy_text.py:206-209, 394-399, 657-666 (the P TABLE is not restored)
       const double* ini = grid_initial(cfg, p);
 #pragma unroll
-      for (int k = 0; k < ND; k++) b.theta[(int64_t)(p * ND + k) * N + i] = ini[k];
-      if (upd_uses_cursor(pc.upd_kind)) b.cursor[(int64_t)p * N + i] = 0;
+      for (int k = 0; k < ND; k++) stg(b.theta + (int64_t)(p * ND + k) * N, o8, ini[k]);
+      if (upd_uses_cursor(pc.upd_kind)) stg(b.cursor + (int64_t)p * N, o4, 0);
       if (FULL && pc.upd_kind == NSG_UPD_D_LCBOUNDED && pc.uses_rng) {  // inner sampler rewound with the deepcopy
         Pcg r;
         if (pc.has_fn_seed) pcg_seed(r, pc.fn_seed, -1);
@@ -610,15 +611,15 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       }
     }
     if (active) {
-      out.env_change[(int64_t)p * N + i] = fired ? 1 : 0;
-      out.delta_change[(int64_t)p * N + i] = (float)delta;
+      stg(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
+      stg(out.delta_change + (int64_t)p * N, o4, (float)delta);
     }
     n_fired += fired ? 1u : 0u;
   }
   if constexpr (ENV != NSG_ENV_BRIDGE) {
     if (do_step && !have_table) {
 #pragma unroll
-      for (int k = 0; k < ND; k++) pt[k] = b.table_prob[(int64_t)k * N + i];
+      for (int k = 0; k < ND; k++) pt[k] = ldg(b.table_prob + (int64_t)k * N, o8);
     }
   }
 
@@ -675,29 +676,29 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       prob = pt[0];
     }
     tnew = t + 1;
-    trunc = cfg.max_episode_steps > 0 && (tnew - (sim ? b.t_fork[i] : 0)) >= cfg.max_episode_steps;
+    trunc = cfg.max_episode_steps > 0 && (tnew - (sim ? ldg(b.t_fork, o4) : 0)) >= cfg.max_episode_steps;
   } else if (do_reset) {
-    if (sim) b.t_fork[i] = 0;
+    if (sim) stg(b.t_fork, o4, 0);
     cell = grid_start_state(cfg, desc);
   }
   const bool done = term || trunc;
   if (active) {
-    b.cell[i] = cell;
-    if (out.obs) ((int32_t*)out.obs)[i] = cell;  // trajectory slice (rollout); NULL for nsg_step: cell[] is the obs
-    b.t[i] = tnew;
-    out.reward[i] = (float)reward;
-    out.terminated[i] = term ? 1 : 0;
-    out.truncated[i] = trunc ? 1 : 0;
-    b.status[i] = done ? NSG_ST_NEEDS_RESET : 0;
-    if (b.prob) b.prob[i] = (float)prob;
+    stg(b.cell, o4, cell);
+    if (out.obs) stg((int32_t*)out.obs, o4, cell);  // trajectory slice (rollout); NULL for nsg_step: cell[] is the obs
+    stg(b.t, o4, tnew);
+    stg(out.reward, o4, (float)reward);
+    stg(out.terminated, o1, (uint8_t)(term ? 1 : 0));
+    stg(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
+    stg(b.status, o1, (uint8_t)(done ? NSG_ST_NEEDS_RESET : 0));
+    if (b.prob) stg(b.prob, o4, (float)prob);
     if (cfg.flags & NSG_F_TRACK_RETURNS) {
-      float er = do_reset ? 0.f : b.ep_return[i] + (float)reward;
+      float er = do_reset ? 0.f : ldg(b.ep_return, o4) + (float)reward;
       if (done) {
-        b.last_return[i] = er;
-        b.last_length[i] = tnew;
+        stg(b.last_return, o4, er);
+        stg(b.last_length, o4, tnew);
         er = 0.f;
       }
-      b.ep_return[i] = er;
+      stg(b.ep_return, o4, er);
     }
   }
   const unsigned long long done_mask = __ballot(done);
@@ -797,8 +798,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
     if (mask && !mask[i]) continue;
     Pcg g;
+    constexpr bool GRID = ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE;
     if (seeds) pcg_seed(g, seeds[i], -1);  // gymnasium Env.reset(seed) -> np_random(seed) [UPSTREAM]
-    else pcg_load(b.rng_env, N, i, g);
+    else pcg_load<GRID>(b.rng_env, N, i, g);
     if constexpr (ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE) {
       // FrozenLakeEnv / CliffWalkingEnv.reset consume one random() (categorical_sample over the one-hot
       // start distribution); Bridge.reset draws nothing
@@ -815,7 +817,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
       env_obs<ENV>(s, o);
       store_obs<ENV>(b.obs, i, o);
     }
-    pcg_store_all(b.rng_env, N, i, g);
+    pcg_store_all<GRID>(b.rng_env, N, i, g);
     b.t[i] = 0;
     if (b.t_fork) b.t_fork[i] = 0;
     for (int p = 0; p < P; p++) {
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const Segment* __restrict_
     }
     Pcg g;
     pcg_seed(g, (uint64_t)i, 999);
-    pcg_store_all(b.rng_env, N, i, g);
+    pcg_store_env(b.rng_env, N, i, g, fl);
     b.t[i] = 0;
     b.status[i] = 0;
     b.reward[i] = 0.f;
@@ -1091,7 +1093,7 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
     }
     Pcg g;  // the copy's base env is a new gym.make(): its np_random is unseeded
     pcg_seed(g, entropy + (uint64_t)i, 7001);
-    pcg_store_all(db.rng_env, N, i, g);
+    pcg_store_env(db.rng_env, N, i, g, fl);
     for (int k = 0; k < obs; k++) db.obs[i * obs + k] = sb.obs[i * obs + k];
     db.reward[i] = sb.reward[i];
     db.terminated[i] = sb.terminated[i];
@@ -1114,7 +1116,7 @@ __global__ __launch_bounds__(kBlock) void seed_streams_kernel(const Segment* __r
     if (which == 0) {
       Pcg g;
       pcg_seed(g, seeds[i], -1);
-      pcg_store_all(sg.buf.rng_env, N, i, g);
+      pcg_store_env(sg.buf.rng_env, N, i, g, is_grid_env(sg.cfg.env_type));
     } else {
       for (int p = 0; p < sg.cfg.n_params; p++)
         if (sg.cfg.params[p].uses_rng) {

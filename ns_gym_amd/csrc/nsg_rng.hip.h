@@ -134,22 +134,49 @@ typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 // inc_lo.  Streams are touched by few, scattered lanes (the ~5 % of envs that reset, the lanes
 // whose scheduler fired), so one 32-byte record = one memory sector per touch; four SoA rows
 // would cost four sectors.  Two 16-byte accesses per lane; only the state half is written back.
+// PCG64 stream storage.  Two layouts, chosen by how a stream is touched:
+//   records (default): [N][4] u64, one 32-byte record per env - update-fn / scheduler streams and the
+//     env streams of the classic-control envs, which only a few scattered lanes touch per step
+//     (resets, fires): one sector per touch instead of four rows;
+//   rows (ROWS = true): [4][N] u64 - the env streams of the grid envs, where EVERY lane draws one
+//     uniform per step: four fully coalesced 8-byte rows instead of 16-byte accesses at a 32-byte
+//     stride (FrozenLake-shaped skeleton, tools/layout_probe.hip: 19.1 us vs 23.0 us per 2^20 envs).
+template <bool ROWS = false>
 __device__ __forceinline__ void pcg_load(const uint64_t* base, int64_t N, int64_t i, Pcg& r) {
-  (void)N;
-  const uint32_t o = (uint32_t)i * 32u;
-  const u64x2 a = ldg(reinterpret_cast<const u64x2*>(base), o);
-  const u64x2 c = ldg(reinterpret_cast<const u64x2*>(base), o + 16u);
-  r.sh = a.x; r.sl = a.y; r.ih = c.x; r.il = c.y;
+  if constexpr (ROWS) {
+    const uint32_t o = (uint32_t)i * 8u;
+    r.sh = ldg(base, o); r.sl = ldg(base + N, o); r.ih = ldg(base + 2 * N, o); r.il = ldg(base + 3 * N, o);
+  } else {
+    const uint32_t o = (uint32_t)i * 32u;
+    const u64x2 a = ldg(reinterpret_cast<const u64x2*>(base), o);
+    const u64x2 c = ldg(reinterpret_cast<const u64x2*>(base), o + 16u);
+    r.sh = a.x; r.sl = a.y; r.ih = c.x; r.il = c.y;
+  }
 }
+template <bool ROWS = false>
 __device__ __forceinline__ void pcg_store_state(uint64_t* base, int64_t N, int64_t i, const Pcg& r) {
-  (void)N;
-  stg(reinterpret_cast<u64x2*>(base), (uint32_t)i * 32u, u64x2{r.sh, r.sl});  // the increment never changes
+  if constexpr (ROWS) {
+    const uint32_t o = (uint32_t)i * 8u;
+    stg(base, o, r.sh); stg(base + N, o, r.sl);  // the increment never changes
+  } else {
+    stg(reinterpret_cast<u64x2*>(base), (uint32_t)i * 32u, u64x2{r.sh, r.sl});
+  }
 }
+template <bool ROWS = false>
 __device__ __forceinline__ void pcg_store_all(uint64_t* base, int64_t N, int64_t i, const Pcg& r) {
-  (void)N;
-  const uint32_t o = (uint32_t)i * 32u;
-  stg(reinterpret_cast<u64x2*>(base), o, u64x2{r.sh, r.sl});
-  stg(reinterpret_cast<u64x2*>(base), o + 16u, u64x2{r.ih, r.il});
+  if constexpr (ROWS) {
+    const uint32_t o = (uint32_t)i * 8u;
+    stg(base, o, r.sh); stg(base + N, o, r.sl); stg(base + 2 * N, o, r.ih); stg(base + 3 * N, o, r.il);
+  } else {
+    const uint32_t o = (uint32_t)i * 32u;
+    stg(reinterpret_cast<u64x2*>(base), o, u64x2{r.sh, r.sl});
+    stg(reinterpret_cast<u64x2*>(base), o + 16u, u64x2{r.ih, r.il});
+  }
+}
+// env stream of env type `grid ? rows : records`, for kernels that take the env type at run time
+__device__ __forceinline__ void pcg_store_env(uint64_t* base, int64_t N, int64_t i, const Pcg& r, bool grid) {
+  if (grid) pcg_store_all<true>(base, N, i, r);
+  else pcg_store_all<false>(base, N, i, r);
 }
 
 // ---- ziggurat normal (numpy random_standard_normal), tables in LDS --------------------

@@ -176,6 +176,54 @@ __global__ __launch_bounds__(256) void copy16_kernel(const f32x4* __restrict__ s
   }
 }
 
+// ---- FrozenLake-shaped skeleton (C3): per-env PCG64 record read + state half written every step ----
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+struct GridRows {
+  u64x2* rng_aos;        // [N][2] x u64x2 = 32-byte records
+  unsigned long long* rng_soa;  // [4][N]
+  int32_t* cell; int32_t* t; uint8_t* status; const int32_t* action; double* prob3;  // [3][N]
+  float* er; float* reward; uint8_t* term; uint8_t* trunc; float* prob; uint8_t* flag; float* delta;
+};
+__device__ __forceinline__ void pcg_step(unsigned long long& sh, unsigned long long& sl, unsigned long long ih, unsigned long long il) {
+  const unsigned long long MH = 2549297995355413924ULL, ML = 4865540595714422341ULL;
+  unsigned long long lo = sl * ML;
+  unsigned long long hi = __umul64hi(sl, ML) + sh * ML + sl * MH;
+  unsigned long long lo2 = lo + il;
+  sl = lo2;
+  sh = hi + ih + (lo2 < lo ? 1ULL : 0ULL);
+}
+template <bool SOA>
+__global__ __launch_bounds__(256) void grid_kernel(GridRows r, int64_t N) {
+  const int64_t chunks = (N + 255) / 256;
+  for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const int64_t i = c * 256 + threadIdx.x;
+    if (i >= N) continue;
+    unsigned long long sh, sl, ih, il;
+    if (SOA) { sh = r.rng_soa[i]; sl = r.rng_soa[N + i]; ih = r.rng_soa[2 * N + i]; il = r.rng_soa[3 * N + i]; }
+    else { u64x2 a = r.rng_aos[2 * i], b = r.rng_aos[2 * i + 1]; sh = a.x; sl = a.y; ih = b.x; il = b.y; }
+    unsigned st = r.status[i];
+    int t = r.t[i];
+    int cell = r.cell[i];
+    const int a = r.action[i];
+    float er = r.er[i];
+    const double p0 = r.prob3[i], p1 = r.prob3[N + i], p2 = r.prob3[2 * N + i];
+    pcg_step(sh, sl, ih, il);
+    const unsigned long long x = sh ^ sl;
+    const unsigned rot = (unsigned)(sh >> 58);
+    const double u = (double)(((x >> rot) | (x << ((64u - rot) & 63u))) >> 11) * (1.0 / 9007199254740992.0);
+    const int idx = p0 > u ? 0 : p0 + p1 > u ? 1 : 2;
+    cell = (cell + a + idx + (int)st) & 63;
+    t += 1;
+    const unsigned term = cell == 63, trunc = t >= 100;
+    st = term | trunc;
+    er += (float)term;
+    if (SOA) { r.rng_soa[i] = sh; r.rng_soa[N + i] = sl; }
+    else r.rng_aos[2 * i] = u64x2{sh, sl};
+    r.cell[i] = cell; r.t[i] = st ? 0 : t; r.status[i] = st; r.reward[i] = (float)term; r.term[i] = term; r.trunc[i] = trunc;
+    r.prob[i] = (float)(idx == 0 ? p0 : idx == 1 ? p1 : p2); r.flag[i] = 0; r.delta[i] = 0.f; r.er[i] = er;
+  }
+}
+
 template <typename F> float time_it(F&& launch, int iters) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
@@ -231,6 +279,20 @@ int main(int argc, char** argv) {
     printf("N=%lld grid=%d  soa %.2f us | state-blocked %.2f | all-blocked %.2f | soa-packed-flags %.2f | copy16(120B/env) %.2f   [120 B/env-step: %.0f %.0f %.0f %.0f %.0f GB/s]\n",
            (long long)N, g, a, b, c, d, e, 120.0 * N / a / 1e3, 120.0 * N / b / 1e3, 120.0 * N / c / 1e3, 120.0 * N / d / 1e3,
            120.0 * N / e / 1e3);
+  }
+  GridRows gr;
+  CHECK(hipMalloc(&gr.rng_aos, N * 32)); CHECK(hipMalloc(&gr.rng_soa, N * 32));
+  CHECK(hipMemset(gr.rng_aos, 1, N * 32)); CHECK(hipMemset(gr.rng_soa, 1, N * 32));
+  CHECK(hipMalloc(&gr.prob3, N * 24)); CHECK(hipMemset(gr.prob3, 0, N * 24));
+  CHECK(hipMalloc(&gr.cell, N * 4)); CHECK(hipMemset(gr.cell, 0, N * 4));
+  CHECK(hipMalloc(&gr.prob, N * 4));
+  gr.t = r.t; gr.status = r.status; gr.action = r.action; gr.er = r.er; gr.reward = r.reward; gr.term = r.term; gr.trunc = r.trunc;
+  gr.flag = r.flag; gr.delta = r.delta;
+  {
+    const int g = (int)(chunks < 4096 ? chunks : 4096);
+    float a = time_it([&] { hipLaunchKernelGGL(grid_kernel<false>, dim3(g), dim3(256), 0, 0, gr, N); }, iters);
+    float b = time_it([&] { hipLaunchKernelGGL(grid_kernel<true>, dim3(g), dim3(256), 0, 0, gr, N); }, iters);
+    printf("FrozenLake-shaped skeleton (117 B/env-step real): rng AoS 32-B records %.2f us | rng SoA rows %.2f us\n", a, b);
   }
   return 0;
 }
