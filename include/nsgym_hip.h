@@ -132,6 +132,7 @@ enum {
   NSG_CNT_COUNT = 4
 };
 #define NSG_CNT_SHARDS 16384
+#define NSG_MAX_ENVS (1LL << 27) /* envs per handle: rows are addressed with 32-bit byte offsets */
 
 /* One tunable parameter = (Scheduler, UpdateFn) pair: UpdateFn.__call__ (ns_gym/base.py:124-149). */
 typedef struct nsg_param_cfg {

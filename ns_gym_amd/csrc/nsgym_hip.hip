@@ -131,7 +131,7 @@ size_t nsg_sizeof_layout(void) { return sizeof(nsg_layout); }
 
 int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
   if (!out) return fail(NSG_EINVAL, "out is NULL");
-  if (n <= 0) return fail(NSG_EINVAL, "n must be positive");
+  if (n <= 0 || n > NSG_MAX_ENVS) return fail(NSG_EINVAL, "n must be in [1, 2^27]");
   if (!cfg || cfg->env_type < 0 || cfg->env_type >= NSG_ENV_COUNT) return fail(NSG_EINVAL, "bad config");
   memset(out, 0, sizeof(*out));
   const int e = cfg->env_type, P = cfg->n_params;
@@ -185,7 +185,8 @@ int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
 int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, int64_t n, nsg_handle** out) {
   if (!out) return fail(NSG_EINVAL, "out is NULL");
   *out = nullptr;
-  if (n <= 0 || n > (int64_t)1 << 31) return fail(NSG_EINVAL, "n must be in [1, 2^31]");
+  // the kernels address a row with a 32-bit BYTE offset per lane (32-byte stream records: i * 32 < 2^32)
+  if (n <= 0 || n > NSG_MAX_ENVS) return fail(NSG_EINVAL, "n must be in [1, 2^27] envs per handle (got %lld); shard larger batches over several handles", (long long)n);
   if (table_bytes && !tables) return fail(NSG_EINVAL, "tables is NULL");
   int rc = validate(cfg, table_bytes);
   if (rc) return rc;

@@ -58,7 +58,10 @@ def test_layout_query_is_pure_host_arithmetic(lib):
     assert lib.nsg_layout_query(C.byref(cfg), 64, C.byref(lay)) == 0
     assert (lay.cell, lay.theta, lay.table_prob, lay.obs, lay.prob, lay.phys) == (64, 192, 192, 0, 64, 0)
     assert lib.nsg_layout_query(C.byref(cfg), 0, C.byref(lay)) != 0
-    assert b"positive" in lib.nsg_last_error()
+    assert b"2^27" in lib.nsg_last_error()
+    # maximum batch per handle: rows are addressed with 32-bit byte offsets (32-byte stream records)
+    assert lib.nsg_layout_query(C.byref(cfg), 1 << 27, C.byref(lay)) == 0 and lay.theta == 3 << 27
+    assert lib.nsg_layout_query(C.byref(cfg), (1 << 27) + 1, C.byref(lay)) == -22
 
 
 def test_errors_do_not_throw_across_the_abi(lib):

@@ -81,3 +81,34 @@ def test_full_batch_is_deterministic():
         env.close()
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["c1_cartpole_masspole_inc", "c3_frozenlake_step50"])
+def test_maximum_batch_per_handle(name):
+    """N = 2^27, the largest batch one handle takes (rows are addressed with 32-bit byte offsets; the
+    32-byte stream records reach offset 2^32 - 32): the envs at the very end of the batch must behave
+    exactly like the same seeds stepped in a small batch."""
+    import torch
+
+    spec = TRAJ_SPECS[name]
+    is_fl = spec["env_id"] == "FrozenLake-v1"
+    big_n, tail, T = 1 << 27, 1000, 12
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 << 30:
+        pytest.skip("needs ~25 GB of device memory")
+    big = make_env_from_spec(_vec, spec, n=big_n, track_returns=True)
+    small = make_env_from_spec(_vec, spec, n=tail, track_returns=True)
+    big.reset(seed=5)                                                     # env i <- seed 5 + i
+    small.reset(seed=(np.arange(big_n - tail, big_n, dtype=np.uint64) + np.uint64(5)))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    acts = torch.randint(0, 4 if is_fl else 2, (big_n,), dtype=torch.int32, device="cuda", generator=g)
+    for k in range(T):
+        a = torch.roll(acts, k)                                           # a different action vector per step, no new 512 MB draws
+        big.step(a)
+        small.step(a[big_n - tail:].contiguous())
+    for attr in ("state", "t", "reward", "terminated", "truncated", "theta"):
+        x, y = getattr(big, attr), getattr(small, attr)
+        assert torch.equal(x[..., big_n - tail:] if attr == "theta" else x[big_n - tail:], y), attr
+    c = big.counters()
+    assert c["env_steps"] + c["episodes"] - int((big.terminated | big.truncated).sum()) == big_n * T
+    big.close(); small.close()
