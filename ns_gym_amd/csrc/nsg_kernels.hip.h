@@ -66,14 +66,16 @@ struct ActionPtrs {
 // Dynamic LDS layout (sized per handle at launch: a batch with tiny tables must not pay 22 KB of
 // LDS per workgroup, which would cap residency at 6-7 workgroups per CU):
 //   [ pad | reset_n[2] | pad | reset_list[kBlock] (short) | reset_state[kBlock][4] (f64) |
-//     table blob | ziggurat ki/wi/fi ]
+//     table blob | ziggurat ki/wi/fi | streams[kBlock][4] (u64; fused rollouts of classic envs only) ]
 struct LdsTables {
   int* reset_n;         // [2] workgroup-level compaction of the autoreset lanes (double-buffered)
   short* reset_list;    // [kBlock] lanes whose env resets in this chunk
   double* reset_state;  // [kBlock][4] initial states drawn by the helper lanes, read back by the owners
   uint64_t* blob;       // constant-table blob
   uint64_t* zig;        // 768 words (normal) + 768 words (exponential), each only when needed
+  uint64_t* streams;    // [kBlock][4] the chunk's env PCG64 records while a fused rollout runs (IoMode::lds_rng)
 };
+constexpr int kLdsStreamBytes = kBlock * 32;
 constexpr int kLdsHeaderBytes = 32 + kBlock * 2 + kBlock * 4 * 8;
 
 __host__ __device__ inline int lds_bytes_for(int table_bytes, int uses_normal, int uses_exp) {
@@ -89,6 +91,7 @@ __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, 
   lds.reset_state = (double*)(base + 32 + kBlock * 2);
   lds.blob = (uint64_t*)(base + kLdsHeaderBytes);
   lds.zig = (uint64_t*)(base + kLdsHeaderBytes + ((sg.table_bytes + 7) & ~7));
+  lds.streams = (uint64_t*)(base + lds_bytes_for(sg.table_bytes, sg.uses_normal, sg.uses_exp));  // valid when the launch reserved it
   const int tid = threadIdx.x;
   uint64_t* zexp = lds.zig + (sg.uses_normal ? 768 : 0);
   if (sg.uses_normal) {
@@ -196,6 +199,7 @@ struct IoMode {  // wave-uniform
   bool load;   // fetch the persistent rows from memory (else: they are in the LaneState)
   bool store;  // write them back
   bool dirty;  // the LaneState's θ rows 0/1 may differ from memory (earlier fused steps did not store)
+  bool lds_rng;  // the chunk's env PCG64 records are in LDS (fused rollouts): the reset hand-over has no global round trip
 };
 
 // Fire predicate of param p of env i.  Deterministic schedulers are pure functions of t; the
@@ -293,10 +297,16 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     helper = tid < n_reset;
     if (helper) {
       owner = lds.reset_list[tid];
-      pcg_load(b.rng_env, N, base + owner, g);
+      if (io.lds_rng) {
+        const uint64_t* rec = lds.streams + owner * 4;
+        g.sh = rec[0]; g.sl = rec[1]; g.ih = rec[2]; g.il = rec[3];
+      } else {
+        pcg_load(b.rng_env, N, base + owner, g);
+      }
     }
   };
-  if constexpr (kEarlyDraw<FULL>) queue_resets();
+  const bool early_draw = kEarlyDraw<FULL> && !io.lds_rng;  // LDS-resident records: no latency to hide
+  if (early_draw) queue_resets();
 
   double th[T::NTHETA + T::NDERIVED];
 #pragma unroll
@@ -439,11 +449,16 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   const bool done = term || trunc;
 
   // ---- compacted resets: queue -> helper lanes draw -> owners read back ----------------------
-  if constexpr (!kEarlyDraw<FULL>) queue_resets();
+  if (!early_draw) queue_resets();
   if (helper) {  // gymnasium reset(): np_random draws of the initial state [UPSTREAM]
     double r0[T::PHYS];
     env_reset_draw<ENV>(g, r0);
-    pcg_store_state(b.rng_env, N, base + owner, g);
+    if (io.lds_rng) {
+      uint64_t* rec = lds.streams + owner * 4;
+      rec[0] = g.sh; rec[1] = g.sl;
+    } else {
+      pcg_store_state(b.rng_env, N, base + owner, g);
+    }
 #pragma unroll
     for (int k = 0; k < T::PHYS; k++) lds.reset_state[owner * 4 + k] = r0[k];
   }
@@ -718,7 +733,7 @@ __device__ __forceinline__ void step_block(const nsg_config& cfg, const nsg_buff
     step_grid<ENV, FULL>(cfg, b, N, tb, zg, actions, out, i, i < N, wc);
   } else {
     LaneState<ENV> ls;
-    step_chunk<ENV, FULL>(cfg, b, N, tb, zg, actions, out, base, parity, lds, wc, ls, IoMode{true, true, false});
+    step_chunk<ENV, FULL>(cfg, b, N, tb, zg, actions, out, base, parity, lds, wc, ls, IoMode{true, true, false, false});
   }
 }
 

@@ -30,6 +30,19 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
   int parity = 0;
   for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
     [[maybe_unused]] LaneState<GRID ? NSG_ENV_CARTPOLE : ENV> ls;
+    // classic envs: the chunk's env streams live in LDS for the K steps, so the per-step reset hand-over
+    // (helper lanes draw the queued envs' initial states) has no global-memory round trip on the
+    // workgroup's critical path; HBM sees the records once per launch
+    [[maybe_unused]] const int64_t ir = c * kBlock + threadIdx.x;
+    if constexpr (!GRID) {
+      if (ir < N) {
+        Pcg g;
+        pcg_load(b.rng_env, N, ir, g);
+        uint64_t* rec = lds.streams + threadIdx.x * 4;
+        rec[0] = g.sh; rec[1] = g.sl; rec[2] = g.ih; rec[3] = g.il;
+      }
+      __syncthreads();
+    }
     for (int k = 0; k < k_steps; k++) {
       StepOut out;
       // the LAST step writes into the env's own output rows (so the handle's buffers describe the env
@@ -50,9 +63,18 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
       if constexpr (GRID) {
         step_block<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc);
       } else {
-        step_chunk<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, k == k_steps - 1, k > 0});
+        step_chunk<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, k == k_steps - 1, k > 0, true});
       }
       parity ^= 1;
+    }
+    if constexpr (!GRID) {
+      __syncthreads();
+      if (ir < N) {
+        const uint64_t* rec = lds.streams + threadIdx.x * 4;
+        Pcg g = {rec[0], rec[1], 0, 0};
+        pcg_store_state(b.rng_env, N, ir, g);
+      }
+      __syncthreads();  // the next chunk refills the records
     }
   }
   flush_counts(b.counters, (int)blockIdx.x, wc);

@@ -314,16 +314,18 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
   memset(&o, 0, sizeof(o));
   if (out) o = *out;
   hipStream_t s = (hipStream_t)stream;
+  // fused rollouts of the classic envs keep the chunk's env PCG64 records in LDS
+  const size_t rollout_lds = (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp) +
+                             (is_grid_env(h->host.cfg.env_type) ? 0 : kLdsStreamBytes);
   if (h->spec) {
     void* args[] = {(void*)&h->dev, (void*)&actions_dev, (void*)&k_steps, (void*)&o};
-    HIP_TRY(hipModuleLaunchKernel(h->spec->rollout, grid_for(h->n), 1, 1, kBlock, 1, 1,
-                                  (unsigned)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp), s, args, nullptr));
+    HIP_TRY(hipModuleLaunchKernel(h->spec->rollout, grid_for(h->n), 1, 1, kBlock, 1, 1, (unsigned)rollout_lds, s, args, nullptr));
   } else if (h->host.simple_theta) {
     DISPATCH_ENV(h->host.cfg.env_type,
-                 hipLaunchKernelGGL((rollout_kernel<E, false>), dim3(grid_for(h->n)), dim3(kBlock), (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp), s, h->dev, actions_dev, k_steps, o));
+                 hipLaunchKernelGGL((rollout_kernel<E, false>), dim3(grid_for(h->n)), dim3(kBlock), rollout_lds, s, h->dev, actions_dev, k_steps, o));
   } else {
     DISPATCH_ENV(h->host.cfg.env_type,
-                 hipLaunchKernelGGL((rollout_kernel<E, true>), dim3(grid_for(h->n)), dim3(kBlock), (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp), s, h->dev, actions_dev, k_steps, o));
+                 hipLaunchKernelGGL((rollout_kernel<E, true>), dim3(grid_for(h->n)), dim3(kBlock), rollout_lds, s, h->dev, actions_dev, k_steps, o));
   }
   HIP_TRY(hipGetLastError());
   // the last step landed in the handle's own output rows: mirror them into the last trajectory slice
