@@ -30,6 +30,9 @@ class ConstraintViolationWarning(Warning):
     (ns_gym/wrappers/classic_control.py:9-12)."""
 
 
+_AUTO_SPECIALIZE_MIN_ENVS = 1 << 16   # below this a launch is latency-bound and the compile is not worth a second
+
+
 class VecNSEnv:
     """Vectorised non-stationary environment (duck-types gymnasium.vector.VectorEnv).
 
@@ -40,11 +43,12 @@ class VecNSEnv:
     def __init__(self, env, tunable_params: dict, num_envs: int, change_notification: bool = False,
                  delta_change_notification: bool = False, in_sim_change: bool = False, scalar_reward: bool = True,
                  persistent_params: bool = False, track_returns: bool = False, device=None, is_sim_env: bool = False,
-                 violation_mask: bool = False, specialize: bool = False,
+                 violation_mask: bool = False, specialize: bool | None = None,
                  **kwargs):
         """`specialize=True` compiles config-specialised step / rollout kernels for this batch (hiprtc, once per
-        distinct configuration per process, ~1 s; `NSG_SPEC_CACHE=<dir>` keeps them on disk): same results,
-        ~10-20 % less time per step.  Worth it for long runs; the generic kernels need no compilation."""
+        distinct configuration per process, ~0.6 s; `NSG_SPEC_CACHE=<dir>` keeps them on disk): same results bit
+        for bit, 10-35 % less time per step.  `False`: the precompiled generic kernels.  `None` (default): specialise
+        batches of >= 65 536 envs when the runtime compiler is available, silently stay generic otherwise."""
         self.lib = _lib.load()
         self._row_cache = {}
         if not torch.cuda.is_available():
@@ -93,8 +97,12 @@ class VecNSEnv:
                        "nsg_create")
             self._h = h
             _lib.check(self.lib.nsg_bind(self._h, C.byref(self._bufs)), "nsg_bind")
-            if specialize:
-                self.specialize()
+            if specialize or (specialize is None and self.N >= _AUTO_SPECIALIZE_MIN_ENVS):
+                try:
+                    self.specialize()
+                except _lib.NsgError:
+                    if specialize:   # asked for explicitly
+                        raise
         self._make_views()
         from . import spaces
 
