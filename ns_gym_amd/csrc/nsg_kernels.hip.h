@@ -740,7 +740,8 @@ __device__ __forceinline__ void step_block(const nsg_config& cfg, const nsg_buff
 // Homogeneous launch: grid-stride over 256-env chunks.  `cfg` is the segment's own copy (generic
 // kernels, scalar loads) or a compile-time constant of a config-specialised build (nsg_spec.hip.h).
 template <int ENV, bool FULL>
-__device__ __forceinline__ void step_body(const nsg_config& cfg, const Segment& sg, const void* __restrict__ actions) {
+__device__ __forceinline__ void step_body(const nsg_config& cfg, const Segment& sg, const void* __restrict__ actions,
+                                          const int block_rel, const int block_count) {
   LdsTables lds;
   Tables tb;
   ZigLds zg;
@@ -751,47 +752,41 @@ __device__ __forceinline__ void step_body(const nsg_config& cfg, const Segment& 
   const StepOut out = default_out(b);
   const int64_t chunks = (N + kBlock - 1) / kBlock;
   int parity = 0;
-  for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x, parity ^= 1)
+  for (int64_t c = block_rel; c < chunks; c += block_count, parity ^= 1)
     step_block<ENV, FULL>(cfg, b, N, tb, zg, actions, out, c * kBlock, parity, lds, wc);
-  flush_counts(b.counters, (int)blockIdx.x, wc);
+  flush_counts(b.counters, block_rel, wc);
 }
 
 template <int ENV, bool FULL>
 __global__ __launch_bounds__(kBlock, NSG_MIN_WAVES) void step_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions) {
-  step_body<ENV, FULL>(seg->cfg, *seg, actions);
+  step_body<ENV, FULL>(seg->cfg, *seg, actions, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Heterogeneous launch: block ranges are assigned to env-type segments, so the env-type switch
 // is uniform per workgroup (no intra-wave divergence between Pendulum and Acrobot lanes).
+__device__ __forceinline__ int group_segment_of_block(const Segment* __restrict__ segs, int nseg) {
+  int sidx = 0;  // block ranges are disjoint but not ordered by member index (the host places long-running env types first)
+  for (int k = 1; k < nseg; k++)
+    if ((int)blockIdx.x >= segs[k].block_begin && (int)blockIdx.x < segs[k].block_begin + segs[k].block_count) sidx = k;
+  return sidx;
+}
+
 template <bool FULL>
 __global__ __launch_bounds__(kBlock) void step_group_kernel(const Segment* __restrict__ segs, int nseg, ActionPtrs acts) {
-  LdsTables lds;
-  int sidx = 0;
-  for (int k = 1; k < nseg; k++)
-    if ((int)blockIdx.x >= segs[k].block_begin) sidx = k;
+  const int sidx = group_segment_of_block(segs, nseg);
   const Segment& sg = segs[sidx];
-  Tables tb;
-  ZigLds zg;
-  stage_tables(sg, lds, tb, zg);
-  WaveCounts wc;
-  const int64_t chunks = (sg.N + kBlock - 1) / kBlock;
   const void* actions = acts.p[sidx];
-  const StepOut out = default_out(sg.buf);
-  int parity = 0;
-  for (int64_t c = (int)blockIdx.x - sg.block_begin; c < chunks; c += sg.block_count, parity ^= 1) {
-    const int64_t base = c * kBlock;
-    switch (sg.cfg.env_type) {
-      case NSG_ENV_CARTPOLE: step_block<NSG_ENV_CARTPOLE, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
-      case NSG_ENV_PENDULUM: step_block<NSG_ENV_PENDULUM, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
-      case NSG_ENV_ACROBOT: step_block<NSG_ENV_ACROBOT, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
-      case NSG_ENV_MOUNTAINCAR: step_block<NSG_ENV_MOUNTAINCAR, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
-      case NSG_ENV_MOUNTAINCAR_CONT: step_block<NSG_ENV_MOUNTAINCAR_CONT, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
-      case NSG_ENV_FROZENLAKE: step_block<NSG_ENV_FROZENLAKE, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
-      case NSG_ENV_CLIFFWALKING: step_block<NSG_ENV_CLIFFWALKING, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
-      default: step_block<NSG_ENV_BRIDGE, FULL>(sg.cfg, sg.buf, sg.N, tb, zg, actions, out, base, parity, lds, wc); break;
-    }
+  const int rel = (int)blockIdx.x - sg.block_begin;
+  switch (sg.cfg.env_type) {
+    case NSG_ENV_CARTPOLE: step_body<NSG_ENV_CARTPOLE, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
+    case NSG_ENV_PENDULUM: step_body<NSG_ENV_PENDULUM, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
+    case NSG_ENV_ACROBOT: step_body<NSG_ENV_ACROBOT, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
+    case NSG_ENV_MOUNTAINCAR: step_body<NSG_ENV_MOUNTAINCAR, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
+    case NSG_ENV_MOUNTAINCAR_CONT: step_body<NSG_ENV_MOUNTAINCAR_CONT, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
+    case NSG_ENV_FROZENLAKE: step_body<NSG_ENV_FROZENLAKE, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
+    case NSG_ENV_CLIFFWALKING: step_body<NSG_ENV_CLIFFWALKING, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
+    default: step_body<NSG_ENV_BRIDGE, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
   }
-  flush_counts(sg.buf.counters, (int)blockIdx.x - sg.block_begin, wc);
 }
 
 // ============================================================================================

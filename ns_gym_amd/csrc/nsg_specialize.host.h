@@ -105,7 +105,7 @@ inline std::string spec_source(const nsg_config& cfg, bool full) {
   s += "#define NSG_SPEC_CFG (*reinterpret_cast<const nsg_config*>(nsg::kCfgWords))\n"
        "extern \"C\" __global__ __launch_bounds__(256) void nsg_spec_step(const nsg::Segment* __restrict__ seg,\n"
        "                                                                const void* __restrict__ actions) {\n"
-       "  nsg::step_body<" + targs + ">(NSG_SPEC_CFG, *seg, actions);\n"
+       "  nsg::step_body<" + targs + ">(NSG_SPEC_CFG, *seg, actions, (int)blockIdx.x, (int)gridDim.x);\n"
        "}\n"
        "extern \"C\" __global__ __launch_bounds__(256) void nsg_spec_rollout(const nsg::Segment* __restrict__ seg,\n"
        "                                                                   const void* __restrict__ actions, int k_steps,\n"
@@ -115,15 +115,67 @@ inline std::string spec_source(const nsg_config& cfg, bool full) {
   return s;
 }
 
+inline void emit_cfg_words(std::string& s, const nsg_config& cfg, int index) {
+  char buf[48];
+  snprintf(buf, sizeof(buf), "__device__ const uint64_t kCfgWords%d[] = {\n", index);
+  s += buf;
+  const uint64_t* w = reinterpret_cast<const uint64_t*>(&cfg);
+  for (size_t k = 0; k < sizeof(nsg_config) / 8; k++) {
+    snprintf(buf, sizeof(buf), "0x%016llxull,%s", (unsigned long long)w[k], (k % 4 == 3) ? "\n" : " ");
+    s += buf;
+  }
+  s += "};\n";
+}
+
+// Heterogeneous launch (nsg_step_group) specialised for the ordered tuple of its members' configs:
+// one kernel, the segment a workgroup belongs to selects the member's folded step_body.
+inline std::string group_source(const nsg_config* const* cfgs, const bool* full, int n) {
+  std::string s;
+  s.reserve(16384 * n);
+  s +=
+      "typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
+      "typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t;\n"
+      "typedef unsigned long size_t;\n"
+      "#define NSG_SPEC_BUILD 1\n"
+      "#include \"nsg_kernels.hip.h\"\n"
+      "namespace nsg {\n";
+  for (int k = 0; k < n; k++) emit_cfg_words(s, *cfgs[k], k);
+  s += "}  // namespace nsg\n"
+       "extern \"C\" __global__ __launch_bounds__(256) void nsg_spec_group(const nsg::Segment* __restrict__ segs, int nseg,\n"
+       "                                                                 nsg::ActionPtrs acts) {\n"
+       "  const int sidx = nsg::group_segment_of_block(segs, nseg);\n"
+       "  const nsg::Segment& sg = segs[sidx];\n"
+       "  const int rel = (int)blockIdx.x - sg.block_begin;\n"
+       "  switch (sidx) {\n";
+  char buf[256];
+  for (int k = 0; k < n; k++) {
+    snprintf(buf, sizeof(buf),
+             "    case %d: nsg::step_body<%d, %s>(*reinterpret_cast<const nsg_config*>(nsg::kCfgWords%d), sg, acts.p[%d], rel, "
+             "sg.block_count); break;\n",
+             k, (int)cfgs[k]->env_type, full[k] ? "true" : "false", k, k);
+    s += buf;
+  }
+  s += "    default: break;\n  }\n}\n";
+  return s;
+}
+
+inline std::vector<char> compile_source(const std::string& src, const char* arch, std::string& err);
+
 // Compile the specialised unit for `arch` (e.g. "gfx950"); no GPU needed.  Returns "" and fills `err` on failure.
 inline std::vector<char> spec_compile(const nsg_config& cfg, bool full, const char* arch, std::string& err) {
+  return compile_source(spec_source(cfg, full), arch, err);
+}
+inline std::vector<char> group_compile(const nsg_config* const* cfgs, const bool* full, int n, const char* arch, std::string& err) {
+  return compile_source(group_source(cfgs, full, n), arch, err);
+}
+
+inline std::vector<char> compile_source(const std::string& src, const char* arch, std::string& err) {
   std::vector<char> code;
   const Rtc* r = rtc();
   if (!r) {
     err = "libhiprtc.so could not be loaded (config specialisation needs the ROCm runtime compiler)";
     return code;
   }
-  const std::string src = spec_source(cfg, full);
   const char* headers[] = {nsg_src_abi, nsg_src_math, nsg_src_rng, nsg_src_theta, nsg_src_envs, nsg_src_kernels, nsg_src_rollout};
   const char* names[] = {"nsgym_hip.h",    "nsg_math.hip.h",    "nsg_rng.hip.h",    "nsg_theta.hip.h",
                          "nsg_envs.hip.h", "nsg_kernels.hip.h", "nsg_rollout.hip.h"};
@@ -178,7 +230,9 @@ inline uint64_t fnv1a(const void* p, size_t n, uint64_t h = 0xcbf29ce484222325ul
 // One loaded code object per (device, config): shared by every handle with the same configuration.
 struct Module {
   hipModule_t mod = nullptr;
-  hipFunction_t step = nullptr, rollout = nullptr;
+  hipFunction_t step = nullptr, rollout = nullptr;  // single-config unit
+  hipFunction_t group = nullptr;                     // heterogeneous-launch unit
+  uint64_t h0 = 0;                                    // config key (group keys are built from their members')
 };
 
 struct Key {

@@ -121,6 +121,71 @@ struct nsg_handle {
   const nsg_spec::Module* spec;  // config-specialised step / rollout kernels (nsg_specialize), or NULL
 };
 
+namespace {
+
+uint64_t spec_source_hash() {
+  uint64_t h1 = 0x9e3779b97f4a7c15ull;
+  for (const char* src : {nsg_src_abi, nsg_src_math, nsg_src_rng, nsg_src_theta, nsg_src_envs, nsg_src_kernels, nsg_src_rollout})
+    h1 = nsg_spec::fnv1a(src, strlen(src), h1);
+  return h1;
+}
+
+// Look a code object up in the process cache, then in NSG_SPEC_CACHE=<dir>, else compile it; load it.
+template <typename Compile>
+int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, const nsg_spec::Module** out) {
+  const uint64_t h1 = spec_source_hash();
+  const nsg_spec::Key key{device, h0, h1};
+  std::lock_guard<std::mutex> lock(nsg_spec::cache_mutex());
+  auto& cache = nsg_spec::cache();
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    std::vector<char> code;
+    std::string path;
+    if (const char* dir = getenv("NSG_SPEC_CACHE")) {
+      char name[64];
+      snprintf(name, sizeof(name), "/nsg_%016llx_%016llx.hsaco", (unsigned long long)h0, (unsigned long long)h1);
+      path = std::string(dir) + name;
+      if (FILE* f = fopen(path.c_str(), "rb")) {
+        fseek(f, 0, SEEK_END);
+        const long n = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        if (n > 0) {
+          code.resize((size_t)n);
+          if (fread(code.data(), 1, (size_t)n, f) != (size_t)n) code.clear();
+        }
+        fclose(f);
+      }
+    }
+    if (code.empty()) {
+      std::string err;
+      code = compile(err);
+      if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
+      if (!path.empty()) {
+        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+        if (FILE* f = fopen(tmp.c_str(), "wb")) {
+          const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+          fclose(f);
+          if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
+        }
+      }
+    }
+    nsg_spec::Module m;
+    m.h0 = h0;
+    HIP_TRY(hipModuleLoadData(&m.mod, code.data()));
+    if (group) {
+      HIP_TRY(hipModuleGetFunction(&m.group, m.mod, "nsg_spec_group"));
+    } else {
+      HIP_TRY(hipModuleGetFunction(&m.step, m.mod, "nsg_spec_step"));
+      HIP_TRY(hipModuleGetFunction(&m.rollout, m.mod, "nsg_spec_rollout"));
+    }
+    it = cache.emplace(key, m).first;
+  }
+  *out = &it->second;
+  return NSG_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int nsg_abi_version(void) { return NSG_ABI_VERSION; }
@@ -356,14 +421,28 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
   static thread_local int total_blocks = 0;
   static thread_local int all_simple = 0;
   static thread_local int group_lds = 0;
+  static thread_local const nsg_spec::Module* group_spec = nullptr;
   bool same = n_members == n_handles && built_at == g_generation;
   for (int k = 0; same && k < n_handles; k++) same = members[k] == hs[k];
   if (!same) {
     Segment tmp[NSG_MAX_SEGMENTS];
-    int begin = 0;
+    int order[NSG_MAX_SEGMENTS];
     for (int k = 0; k < n_handles; k++) {
       if (!hs[k] || !hs[k]->bound) return fail(NSG_ENOTBOUND, "group member %d is not bound", k);
       tmp[k] = hs[k]->host;
+      order[k] = k;
+    }
+    // workgroups are dispatched in block order: the members with the longest-running workgroups get the
+    // lowest block ranges (Acrobot's RK4 step takes ~3x a Pendulum step), the short ones fill in behind them
+    auto cost = [&](int k) {
+      static const int kEnvCost[NSG_ENV_COUNT] = {3, 2, 8, 1, 1, 2, 2, 2};  // relative time per workgroup
+      return kEnvCost[hs[k]->host.cfg.env_type] + (hs[k]->host.simple_theta ? 0 : 2);
+    };
+    for (int a = 1; a < n_handles; a++)
+      for (int b = a; b > 0 && cost(order[b]) > cost(order[b - 1]); b--) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+    int begin = 0;
+    for (int j = 0; j < n_handles; j++) {
+      const int k = order[j];
       tmp[k].block_begin = begin;
       tmp[k].block_count = grid_for(hs[k]->n);
       begin += tmp[k].block_count;
@@ -376,10 +455,30 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
     total_blocks = begin;
     all_simple = 1;
     group_lds = 0;
+    bool all_spec = true;
     for (int k = 0; k < n_handles; k++) {
       all_simple &= hs[k]->host.simple_theta;
+      all_spec = all_spec && hs[k]->spec != nullptr;
       const int l = lds_bytes_for(hs[k]->host.table_bytes, hs[k]->host.uses_normal, hs[k]->host.uses_exp);
       if (l > group_lds) group_lds = l;
+    }
+    // every member runs config-specialised kernels: so does the group (one unit for the ordered tuple of configs)
+    group_spec = nullptr;
+    if (all_spec) {
+      uint64_t h0 = 0x67726f7570ull;  // "group"
+      const nsg_config* cfgs[NSG_MAX_SEGMENTS];
+      bool full[NSG_MAX_SEGMENTS];
+      for (int k = 0; k < n_handles; k++) {
+        h0 = nsg_spec::fnv1a(&hs[k]->spec->h0, sizeof(uint64_t), h0);
+        cfgs[k] = &hs[k]->host.cfg;
+        full[k] = !hs[k]->host.simple_theta;
+      }
+      hipDeviceProp_t prop;
+      HIP_TRY(hipGetDeviceProperties(&prop, hs[0]->device));
+      const int rc = get_spec_module(hs[0]->device, h0, true,
+                                     [&](std::string& err) { return nsg_spec::group_compile(cfgs, full, n_handles, prop.gcnArchName, err); },
+                                     &group_spec);
+      if (rc) group_spec = nullptr;  // the generic group kernel stays in force
     }
   }
   ActionPtrs ap;
@@ -388,7 +487,10 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
     if (!actions_dev[k]) return fail(NSG_EINVAL, "actions_dev[%d] is NULL", k);
     ap.p[k] = actions_dev[k];
   }
-  if (all_simple) hipLaunchKernelGGL(step_group_kernel<false>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, d_group, n_handles, ap);
+  if (group_spec) {
+    void* args[] = {(void*)&d_group, (void*)&n_handles, (void*)&ap};
+    HIP_TRY(hipModuleLaunchKernel(group_spec->group, total_blocks, 1, 1, kBlock, 1, 1, (unsigned)group_lds, (hipStream_t)stream, args, nullptr));
+  } else if (all_simple) hipLaunchKernelGGL(step_group_kernel<false>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, d_group, n_handles, ap);
   else hipLaunchKernelGGL(step_group_kernel<true>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, d_group, n_handles, ap);
   HIP_TRY(hipGetLastError());
   return NSG_OK;
@@ -519,58 +621,13 @@ int nsg_specialize(nsg_handle* h) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, h->device));
   const bool full = !h->host.simple_theta;
-  // key: config bytes + engine variant + target + the kernel sources this library was built from
+  // key: config bytes + engine variant + target (+ the kernel sources this library was built from)
   uint64_t h0 = nsg_spec::fnv1a(&h->host.cfg, sizeof(nsg_config));
   h0 = nsg_spec::fnv1a(&full, sizeof(full), h0);
   h0 = nsg_spec::fnv1a(prop.gcnArchName, strlen(prop.gcnArchName), h0);
   if (const char* e = getenv("NSG_SPEC_FLAGS")) h0 = nsg_spec::fnv1a(e, strlen(e), h0);
-  uint64_t h1 = 0x9e3779b97f4a7c15ull;
-  for (const char* src : {nsg_src_abi, nsg_src_math, nsg_src_rng, nsg_src_theta, nsg_src_envs, nsg_src_kernels, nsg_src_rollout})
-    h1 = nsg_spec::fnv1a(src, strlen(src), h1);
-  const nsg_spec::Key key{h->device, h0, h1};
-  std::lock_guard<std::mutex> lock(nsg_spec::cache_mutex());
-  auto& cache = nsg_spec::cache();
-  auto it = cache.find(key);
-  if (it == cache.end()) {
-    std::vector<char> code;
-    // optional on-disk cache of code objects: NSG_SPEC_CACHE=<dir>
-    std::string path;
-    if (const char* dir = getenv("NSG_SPEC_CACHE")) {
-      char name[64];
-      snprintf(name, sizeof(name), "/nsg_%016llx_%016llx.hsaco", (unsigned long long)h0, (unsigned long long)h1);
-      path = std::string(dir) + name;
-      if (FILE* f = fopen(path.c_str(), "rb")) {
-        fseek(f, 0, SEEK_END);
-        const long n = ftell(f);
-        fseek(f, 0, SEEK_SET);
-        if (n > 0) {
-          code.resize((size_t)n);
-          if (fread(code.data(), 1, (size_t)n, f) != (size_t)n) code.clear();
-        }
-        fclose(f);
-      }
-    }
-    if (code.empty()) {
-      std::string err;
-      code = nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err);
-      if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
-      if (!path.empty()) {
-        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-        if (FILE* f = fopen(tmp.c_str(), "wb")) {
-          const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
-          fclose(f);
-          if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
-        }
-      }
-    }
-    nsg_spec::Module m;
-    HIP_TRY(hipModuleLoadData(&m.mod, code.data()));
-    HIP_TRY(hipModuleGetFunction(&m.step, m.mod, "nsg_spec_step"));
-    HIP_TRY(hipModuleGetFunction(&m.rollout, m.mod, "nsg_spec_rollout"));
-    it = cache.emplace(key, m).first;
-  }
-  h->spec = &it->second;
-  return NSG_OK;
+  return get_spec_module(h->device, h0, false,
+                         [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err); }, &h->spec);
 }
 
 int nsg_is_specialized(const nsg_handle* h) { return h && h->spec ? 1 : 0; }

@@ -83,7 +83,7 @@ def main():
         e.close()
     if "pend" in args.work and "acro" in args.work:  # C4: heterogeneous launch, 2^18 each
         n = 1 << 18
-        ep, ea = mk("pend", n), mk("acro", n)
+        ep, ea = mk("pend", n, spec=args.spec), mk("acro", n, spec=args.spec)
         ap_, aa = actions(ep, n), actions(ea, n)
         for _ in range(20):
             step_group([ep, ea], [ap_, aa])
