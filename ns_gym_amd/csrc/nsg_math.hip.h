@@ -64,17 +64,14 @@ NSG_HD void nsg_sincos(double x, double* sn, double* cs) {
                S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
   const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-  // The library is built with -ffp-contract=off because the REFERENCE's formulas run on Python floats
-  // (no fusion); np.sin / np.cos themselves are libm black boxes, so inside them fused multiply-adds are
-  // free to use: half the instructions of the Horner chains, and a little more accurate.
   const double z = y0 * y0;
   const double v = z * y0;
-  const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2);
-  const double s = y0 - (__builtin_fma(z, __builtin_fma(-v, rs, 0.5 * y1), -y1) - v * S1);
-  const double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
+  const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  const double s = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+  const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
   const double hz = 0.5 * z;
   const double wc = 1.0 - hz;
-  const double c = wc + (((1.0 - wc) - hz) + __builtin_fma(z, rc, -(y0 * y1)));
+  const double c = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
   switch (n & 3) {
     case 0: *sn = s; *cs = c; break;
     case 1: *sn = c; *cs = -s; break;
