@@ -1,0 +1,356 @@
+"""The scenarios of the reference's own step/reset suite (tests/test_step_reset.py, non-MuJoCo part),
+re-stated against the drop-in: same class names, same constructor arguments, same assertions about
+reset / step / notification / reward / constraint / persistence / seeding / planning-copy behaviour -
+driven through the N = 1 adaptors, i.e. through the HIP kernels (a batch of one env).
+
+Scenario -> reference test (file:line):
+  reset restores params            test_step_reset.py:69,96      multiple resets            :121
+  t increments                     :161,175                       known update + resolver    :192
+  notification flag combinations   :222,238,258,276               scalar / dataclass reward  :293,304
+  obs structure                    :323,339                       ground truth in info       :358
+  constraint checker               :379                           persistent_params          :436,463,487,765
+  seeding (no seed / same seed)    :560,587,612,712,737           planning copies diverge    :802,937
+  two envs, same seed              :1000,1084
+"""
+import warnings
+from copy import deepcopy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CLASSIC_CONTROL_ENV_IDS = ["CartPole-v1", "Acrobot-v1", "MountainCar-v0", "MountainCarContinuous-v0", "Pendulum-v1"]
+GRIDWORLD_ENV_IDS = ["CliffWalking-v1", "FrozenLake-v1"]
+OBS_KEYS = ["state", "env_change", "delta_change", "relative_time"]
+SEEDING_PARAM = {"CartPole-v1": "masspole", "Acrobot-v1": "LINK_LENGTH_1", "MountainCar-v0": "force",
+                 "MountainCarContinuous-v0": "power", "Pendulum-v1": "m"}
+
+
+def _api():
+    import ns_gym_amd as nsg
+    from ns_gym_amd import wrappers
+    from ns_gym_amd.schedulers import ContinuousScheduler
+    from ns_gym_amd.update_functions import DistributionIncrementUpdate, IncrementUpdate, RandomWalk
+
+    return nsg, wrappers, ContinuousScheduler, IncrementUpdate, RandomWalk, DistributionIncrementUpdate
+
+
+def cc_params(env_id):
+    _, _, Cont, Inc, _, _ = _api()
+    fn, dec = Inc(Cont(), k=0.1), Inc(Cont(), k=-0.1)
+    return {"CartPole-v1": {"masspole": fn, "gravity": fn}, "Acrobot-v1": {"LINK_LENGTH_1": fn, "LINK_MASS_2": fn},
+            "MountainCar-v0": {"gravity": dec, "force": fn}, "MountainCarContinuous-v0": {"power": fn},
+            "Pendulum-v1": {"m": fn, "g": fn}}[env_id]
+
+
+def make_cc(env_id, params=None, **kw):
+    nsg, W, *_ = _api()
+    return W.NSClassicControlWrapper(nsg.make(env_id), params if params is not None else cc_params(env_id), **kw)
+
+
+def make_gw(env_id, **kw):
+    nsg, W, Cont, _, _, DInc = _api()
+    cls = {"CliffWalking-v1": W.NSCliffWalkingWrapper, "FrozenLake-v1": W.NSFrozenLakeWrapper}[env_id]
+    return cls(nsg.make(env_id), {"P": DInc(Cont(), k=-0.1)}, **kw)
+
+
+def walk(env, param, n, action=None):
+    out = []
+    for _ in range(n):
+        env.step(env.action_space.sample() if action is None else action)
+        out.append(getattr(env.unwrapped, param))
+    return out
+
+
+# ---------------------------------------------------------------- reset
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS)
+def test_reset_restores_all_params_classic_control(env_id):
+    nsg, *_ = _api()
+    env = make_cc(env_id)
+    env.reset(seed=42)
+    names = nsg.TUNABLE_PARAMS[env.spec.class_name]
+    before = {p: getattr(env.unwrapped, p) for p in names}
+    for _ in range(10):
+        _, _, done, trunc, _ = env.step(env.action_space.sample())
+        if done or trunc:
+            break
+    assert any(getattr(env.unwrapped, p) != before[p] for p in cc_params(env_id))
+    env.reset(seed=42)
+    for p in names:
+        assert np.isclose(getattr(env.unwrapped, p), before[p]), p
+
+
+@pytest.mark.parametrize("env_id", GRIDWORLD_ENV_IDS)
+def test_reset_restores_all_params_gridworld(env_id):
+    env = make_gw(env_id)
+    env.reset(seed=42)
+    before = list(env.transition_prob)
+    for _ in range(5):
+        _, _, done, trunc, _ = env.step(env.action_space.sample())
+        if done or trunc:
+            break
+    env.reset(seed=42)
+    assert list(env.transition_prob) == before
+
+
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS)
+def test_multiple_resets_classic_control(env_id):
+    nsg, *_ = _api()
+    env = make_cc(env_id)
+    defaults = nsg.TUNABLE_PARAMS[env.spec.class_name]
+    for cycle in range(3):
+        obs, info = env.reset(seed=42)
+        assert env.t == 0 and isinstance(obs, dict) and all(k in obs for k in OBS_KEYS) and obs["relative_time"] == 0
+        for p in cc_params(env_id):
+            assert obs["env_change"][p] == 0 and obs["delta_change"][p] == 0.0
+        for p, v in defaults.items():
+            assert np.isclose(getattr(env.unwrapped, p), v), (cycle, p)
+        for _ in range(5):
+            _, _, done, trunc, _ = env.step(env.action_space.sample())
+            if done or trunc:
+                break
+
+
+# ---------------------------------------------------------------- step
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS)
+def test_step_increments_t_classic_control(env_id):
+    env = make_cc(env_id)
+    env.reset(seed=42)
+    for k in range(1, 6):
+        obs, _, done, trunc, _ = env.step(env.action_space.sample())
+        if done or trunc:
+            break
+        assert env.t == k and obs["relative_time"] == k
+
+
+@pytest.mark.parametrize("env_id", GRIDWORLD_ENV_IDS)
+def test_step_increments_t_gridworld(env_id):
+    env = make_gw(env_id)
+    env.reset(seed=42)
+    for k in range(1, 6):
+        obs, _, done, trunc, _ = env.step(env.action_space.sample())
+        if done or trunc:
+            break
+        assert obs["relative_time"] == k
+
+
+def test_step_updates_params_by_known_amount():
+    _, _, Cont, Inc, _, _ = _api()
+    k = 0.5
+    env = make_cc("CartPole-v1", {"masspole": Inc(Cont(start=0), k=k)})
+    env.reset(seed=42)
+    u = env.unwrapped
+    masspole, masscart, length = u.masspole, u.masscart, u.length
+    env.step(0)
+    assert np.isclose(u.masspole, masspole + k)
+    assert np.isclose(u.total_mass, masspole + k + masscart)            # dependency resolver, classic_control.py:426-444
+    assert np.isclose(u.polemass_length, (masspole + k) * length)
+
+
+@pytest.mark.parametrize("cn,dn", [(False, False), (True, False), (True, True)])
+def test_step_notification_flags(cn, dn):
+    env = make_cc("CartPole-v1", change_notification=cn, delta_change_notification=dn)
+    env.reset(seed=42)
+    obs, _, _, _, info = env.step(0)
+    names = list(cc_params("CartPole-v1"))
+    assert any(obs["env_change"][p] for p in names) == cn
+    assert any(obs["delta_change"][p] != 0.0 for p in names) == dn
+    # the ground truth is in info whatever the notification flags say (test_step_reset.py:358)
+    assert isinstance(info["Ground Truth Env Change"], dict) and all(info["Ground Truth Env Change"][p] == 1 for p in names)
+    assert isinstance(info["Ground Truth Delta Change"], dict) and all(info["Ground Truth Delta Change"][p] != 0.0 for p in names)
+
+
+def test_step_notification_false_true_raises():
+    with pytest.raises(AssertionError):
+        make_cc("CartPole-v1", change_notification=False, delta_change_notification=True)
+
+
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS)
+def test_step_reward_scalar_and_dataclass(env_id):
+    from ns_gym_amd.base import Reward
+
+    env = make_cc(env_id, scalar_reward=True)
+    env.reset(seed=42)
+    _, reward, _, _, _ = env.step(env.action_space.sample())
+    assert isinstance(reward, (int, float, np.floating))
+    env = make_cc(env_id, scalar_reward=False)
+    env.reset(seed=42)
+    _, reward, _, _, _ = env.step(env.action_space.sample())
+    assert isinstance(reward, Reward)
+    assert all(hasattr(reward, f) for f in ("reward", "env_change", "delta_change", "relative_time"))
+
+
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS + GRIDWORLD_ENV_IDS)
+def test_step_obs_structure(env_id):
+    env = make_cc(env_id) if env_id in CLASSIC_CONTROL_ENV_IDS else make_gw(env_id)
+    obs, info = env.reset(seed=42)
+    assert isinstance(obs, dict) and all(k in obs for k in OBS_KEYS) and obs["relative_time"] == 0
+    obs, _, _, _, _ = env.step(env.action_space.sample())
+    assert isinstance(obs, dict) and all(k in obs for k in OBS_KEYS) and obs["relative_time"] > 0
+
+
+def test_constraint_checker_prevents_invalid_values():
+    _, W, Cont, Inc, _, _ = _api()
+    env = make_cc("CartPole-v1", {"masscart": Inc(Cont(start=0), k=-100.0)})
+    env.reset(seed=42)
+    with pytest.warns(W.ConstraintViolationWarning):
+        env.step(0)
+    assert env.unwrapped.masscart > 0
+
+
+# ---------------------------------------------------------------- persistent_params
+def test_persistent_params_preserves_values():
+    _, _, Cont, Inc, _, _ = _api()
+    env = make_cc("CartPole-v1", {"masspole": Inc(Cont(), k=0.5)}, persistent_params=True)
+    env.reset(seed=42)
+    initial = env.unwrapped.masspole
+    for _ in range(5):
+        _, _, done, trunc, _ = env.step(env.action_space.sample())
+        if done or trunc:
+            break
+    mutated = env.unwrapped.masspole
+    assert mutated != initial
+    env.reset(seed=42)
+    assert env.t == 0 and env.unwrapped.masspole == mutated
+
+
+def test_persistent_params_rng_continuity_and_seed_override():
+    _, _, Cont, _, RW, _ = _api()
+    env = make_cc("CartPole-v1", {"masspole": RW(Cont(), mu=0, sigma=0.01, seed=42)}, persistent_params=True)
+    env.reset(seed=0)
+    a = walk(env, "masspole", 5, action=0)
+    env.reset()                                    # no seed: the stream continues
+    b = walk(env, "masspole", 5, action=0)
+    assert a != b
+    # an explicit seed re-seeds even with persistent params: the same DELTAS again (test_step_reset.py:765)
+    def deltas():
+        prev, out = env.unwrapped.masspole, []
+        for _ in range(5):
+            env.step(0)
+            cur = env.unwrapped.masspole
+            out.append(cur - prev)
+            prev = cur
+        return out
+    env.reset(seed=0)
+    d1 = deltas()
+    env.reset(seed=0)
+    d2 = deltas()
+    assert np.allclose(d1, d2)
+
+
+def test_persistent_params_default_false_restores():
+    env = make_cc("CartPole-v1", persistent_params=False)
+    env.reset(seed=42)
+    initial = env.unwrapped.masspole
+    for _ in range(5):
+        _, _, done, trunc, _ = env.step(env.action_space.sample())
+        if done or trunc:
+            break
+    env.reset(seed=42)
+    assert np.isclose(env.unwrapped.masspole, initial)
+
+
+# ---------------------------------------------------------------- seeding
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS)
+def test_reset_seeding_classic_control(env_id):
+    _, _, Cont, _, RW, _ = _api()
+    param = SEEDING_PARAM[env_id]
+    env = make_cc(env_id, {param: RW(Cont(), mu=0, sigma=0.01, seed=42)})
+    env.reset(seed=0)
+    a = walk(env, param, 5)
+    env.reset()                                    # no seed: a different sequence (test_step_reset.py:560)
+    b = walk(env, param, 5)
+    assert a != b
+    env.reset(seed=0)                              # same seed: the same sequence (:587)
+    c = walk(env, param, 5)
+    assert a == c
+    trajs = []
+    for _ in range(3):                             # several unseeded episodes all differ (:612)
+        env.reset()
+        trajs.append(walk(env, param, 5))
+    assert trajs[0] != trajs[1] and trajs[1] != trajs[2]
+
+
+@pytest.mark.parametrize("env_id", GRIDWORLD_ENV_IDS)
+def test_reset_seeding_gridworld(env_id):
+    def states(env, n=12):
+        out = []
+        for k in range(n):
+            obs, _, done, trunc, _ = env.step(k % 4)
+            out.append(obs["state"])
+            if done or trunc:
+                break
+        return out
+
+    nsg, W, Cont, _, _, DInc = _api()
+    cls = {"CliffWalking-v1": W.NSCliffWalkingWrapper, "FrozenLake-v1": W.NSFrozenLakeWrapper}[env_id]
+    env = cls(nsg.make(env_id), {"P": DInc(Cont(), k=-0.05)}, initial_prob_dist=[0.4, 0.3, 0.3] if env_id == "FrozenLake-v1" else [0.4, 0.2, 0.2, 0.2])
+    env.reset(seed=0)
+    a = states(env)
+    env.reset(seed=0)
+    assert states(env) == a                        # same seed: same slips (test_step_reset.py:737)
+    seen = []
+    for _ in range(6):                             # unseeded resets continue the env stream (:712)
+        env.reset()
+        seen.append(tuple(states(env)))
+    assert len(set(seen)) > 1
+
+
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS)
+def test_two_envs_same_seed_identical(env_id):
+    _, _, Cont, _, RW, _ = _api()
+    param = SEEDING_PARAM[env_id]
+    envs = [make_cc(env_id, {param: RW(Cont(), mu=0, sigma=0.01, seed=42)}) for _ in range(2)]
+    obs = [e.reset(seed=7)[0] for e in envs]
+    assert np.array_equal(obs[0]["state"], obs[1]["state"])
+    for k in range(8):
+        a = 0 if hasattr(envs[0].action_space, "n") else np.zeros(envs[0].action_space.shape, dtype=np.float32)
+        out = [e.step(a) for e in envs]
+        assert np.array_equal(out[0][0]["state"], out[1][0]["state"]) and out[0][1] == out[1][1]
+        assert getattr(envs[0].unwrapped, param) == getattr(envs[1].unwrapped, param)
+
+
+# ---------------------------------------------------------------- planning copies
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS)
+def test_planning_env_rng_diverges_classic_control(env_id):
+    """A planning copy must not foresee the real env's future stochastic parameter changes
+    (base.py:433-441: its update-fn streams are re-seeded from fresh entropy)."""
+    _, _, Cont, _, RW, _ = _api()
+    param = SEEDING_PARAM[env_id]
+    env = make_cc(env_id, {param: RW(Cont(), mu=0, sigma=0.1, seed=42)}, change_notification=True,
+                  delta_change_notification=True, in_sim_change=True)
+    env.reset(seed=0)
+    for _ in range(3):
+        _, _, done, trunc, _ = env.step(env.action_space.sample())
+        if done or trunc:
+            env.reset(seed=0)
+    plan = deepcopy(env)                           # in_sim_change copy: its θ keeps evolving, with its own stream
+    assert plan.is_sim_env and not env.is_sim_env
+    action = 0 if hasattr(env.action_space, "n") else np.zeros(env.action_space.shape, dtype=np.float32)
+    real, sim = [], []
+    for _ in range(10):
+        _, _, done, trunc, _ = env.step(action)
+        if done or trunc:
+            break
+        real.append(getattr(env.unwrapped, param))
+        plan.step(action)
+        sim.append(getattr(plan.unwrapped, param))
+    assert len(real) > 0 and real != sim
+
+
+def test_planning_env_is_frozen_and_requires_reset():
+    env = make_cc("CartPole-v1", change_notification=True, delta_change_notification=True)
+    with pytest.raises(AssertionError):
+        env.get_planning_env()                     # classic_control.py:127-129
+    env.reset(seed=1)
+    for _ in range(3):
+        env.step(0)
+    plan = env.get_planning_env()
+    before = plan.unwrapped.masspole
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plan.step(0)
+    assert plan.unwrapped.masspole == before       # frozen θ (classic_control.py:70-75) ...
+    env.step(0)
+    assert env.unwrapped.masspole != before        # ... while the real env moves on
