@@ -289,6 +289,30 @@ class NSCliffWalkingWrapper(_NSSingle):
         info["prob"] = 1
         return obs, info
 
+    def _build_P(self):
+        """`unwrapped.P` of the reference (toy_text.py:86-148): {s: {a: [(prob, s', reward, terminated) x 4]}} in
+        slip order [a, a+1, a-1, a+2], rebuilt on demand from the device-side table probabilities."""
+        tp = [float(x) for x in self._vec.table_prob[:, 0].tolist()]
+        nrow, ncol = self.shape
+        delta = {0: (-1, 0), 1: (0, 1), 2: (1, 0), 3: (0, -1)}          # UP RIGHT DOWN LEFT (toy_text.py:74-76)
+        mr = self.modified_rewards
+        P = {}
+        for s in range(self.nS):
+            row, col = divmod(s, ncol)
+            P[s] = {}
+            for a in range(self.nA):
+                entries = []
+                for ind, b in enumerate([a, (a + 1) % 4, (a - 1) % 4, (a + 2) % 4]):
+                    nr = min(max(row + delta[b][0], 0), nrow - 1)
+                    nc = min(max(col + delta[b][1], 0), ncol - 1)
+                    cliff = nr == nrow - 1 and 1 <= nc <= ncol - 2
+                    goal = nr == nrow - 1 and nc == ncol - 1
+                    reward = mr["H"] if cliff else mr["G"] if goal else mr["F"]
+                    terminated = bool(self.terminal_cliff) if cliff else goal
+                    entries.append((tp[ind], self.start_state_index if cliff else nr * ncol + nc, reward, terminated))
+                P[s][a] = entries
+        return P
+
 
 class NSBridgeWrapper(_NSSingle):
     """Non-stationary Bridge wrapper (ns_gym/wrappers/toy_text.py:524-715), N = 1 view.  Uniform mode

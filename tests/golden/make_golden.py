@@ -749,6 +749,40 @@ def gen_planning(gym, S, U, CC, FL, spec):
 # --------------------------------------------------------------------------- NumPy bit streams
 
 
+P_TABLE_CASES = {
+    # name: (env id, make kwargs, wrapper kwargs, actions stepped before the table is read)
+    "cliff_default": ("CliffWalking-v1", {}, {}, [0, 1, 2, 3, 0]),
+    "cliff_terminal_rewards": ("CliffWalking-v1", {}, {"terminal_cliff": True, "modified_rewards": {"H": -50, "G": 7, "F": -2, "S": -2},
+                                                     "initial_prob_dist": [0.7, 0.1, 0.1, 0.1]}, [0, 0, 1]),
+    "frozenlake_4x4": ("FrozenLake-v1", {}, {"initial_prob_dist": [0.8, 0.1, 0.1]}, [2, 2, 3]),
+    "frozenlake_8x8_rewards": ("FrozenLake-v1", {"map_name": "8x8"}, {"modified_rewards": {"H": -1, "G": 5, "F": -0.1, "S": -0.1}}, [1, 2, 1, 2, 0]),
+}
+
+
+def gen_p_tables(gym, S, U, FL):
+    """`unwrapped.P` as the reference's NSCliffWalkingWrapper / NSFrozenLakeWrapper install it after a few
+    steps of DistributionDecrementUpdate(k=0.05): [nS, nA, 4, 4] = (prob, next_state, reward, terminated),
+    rows with fewer than 4 outcomes (FrozenLake) padded with NaN."""
+    out = {}
+    for name, (env_id, mk, wk, acts) in P_TABLE_CASES.items():
+        cls = _EXTRA_WRAPPERS[env_id] if env_id in _EXTRA_WRAPPERS else FL
+        env = cls(gym.make(env_id, **mk), {"P": U.DistributionDecrementUpdate(S.ContinuousScheduler(), k=0.05)}, **wk)
+        env.reset(seed=0)
+        for a in acts:
+            _, _, term, trunc, _ = env.step(a)
+            assert not (term or trunc), f"{name}: pick actions that keep the episode alive (stepping a finished env is undefined)"
+        P = env.unwrapped.P
+        nS, nA = len(P), len(P[0])
+        tab = np.full((nS, nA, 4, 4), np.nan)
+        for s in range(nS):
+            for a in range(nA):
+                for i, e in enumerate(P[s][a]):
+                    tab[s, a, i] = [float(e[0]), float(e[1]), float(e[2]), float(bool(e[3]))]
+        out[name] = tab
+        out[name + "__theta"] = np.asarray([float(x) for x in env.transition_prob])
+    return out
+
+
 def gen_numpy_streams():
     out = {}
     seeds = [0, 1, 42, 123, 2**31 - 1, 2**32 - 1, 2**32, 2**32 + 5, 2**63 + 12345, 987654321012345678]
@@ -803,6 +837,10 @@ def gen_numpy_streams():
 def main():
     warnings.simplefilter("ignore")
     gym, S, U, CC, FL = _bind_reference()
+    if "--only-p-tables" in sys.argv:   # add one fixture without touching the others
+        np.savez_compressed(os.path.join(HERE, "p_tables.npz"), **gen_p_tables(gym, S, U, FL))
+        print("p_tables.npz written")
+        return
     manifest = {
         "numpy": np.__version__,
         "python": sys.version.split()[0],
@@ -823,6 +861,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"traj_{name}.npz"), **rec)
         print(name, "episodes:", int(rec["was_reset"].sum()), "fired:", int(rec["gt_env_change"].sum()))
     np.savez_compressed(os.path.join(HERE, "reset_semantics.npz"), **gen_reset_semantics(gym, S, U, CC))
+    np.savez_compressed(os.path.join(HERE, "p_tables.npz"), **gen_p_tables(gym, S, U, FL))
     for name, spec in GRID_SPECS.items():
         rec = gen_grid_trajectory(gym, S, U, spec)
         np.savez_compressed(os.path.join(HERE, f"grid_{name}.npz"), **rec)

@@ -1,0 +1,249 @@
+"""The scenarios of the reference's deepcopy / planning-copy / grid-world wrapper suites
+(tests/test_deepcopy.py, tests/test_gridworld_wrappers.py, tests/test_classic_control_wrapper.py,
+non-MuJoCo), re-stated against the drop-in adaptors: a copy is a batched device fork of one env.
+
+Scenario -> reference test (file:line):
+  deepcopy sets is_sim_env                 test_deepcopy.py:91,107      params match            :121,139
+  copy is independent of the original      :153,183                     frozen unless in_sim_change :205,237,262,293
+  t preserved / copies at various points   :319,332                     reward mode, flags kept :350,370
+  class of the copy (no double wrap)       :405,416                     P is a current snapshot test_gridworld_wrappers.py:179
+  get_planning_env                         test_classic_control_wrapper.py:181, test_gridworld_wrappers.py:128
+  wrapped vs unwrapped, dependency resolver, invalid / valid params   test_classic_control_wrapper.py:246,269,294,306
+"""
+import copy
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_reference_scenarios import CLASSIC_CONTROL_ENV_IDS, GRIDWORLD_ENV_IDS, _api, cc_params, make_cc, make_gw
+
+pytestmark = pytest.mark.gpu
+
+
+def _stepped(env, n, reseed=False):
+    for _ in range(n):
+        _, _, done, trunc, _ = env.step(env.action_space.sample())
+        if (done or trunc) and reseed:
+            env.reset(seed=42)
+    return env
+
+
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS + GRIDWORLD_ENV_IDS)
+def test_deepcopy_sets_is_sim_env_and_keeps_the_class(env_id):
+    env = make_cc(env_id) if env_id in CLASSIC_CONTROL_ENV_IDS else make_gw(env_id)
+    env.reset(seed=42)
+    env.step(env.action_space.sample())
+    sim = copy.deepcopy(env)
+    assert sim.is_sim_env is True and env.is_sim_env is False
+    assert type(sim) is type(env)                    # same wrapper class, wrapped once
+    assert sim is not env and sim.unwrapped is not env.unwrapped
+
+
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS)
+def test_deepcopy_params_match_classic_control(env_id):
+    nsg, *_ = _api()
+    env = _stepped(make_cc(env_id), 0)
+    env.reset(seed=42)
+    _stepped(env, 5)
+    sim = copy.deepcopy(env)
+    for p in nsg.TUNABLE_PARAMS[env.spec.class_name]:
+        assert np.isclose(getattr(env.unwrapped, p), getattr(sim.unwrapped, p)), p
+
+
+@pytest.mark.parametrize("env_id", GRIDWORLD_ENV_IDS)
+def test_deepcopy_params_match_gridworld(env_id):
+    env = make_gw(env_id)
+    env.reset(seed=42)
+    env.step(env.action_space.sample())
+    sim = copy.deepcopy(env)
+    assert sim.unwrapped.P.keys() == env.unwrapped.P.keys()
+    assert list(sim.transition_prob) == list(env.transition_prob)
+
+
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS)
+def test_deepcopy_independence_classic_control(env_id):
+    env = make_cc(env_id, in_sim_change=True)
+    env.reset(seed=42)
+    _stepped(env, 3)
+    before = {p: getattr(env.unwrapped, p) for p in cc_params(env_id)}
+    state, t = np.array(env.unwrapped.state), env.t
+    sim = copy.deepcopy(env)
+    _stepped(sim, 10, reseed=True)
+    for p, v in before.items():
+        assert np.isclose(getattr(env.unwrapped, p), v), p
+    assert np.array_equal(env.unwrapped.state, state) and env.t == t
+
+
+@pytest.mark.parametrize("env_id", GRIDWORLD_ENV_IDS)
+def test_deepcopy_independence_gridworld(env_id):
+    env = make_gw(env_id, in_sim_change=True)
+    env.reset(seed=42)
+    env.step(env.action_space.sample())
+    before = list(env.transition_prob)
+    sim = copy.deepcopy(env)
+    _stepped(sim, 5, reseed=True)
+    assert list(env.transition_prob) == before
+
+
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS)
+@pytest.mark.parametrize("in_sim_change", [False, True])
+def test_deepcopy_sim_env_param_evolution_classic_control(env_id, in_sim_change):
+    env = make_cc(env_id, in_sim_change=in_sim_change)
+    env.reset(seed=42)
+    _stepped(env, 3)
+    sim = copy.deepcopy(env)
+    before = {p: getattr(sim.unwrapped, p) for p in cc_params(env_id)}
+    for _ in range(5):
+        _, _, done, trunc, _ = sim.step(sim.action_space.sample())
+        if done or trunc:
+            break
+    changed = any(not np.isclose(getattr(sim.unwrapped, p), v) for p, v in before.items())
+    assert changed == in_sim_change                  # frozen unless in_sim_change (classic_control.py:70-75)
+
+
+@pytest.mark.parametrize("env_id", GRIDWORLD_ENV_IDS)
+@pytest.mark.parametrize("in_sim_change", [False, True])
+def test_deepcopy_sim_env_param_evolution_gridworld(env_id, in_sim_change):
+    env = make_gw(env_id, in_sim_change=in_sim_change)
+    env.reset(seed=42)
+    env.step(env.action_space.sample())
+    sim = copy.deepcopy(env)
+    before = list(sim.transition_prob)
+    for _ in range(5):
+        _, _, done, trunc, _ = sim.step(sim.action_space.sample())
+        if done or trunc:
+            break
+    assert (list(sim.transition_prob) != before) == in_sim_change
+
+
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS)
+@pytest.mark.parametrize("copy_at_step", [0, 1, 5, 7, 10])
+def test_deepcopy_at_various_points_preserves_t(env_id, copy_at_step):
+    _, W, *_ = _api()
+    env = make_cc(env_id)
+    env.reset(seed=42)
+    _stepped(env, copy_at_step, reseed=True)
+    sim = copy.deepcopy(env)
+    assert sim.is_sim_env is True and sim.t == env.t and isinstance(sim, W.NSClassicControlWrapper)
+
+
+@pytest.mark.parametrize("env_id", ["CartPole-v1", "Pendulum-v1"])
+@pytest.mark.parametrize("scalar_reward", [True, False])
+def test_deepcopy_scalar_reward_propagated(env_id, scalar_reward):
+    from ns_gym_amd.base import Reward
+
+    env = make_cc(env_id, scalar_reward=scalar_reward)
+    env.reset(seed=42)
+    env.step(env.action_space.sample())
+    sim = copy.deepcopy(env)
+    assert sim.scalar_reward == scalar_reward
+    _, reward, _, _, _ = sim.step(sim.action_space.sample())
+    assert isinstance(reward, (int, float, np.floating)) if scalar_reward else isinstance(reward, Reward)
+
+
+@pytest.mark.parametrize("env_id", ["CartPole-v1", "CliffWalking-v1"])
+def test_deepcopy_notification_flags_preserved(env_id):
+    kw = dict(change_notification=True, delta_change_notification=True)
+    env = make_cc(env_id, **kw) if env_id in CLASSIC_CONTROL_ENV_IDS else make_gw(env_id, **kw)
+    env.reset(seed=42)
+    env.step(env.action_space.sample())
+    sim = copy.deepcopy(env)
+    assert sim.change_notification is True and sim.delta_change_notification is True
+
+
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS + GRIDWORLD_ENV_IDS)
+def test_get_planning_env(env_id):
+    kw = dict(change_notification=True, delta_change_notification=True)
+    env = make_cc(env_id, **kw) if env_id in CLASSIC_CONTROL_ENV_IDS else make_gw(env_id, **kw)
+    env.reset(seed=42)
+    env.step(env.action_space.sample())
+    plan = env.get_planning_env()
+    assert type(plan) is type(env) and plan.is_sim_env and plan.t == env.t
+    obs, reward, term, trunc, info = plan.step(plan.action_space.sample())
+    assert set(obs) == {"state", "env_change", "delta_change", "relative_time"}
+    assert all(v == 0 for v in obs["env_change"].values())      # a frozen copy reports no change (base.py:316-321)
+
+
+@pytest.mark.parametrize("env_id", GRIDWORLD_ENV_IDS)
+def test_P_is_current_snapshot_not_future_schedule(env_id):
+    nsg, W, Cont, *_ = _api()
+    from ns_gym_amd.update_functions import DistributionDecrementUpdate
+
+    cls = {"CliffWalking-v1": W.NSCliffWalkingWrapper, "FrozenLake-v1": W.NSFrozenLakeWrapper}[env_id]
+    env = cls(nsg.make(env_id), {"P": DistributionDecrementUpdate(Cont(), k=0.05)})
+    env.reset(seed=0)
+    P_a, P_b = copy.deepcopy(env.unwrapped.P), copy.deepcopy(env.unwrapped.P)
+    assert P_a == P_b                                # re-reads without stepping are identical
+    for _ in range(5):
+        env.step(env.action_space.sample())
+    P_t5 = copy.deepcopy(env.unwrapped.P)
+    assert P_a != P_t5                               # drifts only through step()
+    for s, row in P_t5.items():                      # mass conservation at every (s, a)
+        for a, entries in row.items():
+            assert abs(sum(e[0] for e in entries) - 1.0) < 1e-9, (s, a)
+    snap = copy.deepcopy(env)
+    P_snap = copy.deepcopy(snap.unwrapped.P)
+    for _ in range(3):
+        env.step(env.action_space.sample())
+    assert copy.deepcopy(snap.unwrapped.P) == P_snap  # the copy's table is frozen at copy time
+
+
+@pytest.mark.parametrize("env_id", CLASSIC_CONTROL_ENV_IDS)
+def test_wrapped_vs_unwrapped_and_valid_params(env_id):
+    nsg, W, Cont, Inc, *_ = _api()
+    env = make_cc(env_id)
+    assert env.unwrapped is not env
+    names = nsg.TUNABLE_PARAMS[env.spec.class_name]
+    for p in names:                                   # every tunable name of the env class is accepted ...
+        W.NSClassicControlWrapper(nsg.make(env_id), {p: Inc(Cont(), k=0.0)}).close()
+    with pytest.raises(AssertionError):               # ... and nothing else (classic_control.py:36-38)
+        W.NSClassicControlWrapper(nsg.make(env_id), {"not_a_param": Inc(Cont(), k=0.1)})
+
+
+@pytest.mark.parametrize("env_id", GRIDWORLD_ENV_IDS)
+def test_invalid_tunable_param_gridworld(env_id):
+    nsg, W, Cont, _, _, DInc = _api()
+    cls = {"CliffWalking-v1": W.NSCliffWalkingWrapper, "FrozenLake-v1": W.NSFrozenLakeWrapper}[env_id]
+    with pytest.raises(AssertionError):
+        cls(nsg.make(env_id), {"gravity": DInc(Cont(), k=-0.1)})
+
+
+def test_dependency_resolver():
+    _, _, Cont, Inc, *_ = _api()
+    env = make_cc("CartPole-v1", {"masspole": Inc(Cont(), k=0.1), "length": Inc(Cont(), k=0.05)})
+    env.reset(seed=3)
+    for _ in range(4):
+        env.step(0)
+        u = env.unwrapped
+        assert np.isclose(u.total_mass, u.masspole + u.masscart) and np.isclose(u.polemass_length, u.masspole * u.length)
+
+
+@pytest.mark.parametrize("name", ["cliff_default", "cliff_terminal_rewards", "frozenlake_4x4", "frozenlake_8x8_rewards"])
+def test_unwrapped_P_equals_the_reference_wrappers_table(name):
+    """`env.unwrapped.P` (what planners read) against the table the reference's NSCliffWalkingWrapper /
+    NSFrozenLakeWrapper install after the same steps (tests/golden/p_tables.npz, generated from the
+    reference classes by tests/golden/make_golden.py)."""
+    from tests.golden.make_golden import P_TABLE_CASES
+    from tests.util import load
+
+    nsg, W, Cont, *_ = _api()
+    from ns_gym_amd.update_functions import DistributionDecrementUpdate
+
+    env_id, mk, wk, acts = P_TABLE_CASES[name]
+    cls = {"CliffWalking-v1": W.NSCliffWalkingWrapper, "FrozenLake-v1": W.NSFrozenLakeWrapper}[env_id]
+    env = cls(nsg.make(env_id, **mk), {"P": DistributionDecrementUpdate(Cont(), k=0.05)}, **wk)
+    env.reset(seed=0)
+    for a in acts:
+        env.step(a)
+    g = load("p_tables.npz")
+    want = g[name]
+    assert np.allclose(env.transition_prob, g[name + "__theta"], rtol=0, atol=1e-15)
+    P = env.unwrapped.P
+    assert len(P) == want.shape[0] and len(P[0]) == want.shape[1]
+    for s in range(want.shape[0]):
+        for a in range(want.shape[1]):
+            n_out = int(np.sum(~np.isnan(want[s, a, :, 0])))
+            assert len(P[s][a]) == n_out, (s, a)
+            for i, e in enumerate(P[s][a]):
+                assert abs(float(e[0]) - want[s, a, i, 0]) < 1e-15 and int(e[1]) == int(want[s, a, i, 1]), (s, a, i, e)
+                assert float(e[2]) == want[s, a, i, 2] and bool(e[3]) == bool(want[s, a, i, 3]), (s, a, i, e)
