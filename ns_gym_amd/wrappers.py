@@ -51,6 +51,8 @@ class _Unwrapped:
             return int(o._vec.state[0].item())
         if name in ("P", "P_left", "P_right") and o.spec.class_name == "Bridge":
             return o._dist(name)
+        if name == "split_probs" and o.spec.class_name == "Bridge":
+            return o._split_mode                           # envs/Bridge.py:149-158
         if name == "P" and o._vec.is_frozenlake:
             return o._build_P()
         if name in ("nrow", "ncol") and o._vec.is_frozenlake:
