@@ -308,6 +308,24 @@ int nsg_theta_trace(nsg_handle* h, int32_t p, int32_t n, int32_t t0, int32_t T, 
                     uint64_t* rng_state, double* theta_out, uint8_t* fired_out, double* delta_out,
                     void* stream);
 
+/* The same with the FULL per-object state carried across calls, so that a host-side Scheduler / UpdateFn
+ * object called repeatedly behaves like the reference's stateful objects (rng draws continue, StepWise /
+ * Cyclic lists advance, LCBounded remembers prev_time, stochastic schedulers keep their stream and
+ * transition_time; base.py:67-81,124-149).  All arrays are device pointers, in/out, and may be NULL when
+ * the config has no such state. */
+typedef struct nsg_trace_state {
+  uint64_t* rng;        /* [n][4] update-fn stream records                                         */
+  int32_t* cursor;      /* [n]    list cursor (StepWise/Cyclic) or prev_time + 1 (LCBounded)       */
+  uint64_t* sched_rng;  /* [n][4] stream of a stochastic scheduler                                 */
+  int32_t* sched_next;  /* [n]    MemorylessScheduler.transition_time                              */
+  int32_t resume;       /* 0: cursor / scheduler state start at construction values (the arrays
+                           receive the final state); 1: continue from the arrays                   */
+  int32_t reserved0;
+} nsg_trace_state;
+int nsg_theta_trace_stateful(nsg_handle* h, int32_t p, int32_t n, int32_t t0, int32_t T, const double* theta0,
+                             const nsg_trace_state* state, double* theta_out, uint8_t* fired_out,
+                             double* delta_out, void* stream);
+
 /* NumPy-compatible bit streams on device (SeedSequence -> PCG64; numpy Generator.random /
  * normal).  kind 0: raw uint64, 1: random() double, 2: standard_normal double.
  * seeds[n], spawn_key < 0 = root stream, else SeedSequence(seed).spawn(..)[spawn_key].

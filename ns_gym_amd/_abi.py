@@ -108,6 +108,12 @@ class Layout(C.Structure):
     ] + [(name, C.c_int64) for name, _ in BUFFER_FIELDS]
 
 
+class TraceState(C.Structure):
+    """nsg_trace_state: the per-object state nsg_theta_trace_stateful carries across calls."""
+    _fields_ = [("rng", C.c_void_p), ("cursor", C.c_void_p), ("sched_rng", C.c_void_p), ("sched_next", C.c_void_p),
+                ("resume", C.c_int32), ("reserved0", C.c_int32)]
+
+
 class RolloutOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("obs", "reward", "terminated", "truncated", "env_change", "delta_change")]

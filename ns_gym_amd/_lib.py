@@ -15,7 +15,7 @@ EXPORTS = [
     "nsg_abi_version", "nsg_last_error", "nsg_sizeof_config", "nsg_sizeof_buffers", "nsg_sizeof_layout",
     "nsg_layout_query", "nsg_create", "nsg_bind", "nsg_reset", "nsg_step", "nsg_rollout", "nsg_step_group",
     "nsg_fork", "nsg_seed_streams",
-    "nsg_compact_done", "nsg_theta_trace", "nsg_rng_fill", "nsg_time_steps", "nsg_calib_copy_f64", "nsg_destroy",
+    "nsg_compact_done", "nsg_theta_trace", "nsg_theta_trace_stateful", "nsg_rng_fill", "nsg_time_steps", "nsg_calib_copy_f64", "nsg_destroy",
     "nsg_specialize", "nsg_is_specialized", "nsg_spec_build", "nsg_spec_free",
 ]
 
@@ -68,6 +68,7 @@ def load():
     lib.nsg_seed_streams.argtypes = [vp, vp, i32, vp]
     lib.nsg_compact_done.argtypes = [vp, vp, vp, vp]
     lib.nsg_theta_trace.argtypes = [vp, i32, i32, i32, i32, vp, u64p, vp, vp, vp, vp]
+    lib.nsg_theta_trace_stateful.argtypes = [vp, i32, i32, i32, i32, vp, C.POINTER(A.TraceState), vp, vp, vp, vp]
     lib.nsg_rng_fill.argtypes = [i32, vp, i32, i32, i32, vp, vp, vp]
     lib.nsg_time_steps.argtypes = [vp, vp, i32, vp, C.POINTER(C.c_float)]
     lib.nsg_calib_copy_f64.argtypes = [vp, vp, i64, vp]

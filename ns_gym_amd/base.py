@@ -44,9 +44,15 @@ class Scheduler:
 
     # -- evaluation (device) -------------------------------------------------------------
     def __call__(self, t: int) -> bool:
-        """`start <= t <= end and _check(t)` evaluated by the device θ-engine."""
+        """`start <= t <= end and _check(t)` evaluated by the device θ-engine.  A stochastic scheduler
+        (Random, DecayingProbability, Memoryless) keeps its stream / transition_time between calls like
+        the reference object does (schedulers.py:25-28,107-116,173-177)."""
         from . import functional
 
+        if getattr(self, "_stochastic", False):
+            if not hasattr(self, "_call_state"):
+                self._call_state = {}
+            return bool(functional.schedule_fires(self, [t], state=self._call_state)[0])
         return bool(functional.schedule_fires(self, [t])[0])
 
 
@@ -71,21 +77,33 @@ class UpdateFn:
     def _uses_rng(self) -> bool:
         return hasattr(self, "seed_value")
 
+    def seed(self, seed) -> None:
+        """Re-seed the function's stream: `self.rng = np.random.default_rng(seed)` of the reference
+        (base.py:151-158); no-op for deterministic functions."""
+        if self._uses_rng:
+            self.seed_value = seed
+            if hasattr(self, "_call_state"):
+                self._call_state.pop("rng", None)   # the next call starts from default_rng(seed); cursors are kept
+
     def __call__(self, param: Any, t: Union[int, float]) -> tuple[Any, int, float]:
-        """`(param', fired, delta)` for one (param, t) via the device θ-engine (stateless use:
-        list cursors / RNG streams start fresh on every call; use `functional.theta_trace`
-        for a fed-back trajectory)."""
+        """`(param', fired, delta)` for one (param, t) via the device θ-engine.  The object is stateful like
+        the reference's (base.py:124-149): its rng stream continues, StepWise / Cyclic lists advance, LCBounded
+        remembers prev_time and a stochastic scheduler keeps its own state from call to call (the state lives in
+        device tensors owned by this object; `seed()` re-seeds the stream)."""
         assert isinstance(t, (int, float)), (
             f"Expected t to be an int or float, got {type(t)}, Arrays operations need to inherit from UpdateDistributionFn"
         )
         from . import functional
 
-        th, fired, delta = functional.theta_trace(self, param, t0=int(t), T=1)
+        if not hasattr(self, "_call_state"):
+            self._call_state = {}
+        th, fired, delta = functional.theta_trace(self, param, t0=int(t), T=1, state=self._call_state)
         self.prev_param = param
         self.prev_time = t
+        f, d = int(fired.reshape(-1)[0]), float(delta.reshape(-1)[0])
         if self._is_distribution:
-            return ([float(x) for x in th[0]] if fired[0] else param, int(fired[0]), float(delta[0]))
-        return (float(th[0]) if fired[0] else param, int(fired[0]), float(delta[0]))
+            return ([float(x) for x in th.reshape(-1)] if f else param, f, d)
+        return (float(th.reshape(-1)[0]) if f else param, f, d)
 
 
 class UpdateDistributionFn(UpdateFn):

@@ -962,7 +962,7 @@ __global__ __launch_bounds__(kBlock) void compact_done_kernel(const uint64_t* __
 __global__ __launch_bounds__(kBlock) void theta_trace_kernel(const Segment* __restrict__ seg, int p, int n, int t0, int T,
                                                              const double* __restrict__ theta0, uint64_t* rng_state,
                                                              double* __restrict__ theta_out, uint8_t* __restrict__ fired_out,
-                                                             double* __restrict__ delta_out) {
+                                                             double* __restrict__ delta_out, nsg_trace_state ts) {
   LdsTables lds;
   const Segment& sg = *seg;
   Tables tb;
@@ -978,7 +978,13 @@ __global__ __launch_bounds__(kBlock) void theta_trace_kernel(const Segment* __re
   int cursor = 0, snext = 0;
   Pcg sr = {0, 0, 0, 0};
   const bool stoch = sched_is_stochastic(pc.sched_kind);
-  if (stoch) sched_construct(pc, zg, p, i, sr, snext);
+  if (ts.resume) {  // a host-side object called again: continue from ITS state
+    if (ts.cursor) cursor = ts.cursor[i];
+    if (stoch && ts.sched_rng) pcg_load(ts.sched_rng, n, i, sr);
+    if (stoch && ts.sched_next) snext = ts.sched_next[i];
+  } else if (stoch) {
+    sched_construct(pc, zg, p, i, sr, snext);
+  }
   double th[4] = {0, 0, 0, 0};
   if (dist) {
     for (int c = 0; c < nd; c++) th[c] = theta0[nd * i + c];
@@ -1011,6 +1017,9 @@ __global__ __launch_bounds__(kBlock) void theta_trace_kernel(const Segment* __re
     delta_out[(int64_t)k * n + i] = delta;
   }
   if (pc.uses_rng && rng_state) pcg_store_all(rng_state, n, i, r);
+  if (ts.cursor) ts.cursor[i] = cursor;
+  if (stoch && ts.sched_rng) pcg_store_all(ts.sched_rng, n, i, sr);
+  if (stoch && ts.sched_next) ts.sched_next[i] = snext;
 }
 
 __global__ __launch_bounds__(kBlock) void rng_fill_kernel(int kind, const uint64_t* __restrict__ seeds, int n, int spawn_key,

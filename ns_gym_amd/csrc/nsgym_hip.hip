@@ -532,18 +532,34 @@ int nsg_compact_done(nsg_handle* h, int32_t* idx_out_dev, uint64_t* count_out_de
   return NSG_OK;
 }
 
-int nsg_theta_trace(nsg_handle* h, int32_t p, int32_t n, int32_t t0, int32_t T, const double* theta0, uint64_t* rng_state,
-                    double* theta_out, uint8_t* fired_out, double* delta_out, void* stream) {
+int nsg_theta_trace_stateful(nsg_handle* h, int32_t p, int32_t n, int32_t t0, int32_t T, const double* theta0,
+                             const nsg_trace_state* state, double* theta_out, uint8_t* fired_out, double* delta_out, void* stream) {
   if (!h) return fail(NSG_EINVAL, "handle is NULL");
   if (p < 0 || p >= h->host.cfg.n_params || n <= 0 || T <= 0) return fail(NSG_EINVAL, "bad theta_trace arguments");
   if (!theta0 || !theta_out || !fired_out || !delta_out) return fail(NSG_EINVAL, "NULL buffer");
-  if (h->host.cfg.params[p].uses_rng && !rng_state) return fail(NSG_EINVAL, "rng_state required for a stochastic update fn");
+  nsg_trace_state ts;
+  memset(&ts, 0, sizeof(ts));
+  if (state) ts = *state;
+  const nsg_param_cfg& pc = h->host.cfg.params[p];
+  if (pc.uses_rng && !ts.rng) return fail(NSG_EINVAL, "rng_state required for a stochastic update fn");
+  if (ts.resume && sched_is_stochastic(pc.sched_kind) && !ts.sched_rng)
+    return fail(NSG_EINVAL, "resume: sched_rng required for a stochastic scheduler");
+  if (ts.resume && pc.sched_kind == NSG_SCHED_MEMORYLESS && !ts.sched_next)
+    return fail(NSG_EINVAL, "resume: sched_next required for MemorylessScheduler");
   if (!h->bound) HIP_TRY(hipMemcpy(h->dev, &h->host, sizeof(Segment), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(theta_trace_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock),
                      (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp), (hipStream_t)stream, h->dev, p, n, t0, T,
-                     theta0, rng_state, theta_out, fired_out, delta_out);
+                     theta0, ts.rng, theta_out, fired_out, delta_out, ts);
   HIP_TRY(hipGetLastError());
   return NSG_OK;
+}
+
+int nsg_theta_trace(nsg_handle* h, int32_t p, int32_t n, int32_t t0, int32_t T, const double* theta0, uint64_t* rng_state,
+                    double* theta_out, uint8_t* fired_out, double* delta_out, void* stream) {
+  nsg_trace_state ts;
+  memset(&ts, 0, sizeof(ts));
+  ts.rng = rng_state;
+  return nsg_theta_trace_stateful(h, p, n, t0, T, theta0, &ts, theta_out, fired_out, delta_out, stream);
 }
 
 int nsg_rng_fill(int32_t kind, const uint64_t* seeds_dev, int32_t n, int32_t spawn_key, int32_t count, void* out_dev,

@@ -37,9 +37,14 @@ def rng_fill(kind: int, seeds, count: int, spawn_key: int = -1):
     return (o.view(np.uint64) if kind == 0 else o), st.cpu().numpy().view(np.uint64).T.copy()  # [4, n]
 
 
-def theta_trace(fn: UpdateFn, theta0, t0: int = 0, T: int = 1, n: int = 1, seeds=None):
+def theta_trace(fn: UpdateFn, theta0, t0: int = 0, T: int = 1, n: int = 1, seeds=None, state: dict | None = None):
     """Drive one (scheduler, update fn) pair for t = t0..t0+T-1 with θ fed back, on `n` lanes.
-    Returns (theta[T, n] or [T, 3, n], fired[T, n], delta[T, n]) as NumPy arrays."""
+    Returns (theta[T, n] or [T, 3, n], fired[T, n], delta[T, n]) as NumPy arrays.
+
+    `state`: a dict owned by the caller (empty on the first call).  When given, the object's whole state -
+    update-fn stream, list cursor / prev_time, stochastic scheduler stream and transition_time - is taken
+    from it and written back to it (device tensors), so successive calls continue like successive calls of
+    the reference's stateful objects."""
     lib, dev = _lib.load(), _dev()
     dist = isinstance(fn, UpdateDistributionFn)
     nd = len(theta0) if dist else 0          # 3: FrozenLake / Bridge support, 4: CliffWalking
@@ -51,8 +56,8 @@ def theta_trace(fn: UpdateFn, theta0, t0: int = 0, T: int = 1, n: int = 1, seeds
     try:
         th0 = np.array(np.broadcast_to(np.asarray(theta0, dtype=np.float64), (n, nd) if dist else (n,)))  # writable copy
         d_th0 = torch.from_numpy(th0).to(dev)
-        rng = None
-        if cfg.params[0].uses_rng:
+        rng = state.get("rng") if state else None
+        if cfg.params[0].uses_rng and rng is None:
             sd = np.asarray(seeds if seeds is not None else [cfg.params[0].fn_seed] * n, dtype=np.uint64)
             _, st = rng_fill(0, sd, 0)
             rng = torch.from_numpy(np.ascontiguousarray(st.T).view(np.int64)).to(dev)  # [n, 4] records
@@ -60,21 +65,40 @@ def theta_trace(fn: UpdateFn, theta0, t0: int = 0, T: int = 1, n: int = 1, seeds
         fired = torch.zeros((T, n), dtype=torch.uint8, device=dev)
         delta = torch.zeros((T, n), dtype=torch.float64, device=dev)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.nsg_theta_trace(h, 0, n, int(t0), int(T), d_th0.data_ptr(), rng.data_ptr() if rng is not None else None,
-                                       th.data_ptr(), fired.data_ptr(), delta.data_ptr(), stream), "nsg_theta_trace")
+        if state is None:
+            _lib.check(lib.nsg_theta_trace(h, 0, n, int(t0), int(T), d_th0.data_ptr(), rng.data_ptr() if rng is not None else None,
+                                           th.data_ptr(), fired.data_ptr(), delta.data_ptr(), stream), "nsg_theta_trace")
+        else:
+            resume = bool(state.get("started"))
+            for key, shape in (("cursor", (n,)), ("sched_next", (n,))):
+                if key not in state:
+                    state[key] = torch.zeros(shape, dtype=torch.int32, device=dev)
+            if "sched_rng" not in state:
+                state["sched_rng"] = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+            if rng is not None:
+                state["rng"] = rng
+            ts = A.TraceState(rng=rng.data_ptr() if rng is not None else None, cursor=state["cursor"].data_ptr(),
+                              sched_rng=state["sched_rng"].data_ptr(), sched_next=state["sched_next"].data_ptr(),
+                              resume=1 if resume else 0)
+            _lib.check(lib.nsg_theta_trace_stateful(h, 0, n, int(t0), int(T), d_th0.data_ptr(), C.byref(ts), th.data_ptr(),
+                                                    fired.data_ptr(), delta.data_ptr(), stream), "nsg_theta_trace_stateful")
+            state["started"] = True
         torch.cuda.synchronize(dev)
         return th.cpu().numpy(), fired.cpu().numpy(), delta.cpu().numpy()
     finally:
         lib.nsg_destroy(h)
 
 
-def schedule_fires(scheduler: Scheduler, ts) -> np.ndarray:
-    """Scheduler.__call__ for each t in `ts` (device)."""
+def schedule_fires(scheduler: Scheduler, ts, state: dict | None = None) -> np.ndarray:
+    """Scheduler.__call__ for each t in `ts` (device).  Deterministic schedulers are pure functions of t
+    (one trace over [min, max]); a stochastic scheduler is called once per t, in order, on its `state`."""
     from .update_functions import NoUpdate
 
     ts = [int(t) for t in ts]
     if not ts:
         return np.zeros(0, dtype=bool)
+    if state is not None:
+        return np.array([bool(theta_trace(NoUpdate(scheduler), 0.0, t0=t, T=1, state=state)[1][0, 0]) for t in ts])
     lo, hi = min(ts), max(ts)
     _, fired, _ = theta_trace(NoUpdate(scheduler), 0.0, t0=lo, T=hi - lo + 1)
     return np.array([bool(fired[t - lo, 0]) for t in ts])

@@ -119,6 +119,7 @@ class _StochasticScheduler(Scheduler):
     `reset(seed=...)` never re-seeds it (ns_gym/base.py:151-158,381-384)."""
 
     seed_value = None
+    _stochastic = True   # Scheduler.__call__ keeps this object's stream / transition_time between calls
 
     def _seed_fields(self):
         return {"has_sched_seed": 1, "sched_seed": int(self.seed_value)} if self.seed_value is not None else {}
