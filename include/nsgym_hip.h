@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NSG_ABI_VERSION 1
+#define NSG_ABI_VERSION 2
 #define NSG_MAX_PARAMS 8 /* tunable params per env (Acrobot has 8: ns_gym/base.py:622-631) */
 #define NSG_MAX_THETA 8
 #define NSG_MAX_SEGMENTS 8 /* env-type segments of one heterogeneous launch */
@@ -157,6 +157,15 @@ typedef struct nsg_param_cfg {
   int32_t uses_rng;      /* 1 if the update fn owns a PCG64 stream                          */
   uint64_t sched_seed;   /* constructor seed of a stochastic scheduler (valid if has_sched_seed) */
   int32_t has_sched_seed;
+  /* Shared objects.  The reference's tunable_params may map several parameter names to ONE UpdateFn object, and
+   * several update fns may hold ONE Scheduler object (the reference's own fixtures do: tests/test_step_reset.py:34-44).
+   * A shared stateful object is one stream / one list cursor / one transition_time consumed by its users in dict
+   * order (classic_control.py:80-92).  fn_slot / sched_slot = index of the FIRST entry that uses the same UpdateFn /
+   * Scheduler object (= the entry's own index when it is not shared): the rows of rng_upd + cursor / of
+   * rng_sched + sched_next this entry reads and writes.  rng_child of every sharer is the index of the LAST one
+   * (reset(seed) seeds in dict order: the last seed wins, base.py:412-421). */
+  int32_t fn_slot;
+  int32_t sched_slot;
   int32_t reserved0;
 } nsg_param_cfg;
 

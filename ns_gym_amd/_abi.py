@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-NSG_ABI_VERSION = 1
+NSG_ABI_VERSION = 2
 NSG_MAX_PARAMS = 8
 NSG_MAX_THETA = 8
 NSG_MAX_SEGMENTS = 8
@@ -65,6 +65,8 @@ class ParamCfg(C.Structure):
         ("uses_rng", C.c_int32),
         ("sched_seed", C.c_uint64),
         ("has_sched_seed", C.c_int32),
+        ("fn_slot", C.c_int32),
+        ("sched_slot", C.c_int32),
         ("reserved0", C.c_int32),
     ]
 

@@ -215,18 +215,18 @@ __device__ __forceinline__ bool fire_param(const nsg_config& cfg, const nsg_buff
       bool f = false;
       if (eval) {
         Pcg r;
-        pcg_load(b.rng_sched + (int64_t)p * 4 * N, N, i, r);
-        int next = pc.sched_kind == NSG_SCHED_MEMORYLESS ? b.sched_next[(int64_t)p * N + i] : 0;
+        pcg_load(b.rng_sched + (int64_t)pc.sched_slot * 4 * N, N, i, r);
+        int next = pc.sched_kind == NSG_SCHED_MEMORYLESS ? b.sched_next[(int64_t)pc.sched_slot * N + i] : 0;
         f = sched_fire_stoch(pc, zg, t, r, next);
-        pcg_store_state(b.rng_sched + (int64_t)p * 4 * N, N, i, r);
-        if (pc.sched_kind == NSG_SCHED_MEMORYLESS) b.sched_next[(int64_t)p * N + i] = next;
+        pcg_store_state(b.rng_sched + (int64_t)pc.sched_slot * 4 * N, N, i, r);
+        if (pc.sched_kind == NSG_SCHED_MEMORYLESS) b.sched_next[(int64_t)pc.sched_slot * N + i] = next;
       }
       if (rewind) {
         Pcg r;
         int next;
-        sched_construct(pc, zg, p, i, r, next);
-        pcg_store_all(b.rng_sched + (int64_t)p * 4 * N, N, i, r);
-        b.sched_next[(int64_t)p * N + i] = next;
+        sched_construct(pc, zg, pc.sched_slot, i, r, next);  // the shared object's own construction stream
+        pcg_store_all(b.rng_sched + (int64_t)pc.sched_slot * 4 * N, N, i, r);
+        b.sched_next[(int64_t)pc.sched_slot * N + i] = next;
       }
       return f;
     }
@@ -325,11 +325,11 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
         Pcg r = {0, 0, 0, 0};
         int cursor = 0;
         const bool has_cur = upd_uses_cursor(pc.upd_kind);
-        if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
-        if (has_cur) cursor = ldg(b.cursor + (int64_t)p * N, o4);
+        if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, r);
+        if (has_cur) cursor = ldg(b.cursor + (int64_t)pc.fn_slot * N, o4);
         n = upd_scalar<FULL>(pc, tb, zg, c, t, r, cursor);
-        if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
-        if (has_cur) stg(b.cursor + (int64_t)p * N, o4, cursor);
+        if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, r);
+        if (has_cur) stg(b.cursor + (int64_t)pc.fn_slot * N, o4, cursor);
       }
       const bool rejected = own_constraint_violated<ENV>(slot, n);
       double delta = fired ? n - c : 0.0;  // UpdateFn._get_delta_change, base.py:182
@@ -341,7 +341,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
       }
       if (do_reset) {  // base.py:381-384 + classic_control.py:105-107; streams continue (base.py:389-391)
         fin = persistent ? c : cfg.base_theta[slot];
-        if (!persistent && upd_uses_cursor(pc.upd_kind)) stg(b.cursor + (int64_t)p * N, o4, 0);
+        if (!persistent && upd_uses_cursor(pc.upd_kind)) stg(b.cursor + (int64_t)pc.fn_slot * N, o4, 0);
       }
       Unroll<T::NTHETA>::run([&](int k) {
         if (k == slot) th[k] = fin;
@@ -373,11 +373,11 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
         Pcg r = {0, 0, 0, 0};
         int cursor = 0;
         const bool has_cur = upd_uses_cursor(pc.upd_kind);
-        if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
-        if (has_cur) cursor = ldg(b.cursor + (int64_t)p * N, o4);
+        if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, r);
+        if (has_cur) cursor = ldg(b.cursor + (int64_t)pc.fn_slot * N, o4);
         n = upd_scalar<FULL>(pc, tb, zg, c, t, r, cursor);
-        if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
-        if (has_cur) stg(b.cursor + (int64_t)p * N, o4, cursor);
+        if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, r);
+        if (has_cur) stg(b.cursor + (int64_t)pc.fn_slot * N, o4, cursor);
         firedmask |= 1u << p;
       }
       Unroll<T::NTHETA>::run([&](int k) {
@@ -406,7 +406,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
       }
       if (do_reset) {
         fin = persistent ? c : cfg.base_theta[slot];
-        if (!persistent && upd_uses_cursor(pc.upd_kind)) stg(b.cursor + (int64_t)p * N, o4, 0);
+        if (!persistent && upd_uses_cursor(pc.upd_kind)) stg(b.cursor + (int64_t)pc.fn_slot * N, o4, 0);
       }
       Unroll<T::NTHETA>::run([&](int k) {
         if (k == slot) th[k] = fin;
@@ -585,12 +585,12 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       for (int k = 0; k < ND; k++) pp[k] = ldg(b.theta + (int64_t)(p * ND + k) * N, o8);
       int cursor = 0;
       const bool has_cur = upd_uses_cursor(pc.upd_kind);
-      if (has_cur) cursor = ldg(b.cursor + (int64_t)p * N, o4);
+      if (has_cur) cursor = ldg(b.cursor + (int64_t)pc.fn_slot * N, o4);
       Pcg ur = {0, 0, 0, 0};
-      if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, i, ur);
+      if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, ur);
       upd_dist<ND, FULL>(pc, tb, zg, pp, t, cursor, ur, q);
-      if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, i, ur);
-      if (has_cur && pc.upd_kind != NSG_UPD_D_LCBOUNDED) stg(b.cursor + (int64_t)p * N, o4, cursor);
+      if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, ur);
+      if (has_cur && pc.upd_kind != NSG_UPD_D_LCBOUNDED) stg(b.cursor + (int64_t)pc.fn_slot * N, o4, cursor);
       delta = w1_n<ND>(pp, q);  // base.py:192-203
 #pragma unroll
       for (int k = 0; k < ND; k++) {
@@ -612,17 +612,17 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       }
     }
     if (pc.upd_kind == NSG_UPD_D_LCBOUNDED && do_step && theta_live)
-      stg(b.cursor + (int64_t)p * N, o4, t + 1);  // UpdateFn.__call__ records prev_time = t, fired or not (base.py:143-148)
+      stg(b.cursor + (int64_t)pc.fn_slot * N, o4, t + 1);  // UpdateFn.__call__ records prev_time = t, fired or not (base.py:143-148)
     if (do_reset && !persistent) {  // toy_text.py:206-209, 394-399, 657-666 (the P TABLE is not restored)
       const double* ini = grid_initial(cfg, p);
 #pragma unroll
       for (int k = 0; k < ND; k++) stg(b.theta + (int64_t)(p * ND + k) * N, o8, ini[k]);
-      if (upd_uses_cursor(pc.upd_kind)) stg(b.cursor + (int64_t)p * N, o4, 0);
+      if (upd_uses_cursor(pc.upd_kind)) stg(b.cursor + (int64_t)pc.fn_slot * N, o4, 0);
       if (FULL && pc.upd_kind == NSG_UPD_D_LCBOUNDED && pc.uses_rng) {  // inner sampler rewound with the deepcopy
         Pcg r;
         if (pc.has_fn_seed) pcg_seed(r, pc.fn_seed, -1);
-        else pcg_seed(r, (uint64_t)i, 1000 + p);
-        pcg_store_all(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
+        else pcg_seed(r, (uint64_t)i, 1000 + pc.fn_slot);
+        pcg_store_all(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, r);
       }
     }
     if (active) {

@@ -104,6 +104,13 @@ int validate(const nsg_config* cfg, size_t table_bytes) {
       if ((k == NSG_UPD_CYCLIC || k == NSG_UPD_D_CYCLIC) && pc.val_tab_len == 0) return fail(NSG_EINVAL, "param %d: empty cyclic list", p);
     }
     if (k != NSG_UPD_D_LCBOUNDED && pc.uses_rng != ((upd_is_normal(k) || k == NSG_UPD_D_RANDOMCAT) ? 1 : 0)) return fail(NSG_EINVAL, "param %d: uses_rng does not match update kind %d", p, k);
+    // shared objects: the slot is the FIRST entry using the same object, so it cannot point forward and must agree in kind
+    if (pc.fn_slot < 0 || pc.fn_slot > p || cfg->params[pc.fn_slot].upd_kind != k || cfg->params[pc.fn_slot].uses_rng != pc.uses_rng ||
+        cfg->params[pc.fn_slot].fn_slot != pc.fn_slot)
+      return fail(NSG_EINVAL, "param %d: bad fn_slot %d", p, pc.fn_slot);
+    if (pc.sched_slot < 0 || pc.sched_slot > p || cfg->params[pc.sched_slot].sched_kind != pc.sched_kind ||
+        cfg->params[pc.sched_slot].sched_slot != pc.sched_slot)
+      return fail(NSG_EINVAL, "param %d: bad sched_slot %d", p, pc.sched_slot);
   }
   return NSG_OK;
 }

@@ -108,6 +108,12 @@ def compile_config(env, tunable_params: dict, *, change_notification=False, delt
             cfg.base_theta[k] = float(spec.theta_overrides.get(name, default))
     cfg.flags = flags
     names = list(tunable_params.keys())
+    # shared objects: one UpdateFn for several names / one Scheduler in several update fns is ONE state consumed in
+    # dict order (see nsg_param_cfg.fn_slot); reset(seed) seeds in dict order, so the last sharer's child seed wins
+    fns = list(tunable_params.values())
+    first_fn = {id(fn): min(k for k, g in enumerate(fns) if g is fn) for fn in fns}
+    last_fn = {id(fn): max(k for k, g in enumerate(fns) if g is fn) for fn in fns}
+    first_sched = {id(fn.scheduler): min(k for k, g in enumerate(fns) if g.scheduler is fn.scheduler) for fn in fns}
     for j, (name, fn) in enumerate(tunable_params.items()):
         assert isinstance(fn, UpdateFn), f"tunable_params[{name!r}] must be an UpdateFn, got {type(fn)}"
         if is_fl:
@@ -116,7 +122,9 @@ def compile_config(env, tunable_params: dict, *, change_notification=False, delt
             assert not isinstance(fn, UpdateDistributionFn), f"{name}: scalar parameter needs a scalar UpdateFn"
         pc = cfg.params[j]
         pc.theta_slot = et.theta_names.index(name)
-        pc.rng_child = j
+        pc.rng_child = last_fn[id(fn)]
+        pc.fn_slot = first_fn[id(fn)]
+        pc.sched_slot = first_sched[id(fn.scheduler)]
         pc.sched_end = float("inf")
         fields = {}
         fields.update(fn.scheduler._compile(tables, cfg.max_episode_steps or None))
@@ -145,12 +153,15 @@ def _dec(v):
     return v
 
 
-def build_fn(fn_spec: dict):
+def build_fn(fn_spec: dict, scheduler=None):
     from . import schedulers as S
     from . import update_functions as U
 
-    sname, skw = fn_spec["scheduler"]
-    sched = getattr(S, sname)(**{k: _dec(v) for k, v in skw.items()})
+    if scheduler is None:
+        sname, skw = fn_spec["scheduler"]
+        sched = getattr(S, sname)(**{k: _dec(v) for k, v in skw.items()})
+    else:
+        sched = scheduler
     uname, ukw = fn_spec["update"]
     kw = copy.deepcopy({k: _dec(v) for k, v in ukw.items()})
     if "__inner_seed__" in kw:      # golden specs: the seed installed on LCBounded's inner sampler
@@ -159,4 +170,14 @@ def build_fn(fn_spec: dict):
 
 
 def build_tunable_params(params_spec: dict) -> dict:
-    return {name: build_fn(fs) for name, fs in params_spec.items()}
+    """`{"same_as": name}` re-uses the UpdateFn OBJECT built for `name`; `{"scheduler_of": name, "update": ...}`
+    builds a new update fn around the Scheduler OBJECT of `name` (shared stateful objects, nsg_param_cfg.fn_slot)."""
+    out = {}
+    for name, fs in params_spec.items():
+        if "same_as" in fs:
+            out[name] = out[fs["same_as"]]
+        elif "scheduler_of" in fs:
+            out[name] = build_fn(fs, scheduler=out[fs["scheduler_of"]].scheduler)
+        else:
+            out[name] = build_fn(fs)
+    return out

@@ -236,11 +236,11 @@ static int fire_param(const nsg_config* cfg, const uint8_t* tables, const nsg_bu
   const nsg_param_cfg* pc = &cfg->params[p];
   if (!sched_is_stochastic(pc->sched_kind)) return sched_fire(pc, tables, t);
   pcg64 r;
-  rng_load(b->rng_sched + (int64_t)p * 4 * N, N, i, &r);
-  int32_t next = b->sched_next[p * N + i];
+  rng_load(b->rng_sched + (int64_t)pc->sched_slot * 4 * N, N, i, &r);
+  int32_t next = b->sched_next[pc->sched_slot * N + i];
   int f = sched_fire_stoch(pc, t, &r, &next);
-  rng_store(b->rng_sched + (int64_t)p * 4 * N, N, i, &r);
-  b->sched_next[p * N + i] = next;
+  rng_store(b->rng_sched + (int64_t)pc->sched_slot * 4 * N, N, i, &r);
+  b->sched_next[pc->sched_slot * N + i] = next;
   return f;
 }
 
@@ -790,9 +790,9 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
       double delta = 0.0;
       if (fired) {
         pcg64 ur;
-        if (pc->uses_rng) rng_load(b->rng_upd + (int64_t)p * 4 * N, N, i, &ur);
-        upd_dist(pc, tables, pp, nd, t, b->cursor ? &b->cursor[p * N + i] : NULL, pc->uses_rng ? &ur : NULL, q);
-        if (pc->uses_rng) rng_store(b->rng_upd + (int64_t)p * 4 * N, N, i, &ur);
+        if (pc->uses_rng) rng_load(b->rng_upd + (int64_t)pc->fn_slot * 4 * N, N, i, &ur);
+        upd_dist(pc, tables, pp, nd, t, b->cursor ? &b->cursor[pc->fn_slot * N + i] : NULL, pc->uses_rng ? &ur : NULL, q);
+        if (pc->uses_rng) rng_store(b->rng_upd + (int64_t)pc->fn_slot * 4 * N, N, i, &ur);
         delta = w1_n(pp, q, nd); /* base.py:192-203 */
         for (int k = 0; k < nd; k++) {
           b->theta[(p * nd + k) * N + i] = q[k];
@@ -802,7 +802,7 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
       b->env_change[p * N + i] = (uint8_t)fired;
       b->delta_change[p * N + i] = (float)delta;
       if (fired) cnt[NSG_CNT_FIRED * NSG_CNT_SHARDS]++;
-      if (pc->upd_kind == NSG_UPD_D_LCBOUNDED && theta_live) b->cursor[p * N + i] = t + 1; /* prev_time = t, fired or not */
+      if (pc->upd_kind == NSG_UPD_D_LCBOUNDED && theta_live) b->cursor[pc->fn_slot * N + i] = t + 1; /* prev_time = t, fired or not */
     }
     int a = ((const int32_t*)actions)[i];
     int s = b->cell[i];
@@ -895,9 +895,9 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
       tuned |= 1u << k;
       if (theta_live && fire_param(cfg, tables, b, N, i, p, t)) { /* frozen planning copy: classic_control.py:70-75 */
         pcg64 r;
-        if (pc->uses_rng) rng_load(b->rng_upd + (int64_t)p * 4 * N, N, i, &r);
-        nv[k] = upd_scalar(pc, tables, cur[k], t, pc->uses_rng ? &r : NULL, b->cursor ? &b->cursor[p * N + i] : NULL);
-        if (pc->uses_rng) rng_store(b->rng_upd + (int64_t)p * 4 * N, N, i, &r);
+        if (pc->uses_rng) rng_load(b->rng_upd + (int64_t)pc->fn_slot * 4 * N, N, i, &r);
+        nv[k] = upd_scalar(pc, tables, cur[k], t, pc->uses_rng ? &r : NULL, b->cursor ? &b->cursor[pc->fn_slot * N + i] : NULL);
+        if (pc->uses_rng) rng_store(b->rng_upd + (int64_t)pc->fn_slot * 4 * N, N, i, &r);
         firedmask |= 1u << p;
       }
     }

@@ -105,9 +105,12 @@ def _dec(v):
     return v
 
 
-def build_fn(S, U, fn_spec):
-    sname, skw = fn_spec["scheduler"]
-    sched = getattr(S, sname)(**{k: _dec(v) for k, v in skw.items()})
+def build_fn(S, U, fn_spec, scheduler=None):
+    if scheduler is None:
+        sname, skw = fn_spec["scheduler"]
+        sched = getattr(S, sname)(**{k: _dec(v) for k, v in skw.items()})
+    else:
+        sched = scheduler
     uname, ukw = fn_spec["update"]
     import copy
 
@@ -178,6 +181,19 @@ DIST_UPDATE_SPECS = {
     # build_fn() installs default_rng(seed) on it after construction when "__inner_seed__" is given
     "d_lcbounded": ["LCBoundedDistrubutionUpdate", {"L": 0.25, "__inner_seed__": 77}],
 }
+
+
+def build_params(S, U, params_spec):
+    """tunable_params dict of REFERENCE objects; `same_as` / `scheduler_of` share one object between entries."""
+    out = {}
+    for name, fs in params_spec.items():
+        if "same_as" in fs:
+            out[name] = out[fs["same_as"]]
+        elif "scheduler_of" in fs:
+            out[name] = build_fn(S, U, fs, scheduler=out[fs["scheduler_of"]].scheduler)
+        else:
+            out[name] = build_fn(S, U, fs)
+    return out
 
 
 def gen_schedulers(S, T=80):
@@ -256,6 +272,28 @@ TRAJ_SPECS = {
             "gravity": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["RandomWalk", {}]},
         },
         "flags": {"change_notification": True, "delta_change_notification": False},
+    },
+    # ONE stochastic UpdateFn object under two names (the reference's own fixtures share fn objects,
+    # tests/test_step_reset.py:34-44): one stream consumed alternately in dict order, re-seeded with the LAST child seed
+    "cartpole_shared_randomwalk": {
+        "env_id": "CartPole-v1", "T": 150, "seeds": [3, 4, 5, 6],
+        "params": {
+            "masspole": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["RandomWalk", {"mu": 0.0, "sigma": 0.002}]},
+            "length": {"same_as": "masspole"},
+            "gravity": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["RandomWalk", {"mu": 0.0, "sigma": 0.05}]},
+        },
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    # ONE stochastic Scheduler object inside two update fns + a shared StepWise list (pops alternate between the names)
+    "cartpole_shared_scheduler_and_list": {
+        "env_id": "CartPole-v1", "T": 150, "seeds": [11, 12, 13, 14],
+        "params": {
+            "force_mag": {"scheduler": SCHEDULER_SPECS["random_p3"], "update": ["IncrementUpdate", {"k": 0.05}]},
+            "masscart": {"scheduler_of": "force_mag", "update": ["IncrementUpdate", {"k": 0.01}]},
+            "masspole": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["StepWiseUpdate", {"param_list": [0.11, 0.12, 0.13, 0.14, 0.15, 0.16, 0.17]}]},
+            "length": {"same_as": "masspole"},
+        },
+        "flags": {"change_notification": True, "delta_change_notification": True},
     },
     # constraint rejection: masscart driven <= 0 is blocked, flag/delta zeroed (classic_control.py:87-92)
     "cartpole_constraint": {
@@ -475,7 +513,7 @@ def gen_grid_trajectory(gym, S, U, spec):
     if env_id == "CliffWalking-v1":
         rec["prob"] = np.zeros((T, N), dtype=np.float64)
     for i, seed in enumerate(seeds):
-        tp = {p: build_fn(S, U, fs) for p, fs in spec["params"].items()}
+        tp = build_params(S, U, spec["params"])
         env = _EXTRA_WRAPPERS[env_id](gym.make(env_id, **spec.get("make_kwargs", {})), tp, **spec["flags"],
                                       **{k: _wk(v) for k, v in spec.get("wrapper_kwargs", {}).items()})
         np.random.seed(1000 + int(seed))   # Bridge's global RNG; irrelevant for one-hot distributions
@@ -563,7 +601,7 @@ def gen_trajectory(gym, S, U, CC, FL, spec):
     if is_fl:
         rec["prob"] = np.zeros((T, N), dtype=np.float64)
     for i, seed in enumerate(seeds):
-        tp = {p: build_fn(S, U, fs) for p, fs in spec["params"].items()}
+        tp = build_params(S, U, spec["params"])
         base_env = gym.make(env_id, **spec.get("make_kwargs", {}))
         Wr = FL if is_fl else CC
         env = Wr(base_env, tp, **spec["flags"], **{k: (list(v) if isinstance(v, list) else v)
@@ -612,7 +650,7 @@ def gen_reset_semantics(gym, S, U, CC):
     update-fn streams; no seed continues both; θ restored unless persistent."""
     out = {}
     spec = TRAJ_SPECS["cartpole_two_params"]
-    tp = {p: build_fn(S, U, fs) for p, fs in spec["params"].items()}
+    tp = build_params(S, U, spec["params"])
     env = CC(gym.make("CartPole-v1"), tp, change_notification=True, delta_change_notification=True)
     acts = np.random.default_rng(123).integers(2, size=64)
     log_state, log_theta, log_delta = [], [], []
@@ -696,7 +734,7 @@ def gen_planning(gym, S, U, CC, FL, spec):
     env_id = spec["env_id"]
     is_fl = env_id == "FrozenLake-v1"
     cont = env_id in ("Pendulum-v1",)
-    tp = {p: build_fn(S, U, fs) for p, fs in spec["params"].items()}
+    tp = build_params(S, U, spec["params"])
     Wr = FL if is_fl else CC
     env = Wr(gym.make(env_id, **spec.get("make_kwargs", {})), tp, **spec["flags"], **spec.get("wrapper_kwargs", {}))
     pnames = list(spec["params"].keys())
@@ -837,6 +875,17 @@ def gen_numpy_streams():
 def main():
     warnings.simplefilter("ignore")
     gym, S, U, CC, FL = _bind_reference()
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only-traj=")]
+    if only:   # add trajectory fixtures without touching the others (the manifest is rewritten: it lists every spec)
+        for name in only:
+            rec = gen_trajectory(gym, S, U, CC, FL, TRAJ_SPECS[name])
+            np.savez_compressed(os.path.join(HERE, f"traj_{name}.npz"), **rec)
+            print(name, "episodes:", int(rec["was_reset"].sum()), "fired:", int(rec["gt_env_change"].sum()))
+        man = json.load(open(os.path.join(HERE, "manifest.json")))
+        man["traj_specs"] = TRAJ_SPECS
+        with open(os.path.join(HERE, "manifest.json"), "w") as f:
+            json.dump(man, f, indent=1)
+        return
     if "--only-p-tables" in sys.argv:   # add one fixture without touching the others
         np.savez_compressed(os.path.join(HERE, "p_tables.npz"), **gen_p_tables(gym, S, U, FL))
         print("p_tables.npz written")

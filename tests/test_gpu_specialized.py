@@ -35,7 +35,8 @@ SPECS = [("c1_cartpole_masspole_inc", 5000, 120), ("c2_cartpole_gravity_rw", 409
          ("cartpole_constraint", 2048, 60), ("cartpole_persistent", 1000, 80), ("cartpole_random_sched", 1024, 60),
          ("c4_pendulum_m_inc", 4096, 230), ("pendulum_all_params", 1024, 60), ("acrobot_constraints", 1024, 40),
          ("mountaincar", 1024, 210), ("mountaincar_continuous", 1024, 60), ("c3_frozenlake_step50", 8192, 120),
-         ("frozenlake_randomcat", 1024, 60), ("frozenlake_lcbounded", 1024, 60)]
+         ("frozenlake_randomcat", 1024, 60), ("frozenlake_lcbounded", 1024, 60),
+         ("cartpole_shared_randomwalk", 1024, 60), ("cartpole_shared_scheduler_and_list", 1024, 60)]
 
 
 @pytest.mark.parametrize("name,n,T", SPECS)
