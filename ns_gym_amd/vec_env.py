@@ -299,15 +299,26 @@ class VecNSEnv:
         return float(ms.value)
 
     # ------------------------------------------------------------------ planning copies
-    def fork(self, theta_mode: int = 0, entropy: int | None = None) -> "VecNSEnv":
+    def fork(self, theta_mode: int = 0, entropy: int | None = None, into: "VecNSEnv | None" = None) -> "VecNSEnv":
         """Batched planning-env snapshot: a new `VecNSEnv` (is_sim_env=True) holding a copy of every
         env's state, t and update-fn state, with every stream re-seeded from `entropy` (fresh OS
         entropy by default, like the reference's `_reseed_planning_env_rngs`, ns_gym/base.py:433-441).
-        theta_mode 0 keeps the current θ, 1 installs the construction-time θ."""
+        theta_mode 0 keeps the current θ, 1 installs the construction-time θ.
+
+        `into`: an earlier copy of THIS env to overwrite (a planner that snapshots once per simulation,
+        MCTS.py:131): no allocation, no handle creation - one kernel launch."""
         import os
 
         if entropy is None:
             entropy = int.from_bytes(os.urandom(8), "little")
+        if into is not None:
+            assert into.is_sim_env and into.N == self.N and getattr(into, "_fork_parent", None) is self._fork_root(), \
+                "`into` must be a planning copy previously forked from this env"
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.nsg_fork(self._h, into._h, C.c_uint64(entropy & (2**64 - 1)), int(theta_mode), self._stream),
+                           "nsg_fork")
+            into.has_reset, into.frozen = self.has_reset, self.frozen
+            return into
         kw = dict(self._ctor)
         kw["is_sim_env"] = True
         kw["device"] = self.device
@@ -322,7 +333,12 @@ class VecNSEnv:
                        "nsg_fork")
         dst.has_reset = self.has_reset
         dst.frozen = self.frozen
+        dst._fork_parent = self._fork_root()
         return dst
+
+    def _fork_root(self):
+        """The non-sim env a chain of copies descends from (copies of copies share the config family)."""
+        return getattr(self, "_fork_parent", None) or self
 
     def get_planning_env(self) -> "VecNSEnv":
         """`get_planning_env()` of the reference wrappers for all envs at once

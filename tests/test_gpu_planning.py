@@ -122,3 +122,40 @@ def test_fork_matches_oracle_at_scale(name, theta_mode):
         compare_views(gs.step(acts[k]), os_.step(acts[k]), is_fl, f"fork step {k - pre}")
     # the sources advance independently of their copies
     compare_views(g.step(acts[0]), o.step(acts[0]), is_fl, "source after fork")
+
+
+def test_fork_into_an_earlier_copy_reuses_it():
+    """A planner snapshots the same env once per simulation (MCTS.py:131): `fork(into=copy)` overwrites an
+    earlier copy with one kernel launch and must leave it exactly like a freshly made one."""
+    import torch
+
+    from ns_gym_amd import make
+    from ns_gym_amd.schedulers import ContinuousScheduler, PeriodicScheduler
+    from ns_gym_amd.update_functions import IncrementUpdate, RandomWalk
+    from ns_gym_amd.vec_env import VecNSEnv
+
+    n = 3000
+    env = VecNSEnv(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.01),
+                                          "gravity": RandomWalk(PeriodicScheduler(period=2), seed=4)}, n,
+                   change_notification=True, delta_change_notification=True, in_sim_change=True)
+    env.reset(seed=1)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    acts = torch.randint(0, 2, (40, n), dtype=torch.int32, device="cuda", generator=g)
+    for k in range(10):
+        env.step(acts[k])
+    fresh = env.fork(theta_mode=0, entropy=77)
+    reused = env.fork(theta_mode=0, entropy=5)          # an older snapshot ...
+    for k in range(10, 15):
+        reused.step(acts[k])                           # ... that has been used by a simulation
+    assert env.fork(theta_mode=0, entropy=77, into=reused) is reused
+    for k in range(15, 30):
+        fresh.step(acts[k])
+        reused.step(acts[k])
+    for row in ("phys", "theta", "t", "t_fork", "status", "rng_env", "rng_upd", "obs", "reward", "terminated", "truncated"):
+        assert torch.equal(fresh.buf[row], reused.buf[row]), row
+    other = VecNSEnv(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.01)}, n)
+    other.reset(seed=1)
+    with pytest.raises(AssertionError):
+        other.fork(into=reused)                        # not a copy of that env
+    for e in (env, fresh, reused, other):
+        e.close()
