@@ -161,7 +161,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int ENV> __device__ __forceinline__ void store_obs(float* obs, int64_t i, const float* o) {
   const uint32_t u = (uint32_t)i;
   if constexpr (ENV == NSG_ENV_CARTPOLE) {
-    stg(reinterpret_cast<f32x4*>(obs), u * 16u, f32x4{o[0], o[1], o[2], o[3]});
+    stg_out(reinterpret_cast<f32x4*>(obs), u * 16u, f32x4{o[0], o[1], o[2], o[3]});
   } else if constexpr (ENV == NSG_ENV_PENDULUM) {
     stg(obs, u * 12u, o[0]); stg(obs, u * 12u + 4u, o[1]); stg(obs, u * 12u + 8u, o[2]);
   } else if constexpr (ENV == NSG_ENV_ACROBOT) {
@@ -352,8 +352,8 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
         // rows 0/1 live in registers across fused steps: written when this step stores (always then,
         // because earlier fused steps may have changed them without a store)
         if (p > 1 ? fin != c : (io.store && (fin != c || io.dirty))) stg(b.theta + (int64_t)p * N, o8, fin);
-        stg(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
-        stg(out.delta_change + (int64_t)p * N, o4, (float)delta);
+        stg_out(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
+        stg_out(out.delta_change + (int64_t)p * N, o4, (float)delta);
         if (cfg.flags & NSG_F_VIOLATION_MASK) stg(b.violation + (int64_t)p * N, o1, (uint8_t)(rejected && do_step ? 1 : 0));
       }
       n_fired += fired ? 1u : 0u;
@@ -417,8 +417,8 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
         // rows 0/1 live in registers across fused steps: written when this step stores (always then,
         // because earlier fused steps may have changed them without a store)
         if (p > 1 ? fin != c : (io.store && (fin != c || io.dirty))) stg(b.theta + (int64_t)p * N, o8, fin);
-        stg(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
-        stg(out.delta_change + (int64_t)p * N, o4, (float)delta);
+        stg_out(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
+        stg_out(out.delta_change + (int64_t)p * N, o4, (float)delta);
         if (cfg.flags & NSG_F_VIOLATION_MASK) stg(b.violation + (int64_t)p * N, o1, (uint8_t)(rejected && do_step ? 1 : 0));
       }
       n_fired += fired ? 1u : 0u;
@@ -481,9 +481,9 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     env_obs<ENV>(s, o);
     store_obs<ENV>(out.obs, i, o);
     if (io.store) stg(b.t, o4, tnew);
-    stg(out.reward, o4, (float)reward);
-    stg(out.terminated, o1, (uint8_t)(term ? 1 : 0));
-    stg(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
+    stg_out(out.reward, o4, (float)reward);
+    stg_out(out.terminated, o1, (uint8_t)(term ? 1 : 0));
+    stg_out(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
     if (io.store) stg(b.status, o1, (uint8_t)(done ? NSG_ST_NEEDS_RESET : 0));
     if (track) {  // the episode length is the wrapper time t: only the return needs a running row
       er += (float)reward;
@@ -626,8 +626,8 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       }
     }
     if (active) {
-      stg(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
-      stg(out.delta_change + (int64_t)p * N, o4, (float)delta);
+      stg_out(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
+      stg_out(out.delta_change + (int64_t)p * N, o4, (float)delta);
     }
     n_fired += fired ? 1u : 0u;
   }
@@ -701,9 +701,9 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
     stg(b.cell, o4, cell);
     if (out.obs) stg((int32_t*)out.obs, o4, cell);  // trajectory slice (rollout); NULL for nsg_step: cell[] is the obs
     stg(b.t, o4, tnew);
-    stg(out.reward, o4, (float)reward);
-    stg(out.terminated, o1, (uint8_t)(term ? 1 : 0));
-    stg(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
+    stg_out(out.reward, o4, (float)reward);
+    stg_out(out.terminated, o1, (uint8_t)(term ? 1 : 0));
+    stg_out(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
     stg(b.status, o1, (uint8_t)(done ? NSG_ST_NEEDS_RESET : 0));
     if (b.prob) stg(b.prob, o4, (float)prob);
     if (cfg.flags & NSG_F_TRACK_RETURNS) {

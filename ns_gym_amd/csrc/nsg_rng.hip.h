@@ -26,6 +26,12 @@ namespace nsg {
 // space the compiler must emit flat_* instructions and 64-bit per-lane address arithmetic;
 // with it, every access is `global_load/store vdata, voffset32, s[base:base+1]`.
 #define NSG_GLOBAL __attribute__((address_space(1)))
+// Write-once outputs are stored non-temporally: they should not displace the state rows, which the next launch
+// reads again, from the caches (measured: C1 28.95 -> 28.39 us, Pendulum 21.37 -> 21.19 us).  Non-temporal LOADS of
+// the action row were tried too and cost 5 us (C1 33.5 us): the row usually is cache-resident, written just before.
+#ifndef NSG_NT_OUTPUTS
+#define NSG_NT_OUTPUTS 1
+#endif
 // readfirstlane declares the row base wave-uniform (it is: every lane computes it from the same
 // kernel-uniform values), which keeps it in an SGPR pair instead of 64-bit per-lane arithmetic.
 __device__ __forceinline__ uint64_t pin_sgpr(uint64_t v) {
@@ -40,6 +46,16 @@ template <typename T> __device__ __forceinline__ T ldg(const T* base, uint32_t b
 template <typename T> __device__ __forceinline__ void stg(T* base, uint32_t byte_off, T v) {
   NSG_GLOBAL char* p = (NSG_GLOBAL char*)pin_sgpr((uint64_t)base);
   *(NSG_GLOBAL T*)(p + byte_off) = v;
+}
+
+// write-once outputs (obs, reward, flags, deltas): nothing on the device reads them again
+template <typename T> __device__ __forceinline__ void stg_out(T* base, uint32_t byte_off, T v) {
+#if NSG_NT_OUTPUTS
+  NSG_GLOBAL char* p = (NSG_GLOBAL char*)pin_sgpr((uint64_t)base);
+  __builtin_nontemporal_store(v, (NSG_GLOBAL T*)(p + byte_off));
+#else
+  stg(base, byte_off, v);
+#endif
 }
 
 struct Pcg {
