@@ -1,0 +1,44 @@
+"""The oracle against the REFERENCE ITSELF on random wrapper configurations, live (build container only).
+
+tests/golden/ holds fixed fixtures generated from the reference's classes; here the same machinery
+(tests/golden/make_golden.py: the reference package imported from /root/reference with the module name
+`gymnasium` bound to oracle/gym_restatement.py) drives the reference's NSClassicControlWrapper /
+NSFrozenLakeWrapper on randomly drawn configurations - random (Scheduler, UpdateFn) pairs incl. stochastic
+and shared objects, random flags - and the C oracle must reproduce every trajectory.  Skipped where the
+reference tree is not present (e.g. the GPU box); nothing here touches the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+REFERENCE = os.environ.get("NSG_REFERENCE", "/root/reference")
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "ns_gym")), reason="reference tree not present")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    import warnings
+
+    from tests.golden import make_golden as G
+
+    warnings.simplefilter("ignore")
+    return G, G._bind_reference()
+
+
+@pytest.mark.parametrize("case", range(36))
+def test_oracle_reproduces_the_reference_on_a_random_configuration(ref, case):
+    from oracle.oracle import OracleVecEnv
+    from tests.test_gpu_random_configs import GRID, _decode, random_spec
+    from tests.util import OracleView, check_trajectory, make_env_from_spec
+
+    G, (gym, S, U, CC, FL) = ref
+    rng = np.random.default_rng(50_000 + case)
+    for _ in range(50):                      # the reference path here: classic control + FrozenLake
+        spec = random_spec(rng)              # (CliffWalking / Bridge have their own fixed fixtures, tests/golden/grid_*.npz)
+        if spec["env_id"] not in GRID or spec["env_id"] == "FrozenLake-v1":
+            break
+    spec = {**spec, "T": 40, "seeds": [int(x) for x in rng.integers(0, 2 ** 31, size=3)]}
+    wk = _decode(spec)
+    rec = G.gen_trajectory(gym, S, U, CC, FL, {**spec, "wrapper_kwargs": wk})
+    env = make_env_from_spec(OracleVecEnv, {**spec, "wrapper_kwargs": wk})
+    check_trajectory(OracleView(env), spec, rec)
