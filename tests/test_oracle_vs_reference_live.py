@@ -42,3 +42,28 @@ def test_oracle_reproduces_the_reference_on_a_random_configuration(ref, case):
     rec = G.gen_trajectory(gym, S, U, CC, FL, {**spec, "wrapper_kwargs": wk})
     env = make_env_from_spec(OracleVecEnv, {**spec, "wrapper_kwargs": wk})
     check_trajectory(OracleView(env), spec, rec)
+
+
+class _Rec(dict):
+    """np.load()-like view of an in-memory record (check_grid looks at `.files`)."""
+
+    files = property(lambda self: list(self.keys()))
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_oracle_reproduces_the_reference_cliffwalking_on_a_random_configuration(ref, case):
+    """CliffWalking through the reference's NSCliffWalkingWrapper (bit-exact incl. the env stream's slips)."""
+    from oracle.oracle import OracleVecEnv
+    from tests.test_gpu_random_configs import _decode, random_spec
+    from tests.test_oracle_grid import check_grid
+    from tests.util import OracleView, make_env_from_spec
+
+    G, (gym, S, U, CC, FL) = ref
+    rng = np.random.default_rng(70_000 + case)
+    while True:
+        spec = random_spec(rng)
+        if spec["env_id"] == "CliffWalking-v1":
+            break
+    spec = {**spec, "T": 40, "seeds": [int(x) for x in rng.integers(0, 2 ** 31, size=3)], "wrapper_kwargs": _decode(spec)}
+    rec = _Rec(G.gen_grid_trajectory(gym, S, U, spec))
+    check_grid(OracleView(make_env_from_spec(OracleVecEnv, spec)), spec, rec)
