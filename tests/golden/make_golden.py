@@ -733,7 +733,7 @@ def gen_planning(gym, S, U, CC, FL, spec):
 
     env_id = spec["env_id"]
     is_fl = env_id == "FrozenLake-v1"
-    cont = env_id in ("Pendulum-v1",)
+    cont = env_id in ("Pendulum-v1", "MountainCarContinuous-v0")
     tp = build_params(S, U, spec["params"])
     Wr = FL if is_fl else CC
     env = Wr(gym.make(env_id, **spec.get("make_kwargs", {})), tp, **spec["flags"], **spec.get("wrapper_kwargs", {}))

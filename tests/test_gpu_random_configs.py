@@ -138,3 +138,45 @@ def test_random_configuration_matches_oracle(case):
     if spec["env_id"] != "Acrobot-v1":
         assert [c["episodes"], c["updates_applied"], c["constraint_violations"], c["env_steps"]] == [int(x) for x in oc], tag
     g.env.close()
+
+
+@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("NSG_SWEEP_FORK_CASES", "48"))))
+def test_random_configuration_planning_copy_matches_oracle(case):
+    """The same sweep with a planning copy taken mid-run (random theta_mode, random in_sim_change, the same
+    entropy on both sides): copy and source are stepped on, both must keep matching the oracle's."""
+    from ns_gym_amd.envs import make
+    from ns_gym_amd.spec import build_tunable_params
+    from ns_gym_amd.vec_env import VecNSEnv
+    from oracle.oracle import OracleVecEnv
+
+    rng = np.random.default_rng(30_000 + case)
+    spec = random_spec(rng)
+    n = int(rng.choice([1, 64, 65, 300]))
+    pre, post = int(rng.integers(1, 25)), 25
+    kw = {**spec["flags"], **_decode(spec), "in_sim_change": bool(rng.random() < 0.5)}
+    if spec["env_id"] in ("CliffWalking-v1", "ns_gym/Bridge-v0"):
+        kw.pop("persistent_params", None)
+    g = GpuView(VecNSEnv(make(spec["env_id"], **spec["make_kwargs"]), build_tunable_params(spec["params"]), n,
+                         specialize=bool(case % 2), **kw))
+    o = OracleView(OracleVecEnv(make(spec["env_id"], **spec["make_kwargs"]), build_tunable_params(spec["params"]), n, **kw))
+    seeds = rng.integers(0, 2 ** 40, size=n).astype(np.uint64)
+    is_grid = spec["env_id"] in GRID
+    tag = f"fork case {case}: {spec} kw={kw}"
+    g.reset(seeds), o.reset(seeds)
+    acts = make_actions(spec["env_id"], pre + post, n)
+    for k in range(pre):
+        g.step(acts[k]), o.step(acts[k])
+    mode, entropy = int(rng.integers(0, 2)), int(rng.integers(0, 2 ** 62))
+    gf, of = GpuView(g.env.fork(theta_mode=mode, entropy=entropy)), OracleView(o.env.fork(theta_mode=mode, entropy=entropy))
+    compare_views(gf._out(), of._out(), is_grid, tag + " at fork")
+    acro = spec["env_id"] == "Acrobot-v1"
+    for k in range(pre, pre + post):
+        for x, y, who in ((gf, of, "copy"), (g, o, "source")):
+            a, b = x.step(acts[k]), y.step(acts[k])
+            if acro:
+                same = a["t"] == b["t"]
+                a, b = ({key: (v[..., same] if v.ndim and v.shape[-1] == n else v[same] if v.ndim and v.shape[0] == n else v)
+                         for key, v in d.items()} for d in (a, b))
+            compare_views(a, b, is_grid, tag + f" {who} step {k}")
+    for e in (g.env, gf.env):
+        e.close()

@@ -12,7 +12,10 @@ PLAN = MANIFEST["planning_specs"]
 
 
 def run_planning(factory, view_cls, name, fork):
-    spec, rec = PLAN[name], load(f"plan_{name}.npz")
+    run_planning_rec(factory, view_cls, PLAN[name], load(f"plan_{name}.npz"), fork)
+
+
+def run_planning_rec(factory, view_cls, spec, rec, fork):
     env = make_env_from_spec(factory, {**spec, "seeds": [spec["seed"]]}, n=1)
     v = view_cls(env)
     is_fl = spec["env_id"] == "FrozenLake-v1"

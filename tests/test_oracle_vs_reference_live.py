@@ -67,3 +67,38 @@ def test_oracle_reproduces_the_reference_cliffwalking_on_a_random_configuration(
     spec = {**spec, "T": 40, "seeds": [int(x) for x in rng.integers(0, 2 ** 31, size=3)], "wrapper_kwargs": _decode(spec)}
     rec = _Rec(G.gen_grid_trajectory(gym, S, U, spec))
     check_grid(OracleView(make_env_from_spec(OracleVecEnv, spec)), spec, rec)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("NSG_LIVE_PLANNING_CASES", "24"))))
+def test_oracle_planning_copy_matches_the_reference_on_a_random_configuration(ref, case):
+    """get_planning_env() / deepcopy(env) of the reference's NSClassicControlWrapper on random configurations
+    (deterministic update fns: the reference re-seeds a copy's stochastic fns from OS entropy), then the copy
+    is stepped; the oracle's fork must reproduce it, and the source env must be untouched."""
+    from oracle.oracle import OracleVecEnv
+    from tests.test_gpu_random_configs import SCALAR_KINDS, SCHED_KINDS, TUNABLE, scalar_fn_spec
+    from tests.test_oracle_planning import run_planning_rec
+    from tests.util import OracleView
+
+    G, (gym, S, U, CC, FL) = ref
+    rng = np.random.default_rng(90_000 + case)
+    env_id = str(rng.choice(list(TUNABLE)))
+    det_kinds = [k for k in SCALAR_KINDS if k not in ("randomwalk_mu_sigma", "rw_drift")]
+    det_scheds = [k for k in SCHED_KINDS if not k.startswith("random")]
+    names = [str(x) for x in rng.choice(list(TUNABLE[env_id]), size=int(rng.integers(1, min(3, len(TUNABLE[env_id])) + 1)), replace=False)]
+    params = {pn: {"scheduler": G.SCHEDULER_SPECS[str(rng.choice(det_scheds))],
+                   "update": scalar_fn_spec(rng, str(rng.choice(det_kinds)), TUNABLE[env_id][pn])} for pn in names}
+    cn = bool(rng.random() < 0.8)
+    flags = {"change_notification": cn, "delta_change_notification": bool(cn and rng.random() < 0.5),
+             "in_sim_change": bool(rng.random() < 0.5), "persistent_params": bool(rng.random() < 0.2)}
+    spec = {"env_id": env_id, "params": params, "flags": flags, "kind": str(rng.choice(["planning", "deepcopy"])),
+            "pre": int(rng.integers(1, 7)), "post": 30}
+    for seed in rng.integers(0, 2 ** 31, size=20):      # a seed whose first episode outlives `pre`
+        spec["seed"] = int(seed)
+        try:
+            rec = G.gen_planning(gym, S, U, CC, FL, spec)
+            break
+        except AssertionError:
+            continue
+    else:
+        pytest.skip("no seed kept the first episode alive")
+    run_planning_rec(OracleVecEnv, OracleView, spec, rec, lambda env, mode: env.fork(theta_mode=mode, entropy=99))
