@@ -526,9 +526,22 @@ __device__ __forceinline__ int grid_start_state(const nsg_config& cfg, const uin
   return 0;
 }
 
+// Per-lane copy of a grid env's persistent rows for fused rollouts (the counterpart of LaneState): cell, t,
+// status, episode return, the env PCG64 stream and - FrozenLake / CliffWalking - the probabilities baked into the
+// wrapper's P table stay in registers between the K steps of a launch.  (θ rows and Bridge's per-side
+// distributions are touched on fires / read through the cache: they stay in memory.)
+template <int ND> struct GridLane {
+  int cell = 0, t = 0;
+  unsigned st = 0;
+  float er = 0.f;
+  Pcg g = {0, 0, 0, 0};
+  double tp[ND] = {};
+};
+
 template <int ENV, bool FULL>
 __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffers& b, const int64_t N, const Tables& tb, const ZigLds& zg, const void* actions,
-                                          const StepOut& out, int64_t i, bool active, WaveCounts& wc) {
+                                          const StepOut& out, int64_t i, bool active, WaveCounts& wc,
+                                          GridLane<ENV == NSG_ENV_CLIFFWALKING ? 4 : 3>& gl, const IoMode io) {
   constexpr int ND = ENV == NSG_ENV_CLIFFWALKING ? 4 : 3;
   const int P = cfg.n_params;
   const bool persistent = (cfg.flags & NSG_F_PERSISTENT_PARAMS) != 0;
@@ -537,23 +550,30 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
   const uint8_t* desc = tb.base + cfg.desc_tab_off;
 
   const uint32_t o1 = (uint32_t)i, o4 = o1 * 4u, o8 = o1 * 8u;  // per-lane byte offsets into [N] rows
-  const unsigned st = active ? ldg(b.status, o1) : 0u;
-  const int t = active ? ldg(b.t, o4) : 0;
+  const bool track = (cfg.flags & NSG_F_TRACK_RETURNS) != 0;
+  if (io.load && active) {  // first step of a launch: fetch the persistent rows
+    gl.st = ldg(b.status, o1);
+    gl.t = ldg(b.t, o4);
+    gl.cell = ldg(b.cell, o4);
+    if (track) gl.er = ldg(b.ep_return, o4);
+    pcg_load<true>(b.rng_env, N, i, gl.g);
+    if constexpr (ENV != NSG_ENV_BRIDGE) {
+#pragma unroll
+      for (int k = 0; k < ND; k++) gl.tp[k] = ldg(b.table_prob + (int64_t)k * N, o8);
+    }
+  }
+  const unsigned st = active ? gl.st : 0u;
+  const int t = active ? gl.t : 0;
   const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);
   const bool do_step = active && !do_reset;
 
-  int cell = do_step ? ldg(b.cell, o4) : 0;
+  int cell = do_step ? gl.cell : 0;
   const int a = do_step ? ldg((const int32_t*)actions, o4) : 0;
   // one uniform per step from the env stream (categorical_sample / np.random.choice); FrozenLakeEnv
   // and CliffWalkingEnv.reset also draw one (categorical_sample over the one-hot start distribution),
   // Bridge.reset draws nothing (envs/Bridge.py:103-111)
   double r = 0.0;
-  if (do_step || (do_reset && ENV != NSG_ENV_BRIDGE)) {
-    Pcg g;
-    pcg_load<true>(b.rng_env, N, i, g);
-    r = pcg_double(g);
-    pcg_store_state<true>(b.rng_env, N, i, g);
-  }
+  if (do_step || (do_reset && ENV != NSG_ENV_BRIDGE)) r = pcg_double(gl.g);
 
   // ---- θ: every distribution parameter (toy_text.py:178-185, 362-366, 605-631) ---------------
   unsigned n_fired = 0;
@@ -595,7 +615,10 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
 #pragma unroll
       for (int k = 0; k < ND; k++) {
         stg(b.theta + (int64_t)(p * ND + k) * N, o8, q[k]);
-        if constexpr (ENV != NSG_ENV_BRIDGE) stg(b.table_prob + (int64_t)k * N, o8, q[k]);  // P re-weighted on a fire only
+        if constexpr (ENV != NSG_ENV_BRIDGE) {  // P re-weighted on a fire only
+          stg(b.table_prob + (int64_t)k * N, o8, q[k]);
+          gl.tp[k] = q[k];
+        }
       }
       have_q = true;
     }
@@ -634,7 +657,7 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
   if constexpr (ENV != NSG_ENV_BRIDGE) {
     if (do_step && !have_table) {
 #pragma unroll
-      for (int k = 0; k < ND; k++) pt[k] = ldg(b.table_prob + (int64_t)k * N, o8);
+      for (int k = 0; k < ND; k++) pt[k] = gl.tp[k];
     }
   }
 
@@ -698,22 +721,29 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
   }
   const bool done = term || trunc;
   if (active) {
-    stg(b.cell, o4, cell);
-    if (out.obs) stg((int32_t*)out.obs, o4, cell);  // trajectory slice (rollout); NULL for nsg_step: cell[] is the obs
-    stg(b.t, o4, tnew);
+    gl.cell = cell;
+    gl.t = tnew;
+    gl.st = done ? NSG_ST_NEEDS_RESET : 0u;
+    if (out.obs) stg_out((int32_t*)out.obs, o4, cell);  // trajectory slice (rollout); NULL for nsg_step: cell[] is the obs
     stg_out(out.reward, o4, (float)reward);
     stg_out(out.terminated, o1, (uint8_t)(term ? 1 : 0));
     stg_out(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
-    stg(b.status, o1, (uint8_t)(done ? NSG_ST_NEEDS_RESET : 0));
-    if (b.prob) stg(b.prob, o4, (float)prob);
-    if (cfg.flags & NSG_F_TRACK_RETURNS) {
-      float er = do_reset ? 0.f : ldg(b.ep_return, o4) + (float)reward;
+    if (track) {
+      float er = do_reset ? 0.f : gl.er + (float)reward;
       if (done) {
         stg(b.last_return, o4, er);
         stg(b.last_length, o4, tnew);
         er = 0.f;
       }
-      stg(b.ep_return, o4, er);
+      gl.er = er;
+    }
+    if (io.store) {  // last step of a launch: the persistent rows go back to memory
+      stg(b.cell, o4, cell);
+      stg(b.t, o4, tnew);
+      stg(b.status, o1, (uint8_t)gl.st);
+      if (b.prob) stg(b.prob, o4, (float)prob);
+      if (track) stg(b.ep_return, o4, gl.er);
+      pcg_store_state<true>(b.rng_env, N, i, gl.g);
     }
   }
   const unsigned long long done_mask = __ballot(done);
@@ -730,7 +760,8 @@ __device__ __forceinline__ void step_block(const nsg_config& cfg, const nsg_buff
   // single step: every persistent row round-trips through memory
   if constexpr (ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE) {
     const int64_t i = base + threadIdx.x;
-    step_grid<ENV, FULL>(cfg, b, N, tb, zg, actions, out, i, i < N, wc);
+    GridLane<ENV == NSG_ENV_CLIFFWALKING ? 4 : 3> gl;
+    step_grid<ENV, FULL>(cfg, b, N, tb, zg, actions, out, i, i < N, wc, gl, IoMode{true, true, false, false});
   } else {
     LaneState<ENV> ls;
     step_chunk<ENV, FULL>(cfg, b, N, tb, zg, actions, out, base, parity, lds, wc, ls, IoMode{true, true, false, false});

@@ -5,7 +5,8 @@
 // k-th slice of the caller's trajectory buffers.  For the classic-control envs the persistent rows
 // (integrator state, t, status, θ rows 0-1, episode return) stay in REGISTERS between the K steps
 // (LaneState): HBM sees them once per launch, so a step costs the action (4 B) plus its outputs
-// (~31 B for CartPole) instead of ~140 B.  Grid envs round-trip through their (L2-resident) rows.
+// (~31 B for CartPole) instead of ~140 B.  Grid envs keep cell, t, status, episode return, the env stream and the
+// table probabilities in registers the same way (GridLane): ~23 B per step instead of ~117 B.
 #pragma once
 #include "nsg_kernels.hip.h"
 
@@ -30,6 +31,7 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
   int parity = 0;
   for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
     [[maybe_unused]] LaneState<GRID ? NSG_ENV_CARTPOLE : ENV> ls;
+    [[maybe_unused]] GridLane<ENV == NSG_ENV_CLIFFWALKING ? 4 : 3> gl;
     // classic envs: the chunk's env streams live in LDS for the K steps, so the per-step reset hand-over
     // (helper lanes draw the queued envs' initial states) has no global-memory round trip on the
     // workgroup's critical path; HBM sees the records once per launch
@@ -61,7 +63,8 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
       }
       const void* act = FA ? (const void*)((const float*)actions + (int64_t)k * N) : (const void*)((const int32_t*)actions + (int64_t)k * N);
       if constexpr (GRID) {
-        step_block<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc);
+        const int64_t ig = c * kBlock + threadIdx.x;
+        step_grid<ENV, FULL>(cfg, b, N, tb, zg, act, out, ig, ig < N, wc, gl, IoMode{k == 0, k == k_steps - 1, k > 0, false});
       } else {
         step_chunk<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, k == k_steps - 1, k > 0, true});
       }

@@ -19,6 +19,8 @@ def _vec(*a, **k):
     ("c1_cartpole_masspole_inc", 5000, 97), ("cartpole_two_params", 4096, 64), ("cartpole_constraint", 3000, 50),
     ("c2_cartpole_gravity_rw", 8192, 40), ("c4_pendulum_m_inc", 4096, 230), ("acrobot_constraints", 2048, 40),
     ("mountaincar", 2048, 210), ("c3_frozenlake_step50", 8192, 120), ("cartpole_persistent", 2048, 80),
+    ("frozenlake_decrement", 4096, 150), ("frozenlake_randomcat", 2048, 60), ("frozenlake_lcbounded_persistent", 2048, 60),
+    ("frozenlake_4x4_drift_rewards", 3000, 130), ("cartpole_shared_scheduler_and_list", 2048, 60),
 ])
 def test_rollout_equals_single_steps(name, n, K):
     import torch
@@ -48,5 +50,37 @@ def test_rollout_equals_single_steps(name, n, K):
         assert torch.equal(a.phys, b.phys)
     assert torch.equal(a.buf["status"], b.buf["status"]) and torch.equal(a.buf["rng_env"], b.buf["rng_env"])
     assert torch.equal(a.buf["ep_return"], b.buf["ep_return"]) and torch.equal(a.buf["last_return"], b.buf["last_return"])
+    assert a.counters() == b.counters()
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("name,n,K", [("cliff_decrement", 4096, 90), ("cliff_terminal_stepwise_rewards", 3000, 70),
+                                      ("bridge_split_onehot", 2048, 60), ("bridge_uniform_onehot", 2048, 110)])
+def test_grid_rollout_equals_single_steps(name, n, K):
+    """CliffWalking / Bridge: cell, t, status, episode return, the env stream and the table probabilities ride in
+    registers across the K fused steps; the result must equal K single launches row for row."""
+    import torch
+
+    from tests.test_oracle_grid import grid_spec
+
+    spec = grid_spec(name)
+    a, b = make_env_from_spec(_vec, spec, n=n, track_returns=True), make_env_from_spec(_vec, spec, n=n, track_returns=True)
+    a.reset(seed=5)
+    b.reset(seed=5)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    acts = torch.randint(0, 4, (K, n), dtype=torch.int32, device="cuda", generator=g)
+    rec = ("obs", "reward", "terminated", "truncated", "env_change", "delta_change")
+    k1 = K // 3
+    outs = [b.rollout(acts[:k1], record=rec), b.rollout(acts[k1:], record=rec)]
+    traj = {k: torch.cat([o[k] for o in outs]) for k in rec}
+    P = max(a.cfg.n_params, 1)
+    for k in range(K):
+        obs, r, te, tr, info = a.step(acts[k])
+        assert torch.equal(traj["obs"][k], a.state) and torch.equal(traj["reward"][k], r), f"step {k}"
+        assert torch.equal(traj["terminated"][k], te) and torch.equal(traj["truncated"][k], tr)
+        assert torch.equal(traj["env_change"][k], a.gt_env_change[:P]) and torch.equal(traj["delta_change"][k], a.gt_delta_change[:P])
+    for row in ("cell", "t", "status", "theta", "table_prob", "rng_env", "prob", "ep_return", "last_return", "last_length", "cursor"):
+        if a.buf[row] is not None:
+            assert torch.equal(a.buf[row], b.buf[row]), row
     assert a.counters() == b.counters()
     a.close(); b.close()
