@@ -37,6 +37,8 @@ class _Unwrapped:
         et = o.spec.env_type
         if name == "__class__":
             return type(self)
+        if name == "get_planning_env":      # the wrapper installs itself on the base env (base.py:294): planners call it there
+            return o.get_planning_env
         if name in et.theta_names and not o._vec.is_frozenlake:
             if name in o._vec.param_names:
                 return float(o._vec.theta[o._vec.param_names.index(name), 0].item())

@@ -159,6 +159,8 @@ def test_get_planning_env(env_id):
     env.step(env.action_space.sample())
     plan = env.get_planning_env()
     assert type(plan) is type(env) and plan.is_sim_env and plan.t == env.t
+    via_base = env.unwrapped.get_planning_env()      # base.py:294 installs the method on the base env too
+    assert type(via_base) is type(env) and via_base.is_sim_env and via_base.t == env.t
     obs, reward, term, trunc, info = plan.step(plan.action_space.sample())
     assert set(obs) == {"state", "env_change", "delta_change", "relative_time"}
     assert all(v == 0 for v in obs["env_change"].values())      # a frozen copy reports no change (base.py:316-321)
