@@ -284,7 +284,10 @@ int nsg_step(nsg_handle* h, const void* actions_dev, void* stream);
  *   0 = current θ          (deepcopy; get_planning_env when delta_change_notification or sim env)
  *   1 = construction-time θ (get_planning_env without delta_change_notification)
  * and re-seeds every stream from `entropy` (the reference uses fresh OS entropy:
- * _reseed_planning_env_rngs, base.py:433-441; env np_random of the new gym.make() env). */
+ * _reseed_planning_env_rngs, base.py:433-441; env np_random of the new gym.make() env).
+ * dst may hold k whole copies of src (dst N = k * src N; copy j <- env j mod src N, streams from
+ * entropy + j): the simulations a planner runs for one decision (MCTS.py:131: one deepcopy per
+ * simulation) as ONE batch that a single nsg_rollout launch then advances. */
 int nsg_fork(nsg_handle* src, nsg_handle* dst, uint64_t entropy, int32_t theta_mode, void* stream);
 
 /* Re-seed streams without touching env state: which = 0 env np_random (env.np_random =

@@ -194,6 +194,9 @@ template <int ENV> struct LaneState {
   int t = 0;
   unsigned st = 0;
   float er = 0.f;
+  // planning copies only: TimeLimit origin (t_fork) and CartPole's fork-time total_mass / polemass_length (derived)
+  int tf = 0;
+  double d0 = 0.0, d1 = 0.0;
 };
 struct IoMode {  // wave-uniform
   bool load;   // fetch the persistent rows from memory (else: they are in the LaneState)
@@ -264,6 +267,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   const int t = !active ? 0 : io.load ? ldg(b.t, o4) : ls.t;
   const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);
   const bool do_step = active && !do_reset;
+  if (sim && io.load && active) ls.tf = ldg(b.t_fork, o4);
   double s[T::PHYS];
 #pragma unroll
   for (int k = 0; k < T::PHYS; k++) s[k] = !do_step ? 0.0 : io.load ? ldg(b.phys + (int64_t)k * N, o8) : ls.s[k];
@@ -431,8 +435,12 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   int tnew = 0;
   if constexpr (ENV == NSG_ENV_CARTPOLE) {
     if (sim && !theta_live && b.derived) {  // frozen planning copy: the resolver never runs again
-      th[6] = do_step ? ldg(b.derived, o8) : 0.0;
-      th[7] = do_step ? ldg(b.derived + N, o8) : 0.0;
+      if (io.load && active) {
+        ls.d0 = ldg(b.derived, o8);
+        ls.d1 = ldg(b.derived + N, o8);
+      }
+      th[6] = do_step ? ls.d0 : 0.0;
+      th[7] = do_step ? ls.d1 : 0.0;
     } else {  // _dependency_resolver, classic_control.py:426-444
       th[6] = th[2] + th[1];
       th[7] = th[5] * th[2];
@@ -442,10 +450,13 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     term = env_step<ENV>(th, s, ai, af, reward);
     tnew = t + 1;  // base.py:314
     // TimeLimit [UPSTREAM] counts the steps of ITS env: a planning copy restarts at the fork
-    const int elapsed = tnew - (sim ? ldg(b.t_fork, o4) : 0);
+    const int elapsed = tnew - (sim ? ls.tf : 0);
     trunc = cfg.max_episode_steps > 0 && elapsed >= cfg.max_episode_steps;
   }
-  if (sim && do_reset) stg(b.t_fork, o4, 0);
+  if (sim && do_reset) {
+    stg(b.t_fork, o4, 0);
+    ls.tf = 0;
+  }
   const bool done = term || trunc;
 
   // ---- compacted resets: queue -> helper lanes draw -> owners read back ----------------------
@@ -1083,7 +1094,9 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
   const nsg_config& cfg = ss.cfg;
   const nsg_buffers& sb = ss.buf;
   const nsg_buffers& db = ds.buf;
-  const int64_t N = ss.N;
+  // the copy may hold SEVERAL copies of every source env (dst N = k * src N, copy j <- env j mod src N): a planner's
+  // simulations of one decision as ONE batch; every copy gets its own streams (entropy + j)
+  const int64_t Ns = ss.N, N = ds.N;
   const int env = cfg.env_type, P = cfg.n_params;
   const bool fl = is_grid_env(env);
   const int nd = env == NSG_ENV_CLIFFWALKING ? 4 : 3;
@@ -1091,14 +1104,15 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
   const int phys = fl ? 0 : (env == NSG_ENV_CARTPOLE || env == NSG_ENV_ACROBOT ? 4 : 2);
   const int obs = fl ? 0 : (env == NSG_ENV_CARTPOLE ? 4 : env == NSG_ENV_PENDULUM ? 3 : env == NSG_ENV_ACROBOT ? 6 : 2);
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
-    for (int k = 0; k < phys; k++) db.phys[(int64_t)k * N + i] = sb.phys[(int64_t)k * N + i];
-    if (fl) db.cell[i] = sb.cell[i];
-    const int t = sb.t[i];
+    const int64_t is = i % Ns;
+    for (int k = 0; k < phys; k++) db.phys[(int64_t)k * N + i] = sb.phys[(int64_t)k * Ns + is];
+    if (fl) db.cell[i] = sb.cell[is];
+    const int t = sb.t[is];
     db.t[i] = t;
     db.t_fork[i] = t;
-    db.status[i] = sb.status[i];
+    db.status[i] = sb.status[is];
     for (int r = 0; r < (fl ? nd * P : P); r++) {
-      const double cur = sb.theta[(int64_t)r * N + i];
+      const double cur = sb.theta[(int64_t)r * Ns + is];
       const double init = fl ? grid_initial(cfg, r / nd)[r % nd] : cfg.base_theta[cfg.params[r].theta_slot];
       db.theta[(int64_t)r * N + i] = theta_mode == 1 ? init : cur;
     }
@@ -1107,7 +1121,7 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
       for (int k = 0; k < 6; k++) c[k] = cfg.base_theta[k];
       for (int p = 0; p < P; p++) {
         const int slot = cfg.params[p].theta_slot;
-        const double v = sb.theta[(int64_t)p * N + i];
+        const double v = sb.theta[(int64_t)p * Ns + is];
         for (int k = 0; k < 6; k++)
           if (k == slot) c[k] = v;
       }
@@ -1121,20 +1135,20 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
         // CliffWalking (toy_text.py:219-221,246-249,187): the copy's own table IS the copied current one.
         const bool use_initial = env == NSG_ENV_FROZENLAKE ? (in_sim_change || theta_mode == 1) : (theta_mode == 1 && !in_sim_change);
         for (int k = 0; k < nd; k++)
-          db.table_prob[(int64_t)k * N + i] = use_initial ? cfg.initial_prob[0][k] : sb.table_prob[(int64_t)k * N + i];
+          db.table_prob[(int64_t)k * N + i] = use_initial ? cfg.initial_prob[0][k] : sb.table_prob[(int64_t)k * Ns + is];
       }
-      if (db.prob && sb.prob) db.prob[i] = sb.prob[i];
+      if (db.prob && sb.prob) db.prob[i] = sb.prob[is];
     }
     for (int p = 0; p < P; p++) {
-      if (db.cursor && sb.cursor) db.cursor[(int64_t)p * N + i] = sb.cursor[(int64_t)p * N + i];  // deepcopy(tunable_params)
+      if (db.cursor && sb.cursor) db.cursor[(int64_t)p * N + i] = sb.cursor[(int64_t)p * Ns + is];  // deepcopy(tunable_params)
       if (sched_is_stochastic(cfg.params[p].sched_kind)) {  // scheduler state is copied, never re-seeded (base.py:433-441)
-        for (int k = 0; k < 4; k++) db.rng_sched[((int64_t)p * N + i) * 4 + k] = sb.rng_sched[((int64_t)p * N + i) * 4 + k];
-        db.sched_next[(int64_t)p * N + i] = sb.sched_next[(int64_t)p * N + i];
+        for (int k = 0; k < 4; k++) db.rng_sched[((int64_t)p * N + i) * 4 + k] = sb.rng_sched[((int64_t)p * Ns + is) * 4 + k];
+        db.sched_next[(int64_t)p * N + i] = sb.sched_next[(int64_t)p * Ns + is];
       }
-      db.env_change[(int64_t)p * N + i] = sb.env_change[(int64_t)p * N + i];
-      db.delta_change[(int64_t)p * N + i] = sb.delta_change[(int64_t)p * N + i];
+      db.env_change[(int64_t)p * N + i] = sb.env_change[(int64_t)p * Ns + is];
+      db.delta_change[(int64_t)p * N + i] = sb.delta_change[(int64_t)p * Ns + is];
       if (cfg.params[p].uses_rng && cfg.params[p].upd_kind == NSG_UPD_D_LCBOUNDED) {  // inner rng: deep-copied
-        for (int k = 0; k < 4; k++) db.rng_upd[((int64_t)p * N + i) * 4 + k] = sb.rng_upd[((int64_t)p * N + i) * 4 + k];
+        for (int k = 0; k < 4; k++) db.rng_upd[((int64_t)p * N + i) * 4 + k] = sb.rng_upd[((int64_t)p * Ns + is) * 4 + k];
       } else if (cfg.params[p].uses_rng) {  // _reseed_planning_env_rngs (base.py:433-441): fresh entropy
         Pcg r;
         pcg_seed(r, entropy + (uint64_t)i, 7100 + p);
@@ -1144,16 +1158,17 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
     Pcg g;  // the copy's base env is a new gym.make(): its np_random is unseeded
     pcg_seed(g, entropy + (uint64_t)i, 7001);
     pcg_store_env(db.rng_env, N, i, g, fl);
-    for (int k = 0; k < obs; k++) db.obs[i * obs + k] = sb.obs[i * obs + k];
-    db.reward[i] = sb.reward[i];
-    db.terminated[i] = sb.terminated[i];
-    db.truncated[i] = sb.truncated[i];
+    for (int k = 0; k < obs; k++) db.obs[i * obs + k] = sb.obs[is * obs + k];
+    db.reward[i] = sb.reward[is];
+    db.terminated[i] = sb.terminated[is];
+    db.truncated[i] = sb.truncated[is];
     if (ds.cfg.flags & NSG_F_TRACK_RETURNS) {
-      db.ep_return[i] = (cfg.flags & NSG_F_TRACK_RETURNS) ? sb.ep_return[i] : 0.f;
+      db.ep_return[i] = (cfg.flags & NSG_F_TRACK_RETURNS) ? sb.ep_return[is] : 0.f;
       db.last_return[i] = 0.f;
       db.last_length[i] = 0;
     }
-    if (db.done_bits && (i & 63) == 0) db.done_bits[i >> 6] = sb.done_bits ? sb.done_bits[i >> 6] : 0;
+    const unsigned long long done_mask = __ballot((sb.status[is] & NSG_ST_NEEDS_RESET) != 0);  // == the source's ballot word when N == Ns
+    if (db.done_bits && (i & 63) == 0) db.done_bits[i >> 6] = done_mask;
   }
 }
 

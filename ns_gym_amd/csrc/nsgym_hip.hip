@@ -506,7 +506,8 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
 int nsg_fork(nsg_handle* src, nsg_handle* dst, uint64_t entropy, int32_t theta_mode, void* stream) {
   if (!src || !dst) return fail(NSG_EINVAL, "NULL handle");
   if (!src->bound || !dst->bound) return fail(NSG_ENOTBOUND, "both handles must be bound");
-  if (src->n != dst->n) return fail(NSG_EINVAL, "fork: env counts differ (%lld vs %lld)", (long long)src->n, (long long)dst->n);
+  if (dst->n < src->n || dst->n % src->n != 0)
+    return fail(NSG_EINVAL, "fork: dst must hold a whole number of copies of src (%lld vs %lld envs)", (long long)dst->n, (long long)src->n);
   if (!(dst->host.cfg.flags & NSG_F_SIM_ENV)) return fail(NSG_EINVAL, "fork: dst must be created with NSG_F_SIM_ENV");
   if (theta_mode != 0 && theta_mode != 1) return fail(NSG_EINVAL, "fork: theta_mode must be 0 or 1");
   nsg_config a = src->host.cfg, b = dst->host.cfg;
@@ -514,7 +515,7 @@ int nsg_fork(nsg_handle* src, nsg_handle* dst, uint64_t entropy, int32_t theta_m
   a.max_episode_steps = b.max_episode_steps = 0;  // copies of CliffWalking / Bridge are re-made with 1000 (toy_text.py:229,685)
   if (memcmp(&a, &b, sizeof(a)) != 0 || src->host.table_bytes != dst->host.table_bytes)
     return fail(NSG_EINVAL, "fork: dst was not created from the same configuration");
-  hipLaunchKernelGGL(fork_kernel, dim3(grid_for(src->n)), dim3(kBlock), 0, (hipStream_t)stream, src->dev, dst->dev, entropy, theta_mode);
+  hipLaunchKernelGGL(fork_kernel, dim3(grid_for(dst->n)), dim3(kBlock), 0, (hipStream_t)stream, src->dev, dst->dev, entropy, theta_mode);
   HIP_TRY(hipGetLastError());
   return NSG_OK;
 }

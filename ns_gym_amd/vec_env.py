@@ -299,20 +299,23 @@ class VecNSEnv:
         return float(ms.value)
 
     # ------------------------------------------------------------------ planning copies
-    def fork(self, theta_mode: int = 0, entropy: int | None = None, into: "VecNSEnv | None" = None) -> "VecNSEnv":
+    def fork(self, theta_mode: int = 0, entropy: int | None = None, into: "VecNSEnv | None" = None,
+             repeat: int = 1) -> "VecNSEnv":
         """Batched planning-env snapshot: a new `VecNSEnv` (is_sim_env=True) holding a copy of every
         env's state, t and update-fn state, with every stream re-seeded from `entropy` (fresh OS
         entropy by default, like the reference's `_reseed_planning_env_rngs`, ns_gym/base.py:433-441).
         theta_mode 0 keeps the current θ, 1 installs the construction-time θ.
 
         `into`: an earlier copy of THIS env to overwrite (a planner that snapshots once per simulation,
-        MCTS.py:131): no allocation, no handle creation - one kernel launch."""
+        MCTS.py:131): no allocation, no handle creation - one kernel launch.
+        `repeat`: the copy holds `repeat` copies of every env (copy j <- env j mod N, each with its own
+        streams): all simulations of one decision as ONE batch, advanced by one `rollout` launch."""
         import os
 
         if entropy is None:
             entropy = int.from_bytes(os.urandom(8), "little")
         if into is not None:
-            assert into.is_sim_env and into.N == self.N and getattr(into, "_fork_parent", None) is self._fork_root(), \
+            assert into.is_sim_env and into.N % self.N == 0 and getattr(into, "_fork_parent", None) is self._fork_root(), \
                 "`into` must be a planning copy previously forked from this env"
             with torch.cuda.device(self.device):
                 _lib.check(self.lib.nsg_fork(self._h, into._h, C.c_uint64(entropy & (2**64 - 1)), int(theta_mode), self._stream),
@@ -322,6 +325,7 @@ class VecNSEnv:
         kw = dict(self._ctor)
         kw["is_sim_env"] = True
         kw["device"] = self.device
+        kw["num_envs"] = self.N * int(repeat)
         if self.spec.class_name in ("CliffWalkingEnv", "Bridge"):
             # the reference re-makes these copies with max_episode_steps=1000 (toy_text.py:229,685)
             import dataclasses

@@ -88,6 +88,11 @@ class _NSSingle:
         self.delta_t = 1
         self.action_space = v.single_action_space
         self.observation_space = v.single_observation_space   # Dict(state, env_change, delta_change, relative_time)
+        try:   # with gymnasium installed the spaces ARE gymnasium's, so the reference's planners' isinstance checks hold (MCTS.py:113)
+            self.action_space = self.action_space.to_gymnasium()
+            self.observation_space = self.observation_space.to_gymnasium()
+        except ImportError:
+            pass
         self._done = False
 
     # state mirrored from the vector env

@@ -159,3 +159,48 @@ def test_fork_into_an_earlier_copy_reuses_it():
         other.fork(into=reused)                        # not a copy of that env
     for e in (env, fresh, reused, other):
         e.close()
+
+
+def test_fork_repeat_equals_separate_forks():
+    """`fork(repeat=S)`: S copies of every env in ONE batch (a planner's simulations of one decision).  Copy
+    block s must equal a separate fork taken with entropy + s * N (streams are seeded from entropy + index)."""
+    import torch
+
+    from ns_gym_amd import make
+    from ns_gym_amd.schedulers import ContinuousScheduler, PeriodicScheduler
+    from ns_gym_amd.update_functions import DistributionDecrementUpdate, IncrementUpdate, RandomWalk
+    from ns_gym_amd.vec_env import VecNSEnv
+
+    for mk, tp, n_act in ((lambda: make("CartPole-v1"), lambda: {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.01),
+                                                                "gravity": RandomWalk(PeriodicScheduler(period=2), seed=4)}, 2),
+                          (lambda: make("FrozenLake-v1", map_name="8x8"), lambda: {"P": DistributionDecrementUpdate(ContinuousScheduler(), 0.02)}, 4)):
+        n, S, K = 1000, 3, 25          # 1000 is not a multiple of 64: the done-mask words must be rebuilt, not copied
+        env = VecNSEnv(mk(), tp(), n, change_notification=True, delta_change_notification=True, in_sim_change=True, track_returns=True)
+        env.reset(seed=2)
+        g = torch.Generator(device="cuda").manual_seed(0)
+        acts = torch.randint(0, n_act, (K + 12, n), dtype=torch.int32, device="cuda", generator=g)
+        for k in range(12):
+            env.step(acts[k])
+        big = env.fork(theta_mode=0, entropy=500, repeat=S)
+        assert big.N == S * n and big.is_sim_env
+        parts = [env.fork(theta_mode=0, entropy=500 + s * n) for s in range(S)]
+        assert torch.equal(big.done_indices().sort().values,
+                           torch.cat([p.done_indices() + s * n for s, p in enumerate(parts)]).sort().values)
+        for k in range(12, 12 + K):
+            big.step(acts[k].repeat(S))
+            for p in parts:
+                p.step(acts[k])
+        rows = ("phys", "cell", "theta", "t", "status", "reward", "terminated", "truncated", "ep_return", "last_return")
+        for s, p in enumerate(parts):
+            for row in rows:
+                x, y = big.buf[row], p.buf[row]
+                if x is None:
+                    continue
+                r = x.numel() // big.N if x.numel() % big.N == 0 else None
+                xs = x.view(-1, big.N)[:, s * n:(s + 1) * n] if row in ("phys", "theta") else x.view(big.N, -1)[s * n:(s + 1) * n].reshape(-1)
+                ys = y.view(-1, n) if row in ("phys", "theta") else y.reshape(-1)
+                assert torch.equal(xs, ys), (row, s)
+        # re-use: the big copy is overwritten in place
+        assert env.fork(theta_mode=0, entropy=9, into=big) is big
+        for e in [env, big] + parts:
+            e.close()
