@@ -74,8 +74,22 @@ struct LdsTables {
   uint64_t* blob;       // constant-table blob
   uint64_t* zig;        // 768 words (normal) + 768 words (exponential), each only when needed
   uint64_t* streams;    // [kBlock][4] the chunk's env PCG64 records while a fused rollout runs (IoMode::lds_rng)
+  uint64_t* ustreams;   // [kMaxLdsUpd][kBlock][4] the chunk's update-fn streams (first stochastic fns) during a fused rollout
 };
 constexpr int kLdsStreamBytes = kBlock * 32;
+constexpr int kMaxLdsUpd = 2;  // update-fn streams held in LDS during a fused rollout; further ones go through memory
+
+// Which LDS stream block the update fn in slot `slot` uses (= how many stochastic fn objects precede it).
+__host__ __device__ inline int upd_lds_index(const nsg_config& cfg, int slot) {
+  int n = 0;
+  for (int q = 0; q < slot; q++)
+    if (cfg.params[q].uses_rng && cfg.params[q].fn_slot == q) n++;
+  return n;
+}
+__host__ __device__ inline int upd_lds_count(const nsg_config& cfg) {
+  const int n = upd_lds_index(cfg, cfg.n_params);
+  return n < kMaxLdsUpd ? n : kMaxLdsUpd;
+}
 constexpr int kLdsHeaderBytes = 32 + kBlock * 2 + kBlock * 4 * 8;
 
 __host__ __device__ inline int lds_bytes_for(int table_bytes, int uses_normal, int uses_exp) {
@@ -92,6 +106,7 @@ __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, 
   lds.blob = (uint64_t*)(base + kLdsHeaderBytes);
   lds.zig = (uint64_t*)(base + kLdsHeaderBytes + ((sg.table_bytes + 7) & ~7));
   lds.streams = (uint64_t*)(base + lds_bytes_for(sg.table_bytes, sg.uses_normal, sg.uses_exp));  // valid when the launch reserved it
+  lds.ustreams = lds.streams + kBlock * 4;
   const int tid = threadIdx.x;
   uint64_t* zexp = lds.zig + (sg.uses_normal ? 768 : 0);
   if (sg.uses_normal) {
@@ -237,6 +252,28 @@ __device__ __forceinline__ bool fire_param(const nsg_config& cfg, const nsg_buff
   return eval && sched_fire(pc, tb, t);
 }
 
+// Update-fn stream of the entry `pc`: memory record, or - during a fused rollout - the lane's LDS copy.
+__device__ __forceinline__ void upd_stream_load(const nsg_config& cfg, const nsg_buffers& b, const LdsTables& lds, const nsg_param_cfg& pc,
+                                                int64_t N, int64_t i, const IoMode io, Pcg& r) {
+  const int li = io.lds_rng ? upd_lds_index(cfg, pc.fn_slot) : kMaxLdsUpd;
+  if (li < kMaxLdsUpd) {
+    const uint64_t* rec = lds.ustreams + ((int64_t)li * kBlock + threadIdx.x) * 4;
+    r.sh = rec[0]; r.sl = rec[1]; r.ih = rec[2]; r.il = rec[3];
+  } else {
+    pcg_load(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, r);
+  }
+}
+__device__ __forceinline__ void upd_stream_store(const nsg_config& cfg, const nsg_buffers& b, const LdsTables& lds, const nsg_param_cfg& pc,
+                                                 int64_t N, int64_t i, const IoMode io, const Pcg& r) {
+  const int li = io.lds_rng ? upd_lds_index(cfg, pc.fn_slot) : kMaxLdsUpd;
+  if (li < kMaxLdsUpd) {
+    uint64_t* rec = lds.ustreams + ((int64_t)li * kBlock + threadIdx.x) * 4;
+    rec[0] = r.sh; rec[1] = r.sl;
+  } else {
+    pcg_store_state(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, r);
+  }
+}
+
 // ============================================================================================
 // classic-control step for one chunk of kBlock envs (the whole workgroup; one env per lane).
 //   phase 1: every lane steps its env (θ-engine, constraints, integrator, outputs); an env that
@@ -329,10 +366,10 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
         Pcg r = {0, 0, 0, 0};
         int cursor = 0;
         const bool has_cur = upd_uses_cursor(pc.upd_kind);
-        if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, r);
+        if (FULL && pc.uses_rng) upd_stream_load(cfg, b, lds, pc, N, i, io, r);
         if (has_cur) cursor = ldg(b.cursor + (int64_t)pc.fn_slot * N, o4);
         n = upd_scalar<FULL>(pc, tb, zg, c, t, r, cursor);
-        if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, r);
+        if (FULL && pc.uses_rng) upd_stream_store(cfg, b, lds, pc, N, i, io, r);
         if (has_cur) stg(b.cursor + (int64_t)pc.fn_slot * N, o4, cursor);
       }
       const bool rejected = own_constraint_violated<ENV>(slot, n);
@@ -377,10 +414,10 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
         Pcg r = {0, 0, 0, 0};
         int cursor = 0;
         const bool has_cur = upd_uses_cursor(pc.upd_kind);
-        if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, r);
+        if (FULL && pc.uses_rng) upd_stream_load(cfg, b, lds, pc, N, i, io, r);
         if (has_cur) cursor = ldg(b.cursor + (int64_t)pc.fn_slot * N, o4);
         n = upd_scalar<FULL>(pc, tb, zg, c, t, r, cursor);
-        if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, r);
+        if (FULL && pc.uses_rng) upd_stream_store(cfg, b, lds, pc, N, i, io, r);
         if (has_cur) stg(b.cursor + (int64_t)pc.fn_slot * N, o4, cursor);
         firedmask |= 1u << p;
       }

@@ -42,6 +42,16 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
         pcg_load(b.rng_env, N, ir, g);
         uint64_t* rec = lds.streams + threadIdx.x * 4;
         rec[0] = g.sh; rec[1] = g.sl; rec[2] = g.ih; rec[3] = g.il;
+        if constexpr (FULL) {  // and the first stochastic update fns' streams (each lane touches only its own record)
+          for (int p = 0; p < cfg.n_params; p++) {
+            const nsg_param_cfg& pc = cfg.params[p];
+            if (!pc.uses_rng || pc.fn_slot != p || upd_lds_index(cfg, p) >= kMaxLdsUpd) continue;
+            Pcg u;
+            pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, ir, u);
+            uint64_t* ur = lds.ustreams + ((int64_t)upd_lds_index(cfg, p) * kBlock + threadIdx.x) * 4;
+            ur[0] = u.sh; ur[1] = u.sl; ur[2] = u.ih; ur[3] = u.il;
+          }
+        }
       }
       __syncthreads();
     }
@@ -76,6 +86,15 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
         const uint64_t* rec = lds.streams + threadIdx.x * 4;
         Pcg g = {rec[0], rec[1], 0, 0};
         pcg_store_state(b.rng_env, N, ir, g);
+        if constexpr (FULL) {
+          for (int p = 0; p < cfg.n_params; p++) {
+            const nsg_param_cfg& pc = cfg.params[p];
+            if (!pc.uses_rng || pc.fn_slot != p || upd_lds_index(cfg, p) >= kMaxLdsUpd) continue;
+            const uint64_t* ur = lds.ustreams + ((int64_t)upd_lds_index(cfg, p) * kBlock + threadIdx.x) * 4;
+            Pcg u = {ur[0], ur[1], 0, 0};
+            pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, ir, u);
+          }
+        }
       }
       __syncthreads();  // the next chunk refills the records
     }

@@ -388,7 +388,7 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
   hipStream_t s = (hipStream_t)stream;
   // fused rollouts of the classic envs keep the chunk's env PCG64 records in LDS
   const size_t rollout_lds = (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp) +
-                             (is_grid_env(h->host.cfg.env_type) ? 0 : kLdsStreamBytes);
+                             (is_grid_env(h->host.cfg.env_type) ? 0 : kLdsStreamBytes * (1 + upd_lds_count(h->host.cfg)));
   if (h->spec) {
     void* args[] = {(void*)&h->dev, (void*)&actions_dev, (void*)&k_steps, (void*)&o};
     HIP_TRY(hipModuleLaunchKernel(h->spec->rollout, grid_for(h->n), 1, 1, kBlock, 1, 1, (unsigned)rollout_lds, s, args, nullptr));

@@ -81,7 +81,8 @@ def random_spec(rng):
         names = list(rng.choice(list(TUNABLE[env_id]), size=int(rng.integers(1, min(3, len(TUNABLE[env_id])) + 1)), replace=False))
         for j, pn in enumerate(names):
             pn = str(pn)
-            if j > 0 and rng.random() < 0.2:
+            similar = 0.25 <= TUNABLE[env_id][pn] / TUNABLE[env_id][str(names[0])] <= 4.0
+            if j > 0 and rng.random() < 0.2 and similar:   # (a fn sized for g = 10 would throw dt = 0.05 into chaos)
                 params[pn] = {"same_as": str(names[0])}          # one UpdateFn object under two names
                 continue
             fs = {"update": scalar_fn_spec(rng, str(rng.choice(SCALAR_KINDS)), TUNABLE[env_id][pn])}
@@ -180,3 +181,52 @@ def test_random_configuration_planning_copy_matches_oracle(case):
             compare_views(a, b, is_grid, tag + f" {who} step {k}")
     for e in (g.env, gf.env):
         e.close()
+
+
+@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("NSG_SWEEP_ROLLOUT_CASES", "48"))))
+def test_random_configuration_fused_rollout_matches_oracle(case):
+    """The sweep through nsg_rollout (K fused steps, persistent rows and streams in registers / LDS): every
+    step's outputs and the final rows against the oracle stepped K times."""
+    import torch
+
+    from ns_gym_amd.envs import make
+    from ns_gym_amd.spec import build_tunable_params
+    from ns_gym_amd.vec_env import VecNSEnv
+    from oracle.oracle import OracleVecEnv
+
+    rng = np.random.default_rng(40_000 + case)
+    spec = random_spec(rng)
+    if spec["env_id"] == "Acrobot-v1":
+        spec["env_id"], spec["params"] = "Pendulum-v1", {"m": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": scalar_fn_spec(rng, "randomwalk_mu_sigma", 1.0)}}
+    n = int(rng.choice([1, 64, 65, 300, 513]))
+    K1, K2 = int(rng.integers(1, 20)), int(rng.integers(1, 30))
+    kw = {**spec["flags"], **_decode(spec), "track_returns": True}
+    env = VecNSEnv(make(spec["env_id"], **spec["make_kwargs"]), build_tunable_params(spec["params"]), n, specialize=bool(case % 2), **kw)
+    o = OracleView(OracleVecEnv(make(spec["env_id"], **spec["make_kwargs"]), build_tunable_params(spec["params"]), n, **kw))
+    g = GpuView(env)
+    seeds = rng.integers(0, 2 ** 40, size=n).astype(np.uint64)
+    is_grid = spec["env_id"] in GRID
+    tag = f"rollout case {case}: {spec}"
+    g.reset(seeds), o.reset(seeds)
+    acts = make_actions(spec["env_id"], K1 + K2, n)
+    rec = ("obs", "reward", "terminated", "truncated", "env_change", "delta_change")
+    k = 0
+    for K in (K1, K2):   # two launches: the second starts from what the first wrote back
+        out = env.rollout(torch.from_numpy(acts[k:k + K]).cuda(), record=rec)
+        for j in range(K):
+            b = o.step(acts[k + j])
+            st = out["obs"][j].cpu().numpy()
+            if is_grid:
+                np.testing.assert_array_equal(st.reshape(-1), b["state"].reshape(-1), err_msg=f"{tag} step {k + j}")
+            else:
+                np.testing.assert_allclose(st.reshape(b["state"].shape), b["state"], rtol=1e-5, atol=1e-5, err_msg=f"{tag} step {k + j}")
+            np.testing.assert_allclose(out["reward"][j].cpu().numpy(), b["reward"], rtol=1e-5, atol=1e-5, err_msg=tag)
+            np.testing.assert_array_equal(out["terminated"][j].cpu().numpy().astype(np.uint8), b["terminated"], err_msg=f"{tag} step {k + j}")
+            np.testing.assert_array_equal(out["truncated"][j].cpu().numpy().astype(np.uint8), b["truncated"], err_msg=f"{tag} step {k + j}")
+            P = env.cfg.n_params
+            np.testing.assert_array_equal(out["env_change"][j].cpu().numpy()[:P], b["env_change"], err_msg=f"{tag} step {k + j}")
+        k += K
+        compare_views(g._out(), o._out(), is_grid, tag + f" after {k} steps")
+    c = env.counters()
+    assert [c["episodes"], c["updates_applied"], c["constraint_violations"], c["env_steps"]] == [int(x) for x in o.env.a["counters"].sum(axis=1)], tag
+    env.close()
