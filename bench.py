@@ -221,11 +221,31 @@ def main():
                 "value": v, "unit": "env-steps/s", "cores": threads, "kind": "port",
                 "sample": f"oracle C port (OpenMP, {threads} threads), {n_cpu} envs x {steps_cpu} steps of the same config, "
                           f"{secs:.1f} s wall",
+                # for context: the shape the reference's path has today - one Python wrapper object per env, one step()
+                # call per env per step, dict observations (oracle/python_loop.py), 1 core
+                "python_object_loop": _python_object_loop(),
             }
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _python_object_loop():
+    import numpy as np
+
+    from oracle import python_loop as PL
+
+    envs = [PL.make_c1() for _ in range(64)]
+    for i, e in enumerate(envs):
+        e.reset(seed=i)
+    acts = np.random.default_rng(123).integers(2, size=(8, 64))
+    PL.run_loop(envs, acts, 20)
+    t0 = time.perf_counter()
+    n = PL.run_loop(envs, acts, 600)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "env-steps/s", "cores": 1,
+            "sample": f"64 wrapper objects x 600 steps of the same config in {dt:.1f} s"}
 
 
 def _pmc_traffic(n_envs):
