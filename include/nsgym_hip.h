@@ -224,7 +224,9 @@ typedef struct nsg_buffers {
   uint8_t* violation;    /* [P][N] 1 where this step's proposal was rejected by the constraint checker
                             (classic_control.py:87-92; the reference warns instead).  NSG_F_VIOLATION_MASK */
   float* prob;           /* [N]    FrozenLake info["prob"]                                */
-  float* ep_return;      /* [N]    running episode return      (NSG_F_TRACK_RETURNS)      */
+  float* ep_return;      /* [N]    running episode return      (NSG_F_TRACK_RETURNS).  Not maintained for the env types
+                            whose reward is the same constant on every step (CartPole +1, MountainCar -1): there the
+                            running return IS +-t and last_return is derived from t when an episode ends           */
   int32_t* ep_length;    /* [N]    running episode length                                 */
   float* last_return;    /* [N]    return of the last finished episode                    */
   int32_t* last_length;  /* [N]                                                           */

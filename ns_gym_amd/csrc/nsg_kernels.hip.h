@@ -314,8 +314,9 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     if constexpr (T::FLOAT_ACT) af = ldg((const float*)actions, o4);
     else ai = ldg((const int32_t*)actions, o4);
   }
+  constexpr bool kReturnFromT = T::RETURN_PER_STEP != 0.f;  // the return is a function of t: no running row (nsg_envs.hip.h)
   float er = 0.f;
-  if (track && do_step) er = io.load ? ldg(b.ep_return, o4) : ls.er;
+  if (track && do_step && !kReturnFromT) er = io.load ? ldg(b.ep_return, o4) : ls.er;
   double pre0 = 0.0, pre1 = 0.0;
   if (active && P > 0) pre0 = io.load ? ldg(b.theta, o8) : ls.th0;
   if (active && P > 1) pre1 = io.load ? ldg(b.theta + N, o8) : ls.th1;
@@ -534,14 +535,21 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     stg_out(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
     if (io.store) stg(b.status, o1, (uint8_t)(done ? NSG_ST_NEEDS_RESET : 0));
     if (track) {  // the episode length is the wrapper time t: only the return needs a running row
-      er += (float)reward;
-      if (done) {
-        stg(b.last_return, o4, er);
-        stg(b.last_length, o4, tnew);
-        er = 0.f;
+      if constexpr (kReturnFromT) {
+        if (done) {
+          stg(b.last_return, o4, T::RETURN_PER_STEP * (float)tnew);
+          stg(b.last_length, o4, tnew);
+        }
+      } else {
+        er += (float)reward;
+        if (done) {
+          stg(b.last_return, o4, er);
+          stg(b.last_length, o4, tnew);
+          er = 0.f;
+        }
+        ls.er = er;
+        if (io.store) stg(b.ep_return, o4, er);
       }
-      ls.er = er;
-      if (io.store) stg(b.ep_return, o4, er);
     }
   }
 
