@@ -167,6 +167,45 @@ __global__ __launch_bounds__(256) void soa_packed_kernel(Rows r, int64_t N) {
   }
 }
 
+// F: plain SoA rows, but the four byte rows leave the workgroup as FULL 128-B lines: every lane parks its four flag
+// bytes in LDS as one dword, after a barrier wavefront k writes row k as 64 lanes x 4 B (256 contiguous bytes)
+__global__ __launch_bounds__(256) void soa_linebytes_kernel(Rows r, int64_t N) {
+  __shared__ uint32_t flags[256];
+  const int64_t chunks = (N + 255) / 256;
+  for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const int64_t i = c * 256 + threadIdx.x;
+    unsigned st = 0, term = 0, trunc = 0, flag = 0;
+    if (i < N) {
+      st = r.status[i];
+      int t = r.t[i];
+      double s[4];
+      for (int k = 0; k < 4; k++) s[k] = r.phys[k * N + i];
+      const int a = r.action[i];
+      float er = r.er[i];
+      double th = r.theta[i];
+      f32x4 o;
+      float rew, delta;
+      compute(s, th, t, er, st, a, o, rew, term, trunc, flag, delta);
+      r.theta[i] = th;
+      r.delta[i] = delta;
+      for (int k = 0; k < 4; k++) r.phys[k * N + i] = s[k];
+      r.obs[i] = o;
+      r.t[i] = t;
+      r.reward[i] = rew;
+      r.er[i] = er;
+    }
+    flags[threadIdx.x] = term | (trunc << 8) | (flag << 16) | (st << 24);
+    __syncthreads();
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;   // wavefront w writes row w
+    const uint4 q = ((const uint4*)flags)[l];
+    const unsigned sh = 8 * w;
+    const uint32_t word = ((q.x >> sh) & 0xff) | (((q.y >> sh) & 0xff) << 8) | (((q.z >> sh) & 0xff) << 16) | (((q.w >> sh) & 0xff) << 24);
+    uint8_t* row = w == 0 ? r.term : w == 1 ? r.trunc : w == 2 ? r.flag : r.status;
+    if (c * 256 + 4 * l + 3 < N) ((uint32_t*)(row + c * 256))[l] = word;
+    __syncthreads();
+  }
+}
+
 // E: pure copy of the same byte count with 16-B accesses (upper bound of the memory system for this footprint)
 __global__ __launch_bounds__(256) void copy16_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n16) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
@@ -275,6 +314,8 @@ int main(int argc, char** argv) {
     float b = time_it([&] { hipLaunchKernelGGL(blocked_kernel<false>, dim3(g), dim3(256), 0, 0, r, N); }, iters);
     float c = time_it([&] { hipLaunchKernelGGL(blocked_kernel<true>, dim3(g), dim3(256), 0, 0, r, N); }, iters);
     float d = time_it([&] { hipLaunchKernelGGL(soa_packed_kernel, dim3(g), dim3(256), 0, 0, r, N); }, iters);
+    float f = time_it([&] { hipLaunchKernelGGL(soa_linebytes_kernel, dim3(g), dim3(256), 0, 0, r, N); }, iters);
+    printf("N=%lld grid=%d  soa with byte rows written as full lines through LDS: %.2f us\n", (long long)N, g, f);
     float e = time_it([&] { hipLaunchKernelGGL(copy16_kernel, dim3(g), dim3(256), 0, 0, src, dst, copy_bytes / 16); }, iters);
     printf("N=%lld grid=%d  soa %.2f us | state-blocked %.2f | all-blocked %.2f | soa-packed-flags %.2f | copy16(120B/env) %.2f   [120 B/env-step: %.0f %.0f %.0f %.0f %.0f GB/s]\n",
            (long long)N, g, a, b, c, d, e, 120.0 * N / a / 1e3, 120.0 * N / b / 1e3, 120.0 * N / c / 1e3, 120.0 * N / d / 1e3,
