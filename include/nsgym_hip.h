@@ -225,8 +225,9 @@ typedef struct nsg_buffers {
                             (classic_control.py:87-92; the reference warns instead).  NSG_F_VIOLATION_MASK */
   float* prob;           /* [N]    FrozenLake info["prob"]                                */
   float* ep_return;      /* [N]    running episode return      (NSG_F_TRACK_RETURNS).  Not maintained for the env types
-                            whose reward is the same constant on every step (CartPole +1, MountainCar -1): there the
-                            running return IS +-t and last_return is derived from t when an episode ends           */
+                            whose reward is the same constant on every step (CartPole +1, MountainCar -1: the running return
+                            IS +-t) or paid only by the step that ends the episode (FrozenLake with default rewards,
+                            Bridge: the return IS that reward); last_return is derived when an episode ends        */
   int32_t* ep_length;    /* [N]    running episode length                                 */
   float* last_return;    /* [N]    return of the last finished episode                    */
   int32_t* last_length;  /* [N]                                                           */

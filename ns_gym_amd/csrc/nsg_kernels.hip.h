@@ -607,11 +607,14 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
 
   const uint32_t o1 = (uint32_t)i, o4 = o1 * 4u, o8 = o1 * 8u;  // per-lane byte offsets into [N] rows
   const bool track = (cfg.flags & NSG_F_TRACK_RETURNS) != 0;
+  // FrozenLake with its default rewards and Bridge pay only on the step that ends the episode (toy_text.py:441,
+  // envs/Bridge.py:99-101): the episode return IS that last reward, no running-return row is needed
+  const bool return_is_last_reward = ENV == NSG_ENV_BRIDGE || (ENV == NSG_ENV_FROZENLAKE && !(cfg.flags & NSG_F_MODIFIED_REWARDS));
   if (io.load && active) {  // first step of a launch: fetch the persistent rows
     gl.st = ldg(b.status, o1);
     gl.t = ldg(b.t, o4);
     gl.cell = ldg(b.cell, o4);
-    if (track) gl.er = ldg(b.ep_return, o4);
+    if (track && !return_is_last_reward) gl.er = ldg(b.ep_return, o4);
     pcg_load<true>(b.rng_env, N, i, gl.g);
     if constexpr (ENV != NSG_ENV_BRIDGE) {
 #pragma unroll
@@ -785,7 +788,7 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
     stg_out(out.terminated, o1, (uint8_t)(term ? 1 : 0));
     stg_out(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
     if (track) {
-      float er = do_reset ? 0.f : gl.er + (float)reward;
+      float er = return_is_last_reward ? (float)reward : do_reset ? 0.f : gl.er + (float)reward;
       if (done) {
         stg(b.last_return, o4, er);
         stg(b.last_length, o4, tnew);
@@ -798,7 +801,7 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       stg(b.t, o4, tnew);
       stg(b.status, o1, (uint8_t)gl.st);
       if (b.prob) stg(b.prob, o4, (float)prob);
-      if (track) stg(b.ep_return, o4, gl.er);
+      if (track && !return_is_last_reward) stg(b.ep_return, o4, gl.er);
       pcg_store_state<true>(b.rng_env, N, i, gl.g);
     }
   }
