@@ -154,9 +154,7 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
     double u = (double)af;
     if (u < -2.0) u = -2.0;
     if (u > 2.0) u = 2.0;
-    double r = fmod(t0 + NSG_PI, 2 * NSG_PI);  // Python float %: result takes the divisor's sign
-    if (r != 0 && r < 0) r += 2 * NSG_PI;
-    double an = r - NSG_PI;
+    const double an = nsg_pymod_pos(t0 + NSG_PI, 2 * NSG_PI) - NSG_PI;  // angle_normalize: ((x + pi) % (2 pi)) - pi [UPSTREAM]
     double costs = an * an + 0.1 * (thdot * thdot) + 0.001 * (u * u);
     double newthdot = thdot + (3 * g / (2 * l) * nsg_sin(t0) + 3.0 / (m * (l * l)) * u) * dt;
     if (newthdot < -8.0) newthdot = -8.0;

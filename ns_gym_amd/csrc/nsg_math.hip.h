@@ -80,6 +80,19 @@ NSG_HD void nsg_sincos(double x, double* sn, double* cs) {
   }
 }
 
+// Python's float `x % m` for m > 0 (floor-mod: fmod, then + m when the remainder is negative), exactly, without
+// fmod's long-division loop.  q = floor(x / m) is the true floored quotient or one too large (rounding to nearest is
+// monotonic, so it never falls below an integer the true quotient reaches); x - q*m then lies in (-m, m), is a multiple
+// of the operands' finer ulp and so fits a double: the fused multiply-add returns it EXACTLY, and the one conditional
+// + m (exact too: the sum is the true remainder) finishes.  Valid for |x / m| < 2^52.  tests/test_math_cpu.py checks it
+// against Python's own % bit for bit.
+NSG_HD double nsg_pymod_pos(double x, double m) {
+  const double q = floor(x / m);
+  double r = __builtin_fma(-q, m, x);
+  if (r < 0.0) r += m;
+  return r;
+}
+
 NSG_HD double nsg_sin(double x) { double s, c; nsg_sincos(x, &s, &c); return s; }
 NSG_HD double nsg_cos(double x) { double s, c; nsg_sincos(x, &s, &c); return c; }
 

@@ -15,6 +15,7 @@ SRC = r'''
 #include "%s/ns_gym_amd/csrc/nsg_math.hip.h"
 extern "C" {
 void t_sincos(const double* x, double* s, double* c, long n) { for (long i = 0; i < n; i++) nsg::nsg_sincos(x[i], s + i, c + i); }
+void t_pymod(const double* x, double m, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_pymod_pos(x[i], m); }
 void t_exp(const double* x, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_exp(x[i]); }
 void t_log1p(const double* x, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_log1p(x[i]); }
 }
@@ -72,3 +73,21 @@ def test_exp_and_log1p_within_one_ulp(m):
     assert np.isinf(y[0]) and y[1] == 0.0 and np.isnan(y[2]) and y[3] == 1.0
     (y,) = _call(m.t_log1p, np.array([-1.0, -2.0, 0.0, np.inf]))
     assert y[0] == -np.inf and np.isnan(y[1]) and y[2] == 0.0 and np.isinf(y[3])
+
+
+def test_pymod_equals_python_float_mod_bit_for_bit(m):
+    """Pendulum's angle_normalize uses Python's float %: nsg_pymod_pos must reproduce it exactly (incl. negative
+    arguments, exact multiples, values next to multiples, tiny and large arguments)."""
+    rng = np.random.default_rng(2)
+    two_pi = 2 * np.pi
+    k = np.arange(-3000, 3001, dtype=np.float64) * two_pi
+    xs = np.concatenate([rng.uniform(-r, r, 300_000) for r in (1.0, 10.0, 1e3, 1e6, 1e9)] +
+                        [k, np.nextafter(k, np.inf), np.nextafter(k, -np.inf), np.array([0.0, -0.0, 5e-324, -5e-324, 1e-300, -1e-300])])
+    for mod in (two_pi, 1.0, 0.3, 7.5):
+        y = np.empty_like(xs)
+        m.t_pymod.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_long]
+        m.t_pymod(xs.ctypes.data_as(C.c_void_p), C.c_double(mod), y.ctypes.data_as(C.c_void_p), C.c_long(xs.size))
+        want = np.array([float(v) % mod for v in xs[:200_000]] )      # Python's own operator
+        assert np.array_equal(y[:200_000], want)
+        want_np = np.mod(xs, mod)                                     # NumPy's floor-mod agrees with Python's for floats
+        assert np.array_equal(y, want_np) or np.array_equal(y[want_np != mod], want_np[want_np != mod])
