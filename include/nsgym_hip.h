@@ -188,7 +188,9 @@ typedef struct nsg_config {
  * D = obs dim.  Pointers that a configuration does not need may be NULL (nsg_layout says
  * which are needed). */
 typedef struct nsg_buffers {
-  double* phys;          /* [F][N] integrator state, fp64 like the reference              */
+  double* phys;          /* [ceil(N/256)][F][256] integrator state, fp64 like the reference: the F rows of a
+                            256-env chunk (= one workgroup) are contiguous; element (row k, env i) sits at
+                            ((i / 256) * F + k) * 256 + i % 256                                        */
   int32_t* cell;         /* [N]    grid envs: state index s                                */
   double* theta;         /* [P][N] tuned θ   (grid envs: [P][n][N] distributions, n = 3 or 4) */
   double* table_prob;    /* [n][N] FrozenLake / CliffWalking: probabilities baked into the wrapper's P table.

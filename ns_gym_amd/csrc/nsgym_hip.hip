@@ -222,7 +222,7 @@ int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
   out->n_theta_rows = fl ? kNDist[e] * P : P;
   out->action_is_float = (e == NSG_ENV_PENDULUM || e == NSG_ENV_MOUNTAINCAR_CONT) ? 1 : 0;
   out->n_actions = kNActions[e];
-  out->phys = (int64_t)kPhysDim[e] * n;
+  out->phys = (int64_t)kPhysDim[e] * ((n + kBlock - 1) / kBlock) * kBlock;  // chunk-blocked: [ceil(n/256)][F][256]
   out->cell = fl ? n : 0;
   out->theta = (int64_t)out->n_theta_rows * n;
   out->table_prob = (fl && e != NSG_ENV_BRIDGE) ? (int64_t)kNDist[e] * n : 0;

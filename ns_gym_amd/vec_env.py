@@ -144,7 +144,14 @@ class VecNSEnv:
             self.table_prob = b["table_prob"].view(self.n_dist, N) if b["table_prob"] is not None else None
         else:
             self.state = b["obs"].view(N, self.obs_dim)
-            self.phys = b["phys"].view(self.layout.phys_dim, N)
+            self._phys_blocked = b["phys"].view(-1, self.layout.phys_dim, 256)   # [chunk][F][256], see nsgym_hip.h
+
+    @property
+    def phys(self):
+        """Float64 integrator state as a dense [F, N] tensor (a gathered COPY: the device rows are chunk-blocked,
+        [ceil(N/256)][F][256], so that a workgroup's state is one contiguous run)."""
+        F = self.layout.phys_dim
+        return self._phys_blocked.permute(1, 0, 2).reshape(F, -1)[:, : self.N].contiguous()
 
     @property
     def _stream(self):

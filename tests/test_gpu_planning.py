@@ -190,15 +190,16 @@ def test_fork_repeat_equals_separate_forks():
             big.step(acts[k].repeat(S))
             for p in parts:
                 p.step(acts[k])
-        rows = ("phys", "cell", "theta", "t", "status", "reward", "terminated", "truncated", "ep_return", "last_return")
+        rows = ("cell", "theta", "t", "status", "reward", "terminated", "truncated", "ep_return", "last_return")
         for s, p in enumerate(parts):
+            if not big.is_grid:
+                assert torch.equal(big.phys[:, s * n:(s + 1) * n], p.phys), ("phys", s)
             for row in rows:
                 x, y = big.buf[row], p.buf[row]
                 if x is None:
                     continue
-                r = x.numel() // big.N if x.numel() % big.N == 0 else None
-                xs = x.view(-1, big.N)[:, s * n:(s + 1) * n] if row in ("phys", "theta") else x.view(big.N, -1)[s * n:(s + 1) * n].reshape(-1)
-                ys = y.view(-1, n) if row in ("phys", "theta") else y.reshape(-1)
+                xs = x.view(-1, big.N)[:, s * n:(s + 1) * n] if row == "theta" else x.view(big.N, -1)[s * n:(s + 1) * n].reshape(-1)
+                ys = y.view(-1, n) if row == "theta" else y.reshape(-1)
                 assert torch.equal(xs, ys), (row, s)
         # re-use: the big copy is overwritten in place
         assert env.fork(theta_mode=0, entropy=9, into=big) is big
