@@ -193,7 +193,7 @@ typedef struct nsg_buffers {
                             ((i / 256) * F + k) * 256 + i % 256                                        */
   int32_t* cell;         /* [N]    grid envs: state index s                                */
   double* theta;         /* [P][N] tuned θ   (grid envs: [P][n][N] distributions, n = 3 or 4) */
-  double* table_prob;    /* [n][N] FrozenLake / CliffWalking: probabilities baked into the wrapper's P table.
+  double* table_prob;    /* [ceil(N/256)][n][256] (chunk-blocked like phys) FrozenLake / CliffWalking: probabilities baked into the wrapper's P table.
                             Differs from theta after a reset: the reference's reset restores
                             transition_prob (toy_text.py:396) but its next step re-installs the
                             wrapper's un-reset self.P (toy_text.py:365-367), so the previous
@@ -209,7 +209,7 @@ typedef struct nsg_buffers {
   uint8_t* status;       /* [N]    NSG_ST_* bits                                          */
   uint64_t* rng_env;     /* env np_random PCG64 streams: state_hi,state_lo,inc_hi,inc_lo.  Classic-control envs:
                             [N][4], one 32-byte record per env (touched by the few lanes that reset);
-                            grid envs: [4][N] rows (every lane draws one uniform per step)                 */
+                            grid envs: chunk-blocked rows [ceil(N/256)][4][256] (every lane draws one uniform per step) */
   uint64_t* rng_upd;     /* [P][N][4] update-fn PCG64 streams (only rows with uses_rng)   */
   uint64_t* rng_sched;   /* [P][N][4] PCG64 records of stochastic schedulers (Random, DecayingProbability,
                             Memoryless).  A scheduler lives inside the deep-copied init_initial_params, so a

@@ -44,13 +44,6 @@ template <bool FULL> constexpr bool kEarlyDraw = (NSG_EARLY_DRAW != 0) && !FULL;
 #endif
 
 
-// `phys` is chunk-blocked: [ceil(N / 256)][F][256] float64 - the F integrator-state rows of a workgroup's 256 envs are
-// ONE contiguous run (8 KB for CartPole) instead of F runs 8 MB apart.  Measured on the C1 step: 27.7 -> 26.1 us
-// (2^20 envs), 110 -> 101 us (2^22).  Byte offset of element (row k, env i); fits 32 bits for N <= 2^27, F <= 4.
-__host__ __device__ inline uint32_t phys_off8(int F, int k, int64_t i) {
-  return (uint32_t)((((uint64_t)i >> 8) * (uint64_t)(F * 256) + (uint64_t)k * 256 + ((uint64_t)i & 255)) * 8);
-}
-
 // Device-resident description of one homogeneous env segment (read through scalar loads).
 struct Segment {
   nsg_config cfg;
@@ -314,7 +307,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   if (sim && io.load && active) ls.tf = ldg(b.t_fork, o4);
   double s[T::PHYS];
 #pragma unroll
-  for (int k = 0; k < T::PHYS; k++) s[k] = !do_step ? 0.0 : io.load ? ldg(b.phys, phys_off8(T::PHYS, k, i)) : ls.s[k];
+  for (int k = 0; k < T::PHYS; k++) s[k] = !do_step ? 0.0 : io.load ? ldg(b.phys, blk_off8(T::PHYS, k, i)) : ls.s[k];
   int ai = 0;
   float af = 0.f;
   if (do_step) {
@@ -531,7 +524,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   if (active) {  // every row is written by its owner lane: fully coalesced stores
     if (io.store) {
 #pragma unroll
-      for (int k = 0; k < T::PHYS; k++) stg(b.phys, phys_off8(T::PHYS, k, i), s[k]);
+      for (int k = 0; k < T::PHYS; k++) stg(b.phys, blk_off8(T::PHYS, k, i), s[k]);
     }
     float o[T::OBS];
     env_obs<ENV>(s, o);
@@ -625,7 +618,7 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
     pcg_load<true>(b.rng_env, N, i, gl.g);
     if constexpr (ENV != NSG_ENV_BRIDGE) {
 #pragma unroll
-      for (int k = 0; k < ND; k++) gl.tp[k] = ldg(b.table_prob + (int64_t)k * N, o8);
+      for (int k = 0; k < ND; k++) gl.tp[k] = ldg(b.table_prob, blk_off8(ND, k, i));
     }
   }
   const unsigned st = active ? gl.st : 0u;
@@ -682,7 +675,7 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       for (int k = 0; k < ND; k++) {
         stg(b.theta + (int64_t)(p * ND + k) * N, o8, q[k]);
         if constexpr (ENV != NSG_ENV_BRIDGE) {  // P re-weighted on a fire only
-          stg(b.table_prob + (int64_t)k * N, o8, q[k]);
+          stg(b.table_prob, blk_off8(ND, k, i), q[k]);
           gl.tp[k] = q[k];
         }
       }
@@ -919,7 +912,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
       double s[T::PHYS];
       env_reset_draw<ENV>(g, s);
 #pragma unroll
-      for (int k = 0; k < T::PHYS; k++) b.phys[phys_off8(T::PHYS, k, i) / 8] = s[k];
+      for (int k = 0; k < T::PHYS; k++) b.phys[blk_off8(T::PHYS, k, i) / 8] = s[k];
       float o[T::OBS];
       env_obs<ENV>(s, o);
       store_obs<ENV>(b.obs, i, o);
@@ -994,7 +987,7 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const Segment* __restrict_
       for (int p = 0; p < cfg.n_params; p++)
         for (int k = 0; k < nd; k++) b.theta[(int64_t)(p * nd + k) * N + i] = grid_initial(cfg, p)[k];
       if (b.table_prob)
-        for (int k = 0; k < nd; k++) b.table_prob[(int64_t)k * N + i] = cfg.initial_prob[0][k];
+        for (int k = 0; k < nd; k++) b.table_prob[blk_off8(nd, k, i) / 8] = cfg.initial_prob[0][k];
       b.cell[i] = 0;
       if (b.prob) b.prob[i] = 1.f;
     }
@@ -1160,7 +1153,7 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
   const int obs = fl ? 0 : (env == NSG_ENV_CARTPOLE ? 4 : env == NSG_ENV_PENDULUM ? 3 : env == NSG_ENV_ACROBOT ? 6 : 2);
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
     const int64_t is = i % Ns;
-    for (int k = 0; k < phys; k++) db.phys[phys_off8(phys, k, i) / 8] = sb.phys[phys_off8(phys, k, is) / 8];
+    for (int k = 0; k < phys; k++) db.phys[blk_off8(phys, k, i) / 8] = sb.phys[blk_off8(phys, k, is) / 8];
     if (fl) db.cell[i] = sb.cell[is];
     const int t = sb.t[is];
     db.t[i] = t;
@@ -1190,7 +1183,7 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
         // CliffWalking (toy_text.py:219-221,246-249,187): the copy's own table IS the copied current one.
         const bool use_initial = env == NSG_ENV_FROZENLAKE ? (in_sim_change || theta_mode == 1) : (theta_mode == 1 && !in_sim_change);
         for (int k = 0; k < nd; k++)
-          db.table_prob[(int64_t)k * N + i] = use_initial ? cfg.initial_prob[0][k] : sb.table_prob[(int64_t)k * Ns + is];
+          db.table_prob[blk_off8(nd, k, i) / 8] = use_initial ? cfg.initial_prob[0][k] : sb.table_prob[blk_off8(nd, k, is) / 8];
       }
       if (db.prob && sb.prob) db.prob[i] = sb.prob[is];
     }

@@ -225,13 +225,13 @@ int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
   out->phys = (int64_t)kPhysDim[e] * ((n + kBlock - 1) / kBlock) * kBlock;  // chunk-blocked: [ceil(n/256)][F][256]
   out->cell = fl ? n : 0;
   out->theta = (int64_t)out->n_theta_rows * n;
-  out->table_prob = (fl && e != NSG_ENV_BRIDGE) ? (int64_t)kNDist[e] * n : 0;
+  out->table_prob = (fl && e != NSG_ENV_BRIDGE) ? (int64_t)kNDist[e] * ((n + kBlock - 1) / kBlock) * kBlock : 0;  // chunk-blocked
   out->t = n;
   const bool simenv = (cfg->flags & NSG_F_SIM_ENV) != 0;
   out->t_fork = simenv ? n : 0;
   out->derived = (simenv && e == NSG_ENV_CARTPOLE) ? 2 * n : 0;
   out->status = n;
-  out->rng_env = 4 * n;
+  out->rng_env = fl ? 4 * ((n + kBlock - 1) / kBlock) * kBlock : 4 * n;  // grid envs: chunk-blocked rows; classic: [n][4] records
   out->rng_upd = any_rng ? (int64_t)P * 4 * n : 0;
   out->cursor = any_cursor ? (int64_t)P * n : 0;
   out->rng_sched = any_sched ? (int64_t)P * 4 * n : 0;

@@ -141,10 +141,17 @@ class VecNSEnv:
         if self.is_grid:
             self.state = b["cell"]
             self.prob = b["prob"]
-            self.table_prob = b["table_prob"].view(self.n_dist, N) if b["table_prob"] is not None else None
+            self._table_prob_blocked = (b["table_prob"].view(-1, self.n_dist, 256) if b["table_prob"] is not None else None)
         else:
             self.state = b["obs"].view(N, self.obs_dim)
             self._phys_blocked = b["phys"].view(-1, self.layout.phys_dim, 256)   # [chunk][F][256], see nsgym_hip.h
+
+    @property
+    def table_prob(self):
+        """FrozenLake / CliffWalking: the probabilities baked into the wrapper's P table, dense [n, N] (gathered copy
+        of the chunk-blocked rows)."""
+        tb = self._table_prob_blocked
+        return None if tb is None else tb.permute(1, 0, 2).reshape(self.n_dist, -1)[:, : self.N].contiguous()
 
     @property
     def phys(self):

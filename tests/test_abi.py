@@ -56,7 +56,7 @@ def test_layout_query_is_pure_host_arithmetic(lib):
     assert lay.ep_return == 1000 and lay.counters == A.CNT_COUNT * A.CNT_SHARDS and lay.done_bits == 16
     cfg, _, _, _ = compile_config(make("FrozenLake-v1", map_name="8x8"), {"P": DistributionDecrementUpdate(ContinuousScheduler(), 0.1)})
     assert lib.nsg_layout_query(C.byref(cfg), 64, C.byref(lay)) == 0
-    assert (lay.cell, lay.theta, lay.table_prob, lay.obs, lay.prob, lay.phys) == (64, 192, 192, 0, 64, 0)
+    assert (lay.cell, lay.theta, lay.table_prob, lay.obs, lay.prob, lay.phys, lay.rng_env) == (64, 192, 768, 0, 64, 0, 1024)   # chunk-blocked rows pad to 256 envs
     assert lib.nsg_layout_query(C.byref(cfg), 0, C.byref(lay)) != 0
     assert b"2^27" in lib.nsg_last_error()
     # maximum batch per handle: rows are addressed with 32-bit byte offsets (32-byte stream records)
