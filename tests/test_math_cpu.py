@@ -49,7 +49,11 @@ def test_sincos_within_one_ulp(m):
     xs = [rng.uniform(-r, r, 400_000) for r in (0.3, 4.0, 30.0, 1e3, 1e6)]
     k = np.arange(-2000, 2001)[:, None] * (np.pi / 2)
     near = np.concatenate([np.nextafter(k, np.inf), k, np.nextafter(k, -np.inf)]).ravel()
-    for x in xs + [near]:
+    # either side of the first-round / compensated-reduction switch (|y0| vs |x| * 2^-15)
+    kk = np.arange(-400, 401)[:, None, None] * (np.pi / 2)
+    rel = 2.0 ** -np.arange(8, 30)[None, :, None] * np.array([1.0, -1.0, 0.7, -1.3])[None, None, :]
+    edge = (kk * (1.0 + rel)).ravel()
+    for x in xs + [near, edge]:
         s, c = _call(m.t_sincos, x, 2)
         xl = x.astype(np.longdouble)
         assert _ulps(s, np.sin(xl)) <= 1.0 and _ulps(c, np.cos(xl)) <= 1.0
