@@ -6,7 +6,7 @@ hand-written HIP kernels (gfx950) behind a C-ABI (include/nsgym_hip.h).
 """
 from . import _abi, base, envs, schedulers, spec, update_functions  # noqa: F401
 from .base import Reward, Scheduler, UpdateDistributionFn, UpdateFn  # noqa: F401
-from .envs import TUNABLE_PARAMS, make  # noqa: F401
+from .envs import TUNABLE_PARAMS, make, register, registry  # noqa: F401
 
 __version__ = "0.1.0"
 

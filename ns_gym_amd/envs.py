@@ -96,8 +96,26 @@ class BaseEnvSpec:
         return self
 
 
-def make(env_id: str, max_episode_steps: int | None = None, **kwargs) -> BaseEnvSpec:
-    """`gym.make` counterpart for the supported ids (same ids, same TimeLimit horizons)."""
+# User-registered ids -> entry points: the role gymnasium's `register` / `registry` play for the reference's users, who
+# register a factory that builds base env + NS wrapper and later `gym.make` it (tests/test_registration.py:78-117).
+registry: dict = {}
+
+
+def register(id: str, entry_point, **_gymnasium_options) -> None:
+    """`gymnasium.envs.registration.register` counterpart: `make(id, **kw)` calls `entry_point(**kw)`.  gymnasium's own
+    options (`disable_env_checker`, `order_enforce`, `max_episode_steps` ...) are accepted and have no effect here:
+    the entry point returns the finished wrapper."""
+    if not callable(entry_point):
+        raise TypeError("register(): entry_point must be callable (string entry points need gymnasium's importer)")
+    registry[id] = entry_point
+
+
+def make(env_id: str, max_episode_steps: int | None = None, **kwargs):
+    """`gym.make` counterpart for the supported ids (same ids, same TimeLimit horizons) and for ids added with `register`."""
+    if env_id in registry:
+        if max_episode_steps is not None:
+            kwargs["max_episode_steps"] = max_episode_steps
+        return registry[env_id](**kwargs)
     if env_id not in _REGISTRY:
         raise KeyError(f"{env_id} is not a supported environment; supported: {sorted(_REGISTRY)}")
     class_name, steps = _REGISTRY[env_id]

@@ -74,6 +74,7 @@ class _NSSingle:
     def __init__(self, env, tunable_params, change_notification=False, delta_change_notification=False,
                  in_sim_change=False, _vec=None, **kwargs: Any):
         self.spec: BaseEnvSpec = from_gym_env(env)
+        self.env = env   # gymnasium.Wrapper's attribute: the env this wrapper was built around
         self._vec = _vec if _vec is not None else VecNSEnv(
             self.spec, tunable_params, 1, change_notification=change_notification,
             delta_change_notification=delta_change_notification, in_sim_change=in_sim_change, **kwargs)

@@ -195,3 +195,21 @@ def test_cliffwalking_and_bridge_configs():
     with pytest.raises(AssertionError):
         compile_config(make("ns_gym/Bridge-v0"), {"P": DistributionCyclicUpdate(ContinuousScheduler(), [[0, 1, 0]]),
                                                   "P_left": DistributionCyclicUpdate(ContinuousScheduler(), [[0, 1, 0]])})
+
+
+def test_register_and_make_custom_ids():
+    """`register` / `registry` / `make` in gymnasium's role for user-registered NS envs (reference: tests/test_registration.py:78-117)."""
+    import ns_gym_amd as nsg
+
+    calls = []
+    nsg.register(id="HostApi-Custom-v0", entry_point=lambda **kw: calls.append(kw) or "built", disable_env_checker=True, order_enforce=False)
+    try:
+        assert "HostApi-Custom-v0" in nsg.registry
+        assert nsg.make("HostApi-Custom-v0", flavour=3) == "built" and calls == [{"flavour": 3}]
+    finally:
+        del nsg.registry["HostApi-Custom-v0"]
+    with pytest.raises(KeyError):
+        nsg.make("HostApi-Custom-v0")
+    with pytest.raises(TypeError):
+        nsg.register(id="HostApi-Custom-v1", entry_point="module:factory")
+    assert nsg.make("CartPole-v1").env_id == "CartPole-v1"   # built-in ids unaffected
