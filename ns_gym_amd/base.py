@@ -152,3 +152,13 @@ class TableBuilder:
 
     def blob(self) -> bytes:
         return b"".join(self._chunks) if self._chunks else b"\0" * 8
+
+
+def __getattr__(name):
+    # `from ns_gym.base import NSWrapper` (base.py:206): here the common base of the N = 1 adaptors, which lives with
+    # them in wrappers.py (it needs the vector env, and with it torch - not loaded by importing this module)
+    if name == "NSWrapper":
+        from .wrappers import _NSSingle
+
+        return _NSSingle
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

@@ -16,18 +16,9 @@ from typing import Callable, Optional
 import numpy as np
 import torch
 
-from .base import Reward
+from .utils import type_mismatch_checker  # noqa: F401  (run_experiment.py imports it next to the harness)
 
 CSV_HEADER = ["total_reward", "State-Action-Reward-NextState", "num_steps", "seed", "sample_id", "time"]
-
-
-def type_mismatch_checker(observation=None, reward=None):
-    """`ns_gym.utils.type_mismatch_checker` (ns_gym/utils.py:122-152): NS observation dict -> state,
-    `Reward` -> scalar."""
-    obs = observation["state"] if isinstance(observation, dict) and "state" in observation else observation
-    rew = reward.reward if isinstance(reward, Reward) else reward
-    assert not isinstance(obs, dict), "Observation is still a dict after type checking."
-    return obs, rew
 
 
 def random_policy(env) -> Callable:

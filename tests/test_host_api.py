@@ -213,3 +213,39 @@ def test_register_and_make_custom_ids():
     with pytest.raises(TypeError):
         nsg.register(id="HostApi-Custom-v1", entry_point="module:factory")
     assert nsg.make("CartPole-v1").env_id == "CartPole-v1"   # built-in ids unaffected
+
+
+def test_utils_wasserstein_distance_equals_scipy_bit_for_bit():
+    """ns_gym_amd.utils.wasserstein_distance restates SciPy's CDF-distance sum (ns_gym/utils.py:55-94) term for term."""
+    from scipy.stats import wasserstein_distance as scipy_w1
+
+    from ns_gym_amd.utils import wasserstein_distance
+
+    rng = np.random.default_rng(3)
+    assert wasserstein_distance([1, 0, 0], [0, 0, 1]) == 2.0
+    assert wasserstein_distance([1.0, 0.0, 0.0], [0.6, 0.2, 0.2]) == scipy_w1([0, 1, 2], [0, 1, 2], [1.0, 0.0, 0.0], [0.6, 0.2, 0.2])
+    for n in list(range(1, 12)) + [16, 17, 33, 64, 129]:
+        for _ in range(40):
+            u, v = rng.random(n) * rng.integers(1, 5), rng.dirichlet(np.ones(n))
+            idx = np.arange(n, dtype=float)
+            assert wasserstein_distance(u, v) == float(scipy_w1(idx, idx, u_weights=u, v_weights=v)), n
+    with pytest.raises(ValueError):
+        wasserstein_distance([0.5, 0.5], [1.0, 0.0, 0.0])
+    with pytest.raises(ValueError):
+        wasserstein_distance([1.2, -0.2, 0.0], [1.0, 0.0, 0.0])   # the reference documents SciPy's refusal (tests/test_gridworld_wrappers.py:192-199)
+
+
+def test_utils_helpers_and_reference_import_locations():
+    import ns_gym_amd as nsg
+    from ns_gym_amd import utils
+    from ns_gym_amd.base import Reward
+
+    assert utils.n_choose_k(5, 2) == 10 and utils.n_choose_k(4, 0) == 1
+    row = [(1 / 3, 4, 0.0, False), (1 / 3, 0, 0.0, False), (1 / 3, 1, 1.0, True)]
+    assert utils.state_action_update(row, [0.6, 0.2, 0.2]) == [(0.6, 4, 0.0, False), (0.2, 0, 0.0, False), (0.2, 1, 1.0, True)]
+    assert utils.type_mismatch_checker({"state": 3, "relative_time": 1}, Reward(1.0, {}, {}, 1)) == (3, 1.0)
+    assert utils.type_mismatch_checker() == (None, None) and utils.type_mismatch_checker(5, 2.0) == (5, 2.0)
+    assert 0 <= utils.categorical_sample([0.2, 0.3, 0.5]) < 3
+    assert isinstance(nsg.__version__, str) and nsg.utils is utils
+    from ns_gym_amd.evaluate import type_mismatch_checker   # the harness's import location
+    assert type_mismatch_checker is utils.type_mismatch_checker
