@@ -139,6 +139,11 @@ class _NSSingle:
         terminated, truncated = bool(term[0].item()), bool(trunc[0].item())
         if not self._vec.is_grid:
             self._vec.check_constraints()  # aggregated ConstraintViolationWarning (classic_control.py:212-234)
+        elif bool((self._vec.theta < 0).any().item()):
+            # The reference's step() raises out of SciPy's W1 as soon as an update function hands back a pmf with a
+            # negative weight (base.py:192-203, utils.py:87-94) - DistributionIncrementUpdate has no lower clamp, so a
+            # negative k gets there (documented in the reference's tests/test_gridworld_wrappers.py:192-199).
+            raise ValueError("All weights must be non-negative.")
         if not self.scalar_reward:
             r = Reward(reward=r, env_change=o["env_change"], delta_change=o["delta_change"],
                        relative_time=o["relative_time"])

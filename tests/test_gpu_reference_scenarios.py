@@ -285,7 +285,7 @@ def test_reset_seeding_gridworld(env_id):
 
     nsg, W, Cont, _, _, DInc = _api()
     cls = {"CliffWalking-v1": W.NSCliffWalkingWrapper, "FrozenLake-v1": W.NSFrozenLakeWrapper}[env_id]
-    env = cls(nsg.make(env_id), {"P": DInc(Cont(), k=-0.05)}, initial_prob_dist=[0.4, 0.3, 0.3] if env_id == "FrozenLake-v1" else [0.4, 0.2, 0.2, 0.2])
+    env = cls(nsg.make(env_id), {"P": DInc(Cont(), k=-0.02)}, initial_prob_dist=[0.4, 0.3, 0.3] if env_id == "FrozenLake-v1" else [0.4, 0.2, 0.2, 0.2])
     env.reset(seed=0)
     a = states(env)
     env.reset(seed=0)
@@ -354,3 +354,26 @@ def test_planning_env_is_frozen_and_requires_reset():
     assert plan.unwrapped.masspole == before       # frozen θ (classic_control.py:70-75) ...
     env.step(0)
     assert env.unwrapped.masspole != before        # ... while the real env moves on
+
+
+@pytest.mark.parametrize("wrapper,env_id", [("NSFrozenLakeWrapper", "FrozenLake-v1"), ("NSCliffWalkingWrapper", "CliffWalking-v1")])
+def test_unclamped_distribution_increment_raises_where_the_reference_does(wrapper, env_id):
+    """DistributionIncrementUpdate(k=-0.1) from [1, 0, ...]: ten updates bring p0 to 1.4e-16, the eleventh makes it
+    negative and the reference's step() raises SciPy's ValueError from the W1 delta (observed with the reference's own
+    classes: steps 1-10 pass, step 11 raises "All weights must be non-negative."; its tests/test_gridworld_wrappers.py:192-199
+    documents the behaviour)."""
+    import ns_gym_amd as nsg
+    from ns_gym_amd import wrappers
+    from ns_gym_amd.schedulers import ContinuousScheduler
+    from ns_gym_amd.update_functions import DistributionIncrementUpdate
+
+    env = getattr(wrappers, wrapper)(nsg.make(env_id), {"P": DistributionIncrementUpdate(ContinuousScheduler(), k=-0.1)})
+    env.reset(seed=0)
+    for k in range(10):
+        _, _, terminated, truncated, info = env.step(0)
+        assert not (terminated or truncated)
+        assert info["transition_prob"][0] >= 0.0
+    assert info["transition_prob"][0] == pytest.approx(1.3877787807814457e-16, abs=1e-30)
+    with pytest.raises(ValueError, match="All weights must be non-negative"):
+        env.step(0)
+    env.close()
