@@ -66,6 +66,43 @@ def test_subset_of_full_batch_equals_oracle(name, T):
     env.close()
 
 
+@pytest.mark.parametrize("name,n,T", [("c1_cartpole_masspole_inc", N, 200), ("c2_cartpole_gravity_rw", 65536, 1000),
+                                      ("c3_frozenlake_step50", N, 200), ("c4_pendulum_m_inc", 262144, 200),
+                                      ("c4_acrobot_mass2_inc", 262144, 100)])
+def test_every_env_of_the_full_batch_equals_oracle(name, n, T):
+    """Not a sample: ALL envs of the BASELINE configurations at BASELINE's own batch sizes and step counts (C1's config at
+    C5's per-GPU size; C2 65 536 x 1000; C3 2^20 x 200; C4 2^18 each, Acrobot over the horizon its float32 tolerance
+    holds for) against the oracle (its OpenMP stepper on the host's cores), every compared row at checkpoints and at the end."""
+    N = n
+    import os
+
+    import torch
+
+    from oracle.oracle import OracleVecEnv
+    from tests.util import GpuView
+
+    spec = TRAJ_SPECS[name]
+    is_fl = spec["env_id"] == "FrozenLake-v1"
+    env = make_env_from_spec(_vec, spec, n=N, track_returns=True, specialize=True)
+    orc = make_env_from_spec(OracleVecEnv, spec, n=N, track_returns=True)
+    seeds = np.arange(N, dtype=np.uint64) + np.uint64(4242)
+    env.reset(seed=seeds)
+    orc.reset(seed=seeds)
+    view, oview = GpuView(env), OracleView(orc)
+    g = torch.Generator(device="cuda").manual_seed(17)
+    threads = min(16, os.cpu_count() or 1)
+    for k in range(T):
+        if env.action_is_float:
+            a = torch.rand(N, device="cuda", generator=g) * 4 - 2
+        else:
+            a = torch.randint(0, env.n_actions, (N,), dtype=torch.int32, device="cuda", generator=g)
+        env.step(a)
+        orc.step_mt(a.cpu().numpy(), threads)
+        if k % 50 == 0 or k == T - 1:
+            compare_views(view._out(), oview._out(), is_fl, f"{name}: all {N} envs, step {k}")
+    env.close()
+
+
 def test_full_batch_is_deterministic():
     import torch
 
