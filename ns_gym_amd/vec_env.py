@@ -25,6 +25,9 @@ _TORCH_DT = {C.c_double: torch.float64, C.c_int32: torch.int32, C.c_uint8: torch
              C.c_float: torch.float32}
 
 
+_NP_DT = {C.c_double: "<f8", C.c_int32: "<i4", C.c_uint8: "u1", C.c_uint64: "<u8", C.c_float: "<f4"}
+
+
 class ConstraintViolationWarning(Warning):
     """Issued when updates were rejected by the physical-constraint checker
     (ns_gym/wrappers/classic_control.py:9-12)."""
@@ -87,10 +90,22 @@ class VecNSEnv:
         self.action_is_float = bool(lay.action_is_float)
         self.n_actions = lay.n_actions
         with torch.cuda.device(self.device):
-            self.buf = {}
-            for name, ct in A.BUFFER_FIELDS:
+            # every row is a view into ONE zeroed allocation (256-byte aligned rows; the counter shards last): a planning
+            # copy costs one allocation instead of 25, and the N = 1 adaptors read a whole step back in one copy (host_rows)
+            spans, off = {}, 0
+            order = [f for f in A.BUFFER_FIELDS if f[0] != "counters"] + [f for f in A.BUFFER_FIELDS if f[0] == "counters"]
+            for name, ct in order:
                 n = getattr(lay, name)
-                self.buf[name] = torch.zeros(n, dtype=_TORCH_DT[ct], device=self.device) if n > 0 else None
+                if name == "counters":
+                    self._arena_head = off
+                if n > 0:
+                    spans[name] = (off, n * C.sizeof(ct), ct)
+                    off += (n * C.sizeof(ct) + 255) & ~255
+            self._arena = torch.zeros(max(off, 256), dtype=torch.uint8, device=self.device)
+            self._spans = spans
+            self.buf = {name: None for name, _ in A.BUFFER_FIELDS}
+            for name, (o, nb, ct) in spans.items():
+                self.buf[name] = self._arena[o:o + nb].view(_TORCH_DT[ct])
             self._bufs = A.Buffers(**{k: (v.data_ptr() if v is not None else None) for k, v in self.buf.items()})
             h = C.c_void_p()
             _lib.check(self.lib.nsg_create(C.byref(self.cfg), self.tables, len(self.tables), self.N, C.byref(h)),
@@ -269,6 +284,12 @@ class VecNSEnv:
             info["transition_prob"] = (self.theta if len(self.param_names) == 1 else
                                        {p: self.theta[j * n:(j + 1) * n] for j, p in enumerate(self.param_names)})
         return info
+
+    def host_rows(self) -> dict:
+        """Every row except the counter shards as NumPy arrays, fetched with ONE device-to-host copy (synchronises).
+        Meant for small batches - the N = 1 adaptors read a step's outputs from it instead of one `.item()` per scalar."""
+        h = self._arena[:self._arena_head].cpu().numpy()
+        return {name: h[o:o + nb].view(_NP_DT[ct]) for name, (o, nb, ct) in self._spans.items() if name != "counters"}
 
     # ------------------------------------------------------------------ reductions / bookkeeping
     def counters(self) -> dict:

@@ -75,6 +75,9 @@ class _NSSingle:
                  in_sim_change=False, _vec=None, **kwargs: Any):
         self.spec: BaseEnvSpec = from_gym_env(env)
         self.env = env   # gymnasium.Wrapper's attribute: the env this wrapper was built around
+        self._act = None
+        self._host = None
+        kwargs.setdefault("violation_mask", True)   # the per-step rejected-update row feeds the ConstraintViolationWarning
         self._vec = _vec if _vec is not None else VecNSEnv(
             self.spec, tunable_params, 1, change_notification=change_notification,
             delta_change_notification=delta_change_notification, in_sim_change=in_sim_change, **kwargs)
@@ -102,44 +105,52 @@ class _NSSingle:
     frozen = property(lambda self: self._vec.frozen)
     is_sim_env = property(lambda self: self._vec.is_sim_env)
 
-    def _scalars(self, obs, info):
-        names = self._vec.param_names
-        state = obs["state"]
-        if self._vec.is_frozenlake:
-            st = int(state[0].item())
-        else:
-            st = state[0].cpu().numpy().copy()
+    def _scalars(self):
+        """The wrapper's scalar observation / info dicts (base.py:343-363) out of ONE read-back of the env's rows
+        (`VecNSEnv.host_rows`); the snapshot stays in `self._host` for the subclass's extra info fields."""
+        v = self._vec
+        h = self._host = v.host_rows()
+        names = v.param_names
+        st = int(h["cell"][0]) if v.is_grid else h["obs"][:v.obs_dim].copy()
+        gt_ec = {p: int(h["env_change"][j]) for j, p in enumerate(names)}
+        gt_dc = {p: float(h["delta_change"][j]) for j, p in enumerate(names)}
+        hide = v.frozen or (v.is_sim_env and not v.in_sim_change)   # VecNSEnv._masked (base.py:316-321)
+        show_ec, show_dc = v.change_notification and not hide, v.delta_change_notification and not hide
         out = {
             "state": st,
-            "env_change": {p: int(obs["env_change"][p][0].item()) for p in names},
-            "delta_change": {p: float(obs["delta_change"][p][0].item()) for p in names},
-            "relative_time": int(obs["relative_time"][0].item()),
+            "env_change": gt_ec if show_ec else {p: 0 for p in names},
+            "delta_change": gt_dc if show_dc else {p: 0.0 for p in names},
+            "relative_time": int(h["t"][0]),
         }
-        inf = {
-            "Ground Truth Env Change": {p: int(info["Ground Truth Env Change"][p][0].item()) for p in names},
-            "Ground Truth Delta Change": {p: float(info["Ground Truth Delta Change"][p][0].item()) for p in names},
-        }
+        inf = {"Ground Truth Env Change": dict(gt_ec), "Ground Truth Delta Change": dict(gt_dc)}
         return out, inf
 
     def reset(self, *, seed: int | None = None, options: dict | None = None):
-        obs, info = self._vec.reset(seed=None if seed is None else [int(seed)], options=options)
+        self._vec.reset(seed=None if seed is None else [int(seed)], options=options)
         self._done = False
-        o, inf = self._scalars(obs, info)
+        o, inf = self._scalars()
         # the reference's reset info carries the zero dicts (base.py:397-408)
         return o, inf
 
     def _step(self, action):
-        if self._vec.action_is_float:
-            a = torch.tensor([float(np.asarray(action, dtype=np.float64).reshape(-1)[0])], dtype=torch.float32)
-        else:
-            a = torch.tensor([int(action)], dtype=torch.int32)
-        obs, rew, term, trunc, info = self._vec.step(a)
-        o, inf = self._scalars(obs, info)
-        r = float(rew[0].item())
-        terminated, truncated = bool(term[0].item()), bool(trunc[0].item())
-        if not self._vec.is_grid:
-            self._vec.check_constraints()  # aggregated ConstraintViolationWarning (classic_control.py:212-234)
-        elif bool((self._vec.theta < 0).any().item()):
+        v = self._vec
+        if self._act is None:
+            self._act = torch.zeros(1, dtype=torch.float32 if v.action_is_float else torch.int32, device=v.device)
+        # the action reaches the device as the scalar argument of a fill kernel (asynchronous), not as a host-to-device copy
+        self._act.fill_(float(np.asarray(action, dtype=np.float64).reshape(-1)[0]) if v.action_is_float else int(action))
+        v.step(self._act)
+        o, inf = self._scalars()
+        h = self._host
+        r = float(h["reward"][0])
+        terminated, truncated = bool(h["terminated"][0]), bool(h["truncated"][0])
+        if not v.is_grid:
+            if "violation" not in h:
+                v.check_constraints()
+            new = int(h["violation"].sum()) if "violation" in h else 0   # this step's rejected updates (violation_mask row)
+            if new:  # aggregated ConstraintViolationWarning (classic_control.py:212-234), same text as VecNSEnv.check_constraints
+                v._viol_seen += new
+                warnings.warn(f"{new} parameter updates violated a physical constraint and were not applied", ConstraintViolationWarning)
+        elif bool((h["theta"] < 0).any()):
             # The reference's step() raises out of SciPy's W1 as soon as an update function hands back a pmf with a
             # negative weight (base.py:192-203, utils.py:87-94) - DistributionIncrementUpdate has no lower clamp, so a
             # negative k gets there (documented in the reference's tests/test_gridworld_wrappers.py:192-199).
@@ -164,6 +175,7 @@ class _NSSingle:
 
         new = _copy.copy(self)            # shallow: shares the descriptor objects, not device state
         new._vec = vec
+        new._act = new._host = None
         new.unwrapped = _Unwrapped(new)
         return new
 
@@ -227,8 +239,8 @@ class NSFrozenLakeWrapper(_NSSingle):
 
     def step(self, action: int):
         obs, reward, terminated, truncated, info = self._step(action)
-        info["prob"] = float(self._vec.prob[0].item())
-        info["transition_prob"] = self.transition_prob  # toy_text.py:379
+        info["prob"] = float(self._host["prob"][0])
+        info["transition_prob"] = [float(x) for x in self._host["theta"]]  # toy_text.py:379
         return obs, reward, terminated, truncated, info
 
     def reset(self, *, seed: int | None = None, options: dict | None = None):
@@ -295,8 +307,8 @@ class NSCliffWalkingWrapper(_NSSingle):
 
     def step(self, action: int):
         obs, reward, terminated, truncated, info = self._step(action)
-        info["prob"] = float(self._vec.prob[0].item())
-        info["transition_prob"] = self.transition_prob  # toy_text.py:192
+        info["prob"] = float(self._host["prob"][0])
+        info["transition_prob"] = [float(x) for x in self._host["theta"]]  # toy_text.py:192
         return obs, reward, terminated, truncated, info
 
     def reset(self, *, seed: int | None = None, options: dict | None = None):
@@ -343,10 +355,12 @@ class NSBridgeWrapper(_NSSingle):
         self._split_mode = ("P_left" in tunable_params) or ("P_right" in tunable_params)
         self.initial_prob_dist = initial_prob_dist
 
-    def _dist(self, name):
+    def _dist(self, name, host=None):
         v = self._vec
         if name in v.param_names:
             j = v.param_names.index(name)
+            if host is not None:   # this step's read-back (N = 1: row k of theta is element k)
+                return [float(x) for x in host["theta"][3 * j:3 * j + 3]]
             return [float(x) for x in v.theta[3 * j:3 * j + 3, 0].tolist()]
         side = 1 if name == "P_right" else 0
         return [float(v.cfg.initial_prob[side][k]) for k in range(3)]
@@ -355,6 +369,6 @@ class NSBridgeWrapper(_NSSingle):
         obs, reward, terminated, truncated, info = self._step(action)
         reward = int(reward) if self.scalar_reward else reward   # Bridge returns int rewards (envs/Bridge.py:101)
         col = obs["state"] % int(self._vec.cfg.ncol)
-        info["prob"] = (self._dist("P_left" if col < int(self._vec.cfg.ncol) // 2 else "P_right")
-                        if self._split_mode else self._dist("P"))
+        info["prob"] = (self._dist("P_left" if col < int(self._vec.cfg.ncol) // 2 else "P_right", self._host)
+                        if self._split_mode else self._dist("P", self._host))
         return obs, reward, terminated, truncated, info
