@@ -119,12 +119,7 @@ class VecNSEnv:
                     if specialize:   # asked for explicitly
                         raise
         self._make_views()
-        from . import spaces
-
-        # per-env spaces (gymnasium.vector naming) and the NS observation Dict of base.py:275-292
-        self.single_state_space, self.single_action_space = spaces.base_spaces(self.spec.class_name, self.spec.desc)
-        self.single_observation_space = spaces.ns_observation_space(self.single_state_space, self.param_names)
-        self.observation_space, self.action_space = self.single_observation_space, self.single_action_space
+        self._spaces = None   # built on first use: planning copies are made per simulation and rarely look at them
         self._zero_flags = None
         self._viol_seen = 0
 
@@ -284,6 +279,21 @@ class VecNSEnv:
             info["transition_prob"] = (self.theta if len(self.param_names) == 1 else
                                        {p: self.theta[j * n:(j + 1) * n] for j, p in enumerate(self.param_names)})
         return info
+
+    def _get_spaces(self):
+        """Per-env spaces (gymnasium.vector naming) and the NS observation Dict of base.py:275-292."""
+        if self._spaces is None:
+            from . import spaces
+
+            state, action = spaces.base_spaces(self.spec.class_name, self.spec.desc)
+            self._spaces = (state, action, spaces.ns_observation_space(state, self.param_names))
+        return self._spaces
+
+    single_state_space = property(lambda self: self._get_spaces()[0])
+    single_action_space = property(lambda self: self._get_spaces()[1])
+    single_observation_space = property(lambda self: self._get_spaces()[2])
+    observation_space = property(lambda self: self._get_spaces()[2])
+    action_space = property(lambda self: self._get_spaces()[1])
 
     def host_rows(self) -> dict:
         """Every row except the counter shards as NumPy arrays, fetched with ONE device-to-host copy (synchronises).

@@ -30,7 +30,18 @@ class _Unwrapped:
     """`env.unwrapped.<attr>` of the reference: live view of the base env's attributes."""
 
     def __init__(self, owner: "_NSSingle"):
-        object.__setattr__(self, "_o", owner)
+        import weakref
+
+        # weak: wrapper <-> view must not form a cycle, or a dropped planning copy would wait for the cycle collector
+        # before its device handle is recycled (_NSSingle._copy)
+        object.__setattr__(self, "_ref", weakref.ref(owner))
+
+    @property
+    def _o(self):
+        o = self._ref()
+        if o is None:
+            raise ReferenceError("the wrapper this `unwrapped` view belongs to no longer exists")
+        return o
 
     def __getattr__(self, name):
         o = self._o
@@ -179,16 +190,55 @@ class _NSSingle:
         new.unwrapped = _Unwrapped(new)
         return new
 
+    # Planners in the reference's style deep-copy the env once per simulation and drop the copy (MCTS.py:131,162-181).  A
+    # dropped copy's device handle goes back to a small pool on the root env and the next copy overwrites it in place
+    # (`fork(into=)`: one launch) instead of paying allocation + handle creation + destruction every time.
+    _POOL_MAX = 8
+
+    def _copy(self, theta_mode):
+        import weakref
+
+        src = self._vec
+        root = src._fork_root()
+        pool = root.__dict__.setdefault("_copy_pool", [])
+        vec = pool.pop() if pool else None
+        if vec is not None:
+            src.fork(theta_mode=theta_mode, into=vec)
+        else:
+            vec = src.fork(theta_mode=theta_mode)
+        new = self._wrap(vec)
+        new._recycle = weakref.finalize(new, _NSSingle._give_back, weakref.ref(root), vec)
+        return new
+
+    @staticmethod
+    def _give_back(root_ref, vec):
+        root = root_ref()
+        pool = root.__dict__.get("_copy_pool") if root is not None and getattr(root, "_h", None) else None
+        if pool is not None and len(pool) < _NSSingle._POOL_MAX and getattr(vec, "_h", None):
+            pool.append(vec)
+        else:
+            vec.close()
+
     def get_planning_env(self):
-        """Planning copy (classic_control.py:120-136 / toy_text.py:471-481)."""
+        """Planning copy (classic_control.py:120-136 / toy_text.py:471-481): the current θ if the agent is told the deltas
+        (or this already is a copy), otherwise the initial θ."""
         assert self.has_reset, "The environment must be reset before getting the planning environment."
-        return self._wrap(self._vec.get_planning_env())
+        v = self._vec
+        return self._copy(0 if (v.is_sim_env or v.delta_change_notification) else 1)
 
     def __deepcopy__(self, memo):
         """`deepcopy(env)` sets is_sim_env on the copy (classic_control.py:138-186)."""
-        return self._wrap(self._vec.fork(theta_mode=0))
+        return self._copy(0)
 
     def close(self):
+        fin = getattr(self, "_recycle", None)
+        if fin is not None:    # a copy: its handle returns to the root's pool (or is destroyed if the pool is full), once
+            if fin.alive:
+                fin()
+                self._vec = None   # the handle may already serve another copy: this wrapper must not touch it again
+            return
+        for vec in self._vec.__dict__.pop("_copy_pool", []):
+            vec.close()
         self._vec.close()
 
 

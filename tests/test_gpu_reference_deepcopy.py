@@ -249,3 +249,50 @@ def test_unwrapped_P_equals_the_reference_wrappers_table(name):
             for i, e in enumerate(P[s][a]):
                 assert abs(float(e[0]) - want[s, a, i, 0]) < 1e-15 and int(e[1]) == int(want[s, a, i, 1]), (s, a, i, e)
                 assert float(e[2]) == want[s, a, i, 2] and bool(e[3]) == bool(want[s, a, i, 3]), (s, a, i, e)
+
+
+def test_dropped_copies_are_recycled_and_recycled_copies_behave_like_fresh_ones():
+    """Planner-style use (MCTS.py:131,162-181): one deepcopy per simulation, dropped afterwards.  The dropped copy's device
+    handle is overwritten in place by the next copy; that copy must start from the source's current state exactly like
+    a freshly allocated one, whatever the recycled handle last held."""
+    import copy
+    import gc
+
+    import ns_gym_amd as nsg
+    from ns_gym_amd.schedulers import ContinuousScheduler
+    from ns_gym_amd.update_functions import IncrementUpdate
+    from ns_gym_amd.wrappers import NSClassicControlWrapper
+
+    env = NSClassicControlWrapper(nsg.make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.05)},
+                                  change_notification=True, delta_change_notification=True)
+    env.reset(seed=3)
+    env.step(1)
+    first = copy.deepcopy(env)
+    handle = first._vec
+    for a in (0, 1, 1, 0, 1):          # leave the copy in a different state / time / θ than the source
+        first.step(a)
+    del first
+    gc.collect()
+    for k in range(6):
+        obs, _, term, trunc, _ = env.step(k % 2)
+        if term or trunc:
+            env.reset(seed=10 + k)
+        sim = copy.deepcopy(env)
+        assert sim._vec is handle                      # the recycled handle
+        assert sim.is_sim_env and sim.t == env.t
+        assert sim.unwrapped.masspole == env.unwrapped.masspole
+        assert np.array_equal(sim.unwrapped.state, env.unwrapped.state)
+        o_sim, r_sim, te_sim, tr_sim, _ = sim.step(1)
+        fresh = NSClassicControlWrapper._wrap(env, env._vec.fork(theta_mode=0))   # never pooled
+        o_new, r_new, te_new, tr_new, _ = fresh.step(1)
+        assert np.array_equal(o_sim["state"], o_new["state"]) and (r_sim, te_sim, tr_sim) == (r_new, te_new, tr_new)
+        assert o_sim["relative_time"] == o_new["relative_time"] == env.t + 1
+        fresh._vec.close()
+        del sim, fresh
+        gc.collect()
+    plan = env.get_planning_env()                     # planning copies draw from the same pool
+    assert plan._vec is handle and plan.is_sim_env
+    plan.close()                                      # explicit close recycles too, and only once
+    plan.close()
+    assert copy.deepcopy(env)._vec is handle
+    env.close()
