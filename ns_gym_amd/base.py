@@ -161,4 +161,8 @@ def __getattr__(name):
         from .wrappers import _NSSingle
 
         return _NSSingle
+    if name == "TUNABLE_PARAMS":   # base.py:1156 in the reference; the table lives with the env descriptors here
+        from .envs import TUNABLE_PARAMS
+
+        return TUNABLE_PARAMS
     raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

