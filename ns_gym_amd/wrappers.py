@@ -212,12 +212,15 @@ class _NSSingle:
 
     @staticmethod
     def _give_back(root_ref, vec):
-        root = root_ref()
-        pool = root.__dict__.get("_copy_pool") if root is not None and getattr(root, "_h", None) else None
-        if pool is not None and len(pool) < _NSSingle._POOL_MAX and getattr(vec, "_h", None):
-            pool.append(vec)
-        else:
-            vec.close()
+        try:
+            root = root_ref()
+            pool = root.__dict__.get("_copy_pool") if root is not None and getattr(root, "_h", None) else None
+            if pool is not None and len(pool) < _NSSingle._POOL_MAX and getattr(vec, "_h", None):
+                pool.append(vec)
+            else:
+                vec.close()
+        except Exception:   # interpreter shutdown: the runtime underneath may already be gone
+            pass
 
     def get_planning_env(self):
         """Planning copy (classic_control.py:120-136 / toy_text.py:471-481): the current θ if the agent is told the deltas

@@ -12,7 +12,9 @@ import numpy as np
 import pytest
 
 REFERENCE = os.environ.get("NSG_REFERENCE", "/root/reference")
-pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "ns_gym")), reason="reference tree not present")
+pytestmark = [pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "ns_gym")), reason="reference tree not present"),
+              # the reference's own warning classes cannot be un-pickled by an xdist controller that never imported it
+              pytest.mark.filterwarnings("ignore")]
 
 
 @pytest.fixture(scope="module")
