@@ -411,6 +411,31 @@ class VecNSEnv:
             _lib.check(self.lib.nsg_seed_streams(self._h, d.data_ptr(), 0 if which == "env" else 1, self._stream),
                        "nsg_seed_streams")
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def _signature(self) -> str:
+        import hashlib
+
+        return hashlib.sha1(bytes(self.cfg) + bytes(self.tables) + str(self.N).encode()).hexdigest()
+
+    def state_dict(self, to_cpu: bool = True) -> dict:
+        """Checkpoint of the whole batch.  Every device row - state, θ, t, every PCG64 stream, list cursors, last outputs,
+        counters - is a view into one allocation, so the device state IS that byte string; the host adds the two flags the
+        reference keeps on the wrapper.  (The reference has no env checkpointing; its nearest mechanism, `deepcopy`,
+        deliberately re-seeds the streams: base.py:433-441.)  A restored batch continues bit for bit."""
+        arena = self._arena.cpu() if to_cpu else self._arena.clone()
+        return {"arena": arena, "signature": self._signature(), "has_reset": self.has_reset, "frozen": self.frozen,
+                "viol_seen": self._viol_seen}
+
+    def load_state_dict(self, sd: dict):
+        """Restore a `state_dict()` taken from a batch with the same configuration and size."""
+        if sd.get("signature") != self._signature():
+            raise ValueError("load_state_dict: the checkpoint was taken from a different configuration or batch size")
+        if sd["arena"].numel() != self._arena.numel():
+            raise ValueError("load_state_dict: buffer size mismatch")
+        self._arena.copy_(sd["arena"].to(self.device, non_blocking=False))
+        self.has_reset, self.frozen, self._viol_seen = bool(sd["has_reset"]), bool(sd["frozen"]), int(sd["viol_seen"])
+        return self
+
     def freeze(self, mode: bool = True):
         if not isinstance(mode, bool):
             raise TypeError(f"Expected mode to be a boolean, got {type(mode)}")
