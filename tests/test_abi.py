@@ -68,3 +68,95 @@ def test_errors_do_not_throw_across_the_abi(lib):
     assert lib.nsg_step(None, None, None) != 0
     assert b"NULL" in lib.nsg_last_error()
     assert lib.nsg_destroy(None) == 0
+
+
+def _compiled(env_id, tp, **kw):
+    from ns_gym_amd import make
+    from ns_gym_amd.spec import compile_config
+
+    cfg, tables, _, _ = compile_config(make(env_id), tp, **kw)
+    return cfg, bytes(tables)
+
+
+def _create(lib, cfg, tables, n=64):
+    h = C.c_void_p()
+    rc = lib.nsg_create(C.byref(cfg), tables, len(tables), n, C.byref(h))
+    return rc, lib.nsg_last_error().decode(), h
+
+
+MALFORMED = [
+    ("abi_version", lambda c: setattr(c, "abi_version", A.NSG_ABI_VERSION + 1), "abi_version"),
+    ("env_type", lambda c: setattr(c, "env_type", 99), "env_type"),
+    ("n_params", lambda c: setattr(c, "n_params", 1000), "n_params"),
+    ("theta_slot", lambda c: setattr(c.params[0], "theta_slot", 77), "theta_slot"),
+    ("same slot twice", lambda c: setattr(c.params[1], "theta_slot", c.params[0].theta_slot), "configured twice"),
+    ("update kind", lambda c: setattr(c.params[0], "upd_kind", 9999), "update kind"),
+    ("scheduler kind", lambda c: setattr(c.params[0], "sched_kind", 9999), "scheduler kind"),
+    ("period 0", lambda c: setattr(c.params[1], "sched_i0", 0), "period"),
+    ("uses_rng", lambda c: setattr(c.params[1], "uses_rng", 0), "uses_rng"),
+    ("fn_slot", lambda c: setattr(c.params[0], "fn_slot", 5), "fn_slot"),
+    ("sched_slot", lambda c: setattr(c.params[1], "sched_slot", -3), "sched_slot"),
+]
+
+
+@pytest.mark.parametrize("what,mutate,needle", MALFORMED, ids=[m[0] for m in MALFORMED])
+def test_malformed_configs_are_refused_before_any_device_work(lib, what, mutate, needle):
+    """nsg_create validates the whole config on the host first: every malformed field comes back as NSG_EINVAL with a
+    message that names it - nothing throws, nothing reaches the GPU (this test runs without one)."""
+    from ns_gym_amd.schedulers import ContinuousScheduler, PeriodicScheduler
+    from ns_gym_amd.update_functions import IncrementUpdate, RandomWalk
+
+    cfg, tables = _compiled("CartPole-v1", {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1),
+                                            "gravity": RandomWalk(PeriodicScheduler(period=3))})
+    mutate(cfg)
+    rc, msg, h = _create(lib, cfg, tables)
+    assert rc == -22 and not h.value, (what, rc, msg)
+    assert needle in msg, (what, msg)
+
+
+def test_malformed_grid_and_table_configs_are_refused(lib):
+    from ns_gym_amd.schedulers import ContinuousScheduler, MemorylessScheduler, RandomScheduler
+    from ns_gym_amd.update_functions import CyclicUpdate, DistributionDecrementUpdate, IncrementUpdate
+
+    cfg, tables = _compiled("FrozenLake-v1", {"P": DistributionDecrementUpdate(ContinuousScheduler(), k=0.05)})
+    cfg.nrow = 0
+    rc, msg, _ = _create(lib, cfg, tables)
+    assert rc == -22 and "grid map" in msg
+    cfg, tables = _compiled("FrozenLake-v1", {"P": DistributionDecrementUpdate(ContinuousScheduler(), k=0.05)})
+    cfg.n_params = 2
+    rc, msg, _ = _create(lib, cfg, tables)
+    assert rc == -22 and "exactly one" in msg
+    cfg, tables = _compiled("FrozenLake-v1", {"P": DistributionDecrementUpdate(ContinuousScheduler(), k=0.05)})
+    rc, msg, _ = _create(lib, cfg, tables[:8])          # the map does not fit the blob that was handed over
+    assert rc == -22 and "out of range" in msg
+    cfg, tables = _compiled("CartPole-v1", {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)})
+    cfg.params[0].upd_kind = A.NSG_UPD_D_DECREMENT if hasattr(A, "NSG_UPD_D_DECREMENT") else 9999
+    rc, msg, _ = _create(lib, cfg, tables)
+    assert rc == -22                                     # a distribution update on a scalar parameter
+    cfg, tables = _compiled("CartPole-v1", {"length": CyclicUpdate(ContinuousScheduler(), [0.4, 0.5, 0.6])})
+    cfg.params[0].val_tab_len = 0
+    rc, msg, _ = _create(lib, cfg, tables)
+    assert rc == -22 and "empty cyclic" in msg
+    cfg.params[0].val_tab_len = 1 << 20
+    rc, msg, _ = _create(lib, cfg, tables)
+    assert rc == -22 and "out of range" in msg
+    cfg, tables = _compiled("CartPole-v1", {"masspole": IncrementUpdate(RandomScheduler(probability=0.3, seed=1), k=0.1)})
+    cfg.params[0].sched_p0 = float("nan")
+    rc, msg, _ = _create(lib, cfg, tables)
+    assert rc == -22 and "NaN" in msg
+    cfg, tables = _compiled("CartPole-v1", {"masspole": IncrementUpdate(MemorylessScheduler(p=0.5, seed=1), k=0.1)})
+    cfg.params[0].sched_p0 = 1.5
+    rc, msg, _ = _create(lib, cfg, tables)
+    assert rc == -22 and "Memoryless" in msg
+    # argument-level refusals of the other entry points, still without a device
+    out = C.c_void_p()
+    good, gt = _compiled("CartPole-v1", {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)})
+    assert lib.nsg_create(C.byref(good), gt, len(gt), 0, C.byref(out)) == -22
+    assert lib.nsg_create(C.byref(good), None, 16, 64, C.byref(out)) == -22
+    assert lib.nsg_create(C.byref(good), gt, len(gt), 64, None) == -22
+    assert lib.nsg_rollout(None, None, 4, None, None) == -22
+    assert lib.nsg_fork(None, None, 0, 0, None) == -22
+    assert lib.nsg_step_group(None, 0, None, None) == -22
+    assert lib.nsg_specialize(None) == -22 and lib.nsg_is_specialized(None) == 0
+    assert lib.nsg_seed_streams(None, None, 0, None) == -22
+    assert lib.nsg_compact_done(None, None, None, None) == -22
