@@ -1,0 +1,64 @@
+"""Misuse of the C-ABI with live handles: negative code + message, no exception, no launch, and the handle stays usable."""
+import ctypes as C
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ENOTBOUND, EINVAL = -77, -22   # include/nsgym_hip.h
+
+
+def _handle(lib, cfg, tables, n):
+    h = C.c_void_p()
+    assert lib.nsg_create(C.byref(cfg), tables, len(tables), n, C.byref(h)) == 0, lib.nsg_last_error()
+    return h
+
+
+def test_live_handle_misuse_is_refused_and_harmless():
+    import torch
+
+    from ns_gym_amd import _abi as A
+    from ns_gym_amd import _lib, make
+    from ns_gym_amd.schedulers import ContinuousScheduler
+    from ns_gym_amd.spec import compile_config
+    from ns_gym_amd.update_functions import IncrementUpdate
+    from ns_gym_amd.vec_env import VecNSEnv
+
+    lib = _lib.load()
+    tp = {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)}
+    cfg, tables, _, _ = compile_config(make("CartPole-v1"), tp)
+    tables = bytes(tables)
+    acts = torch.zeros(256, dtype=torch.int32, device="cuda")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    raw = _handle(lib, cfg, tables, 256)            # created, never bound
+    for rc in (lib.nsg_step(raw, acts.data_ptr(), stream), lib.nsg_reset(raw, None, None, stream),
+               lib.nsg_rollout(raw, acts.data_ptr(), 1, None, stream)):
+        assert rc == ENOTBOUND and b"nsg_bind" in lib.nsg_last_error()
+    bufs = A.Buffers()                              # binding without the required rows
+    assert lib.nsg_bind(raw, C.byref(bufs)) == EINVAL and b"required" in lib.nsg_last_error()
+    assert lib.nsg_destroy(raw) == 0
+
+    env = VecNSEnv(make("CartPole-v1"), tp, 256)
+    env.reset(seed=0)
+    h = env._h
+    assert lib.nsg_step(h, None, stream) == EINVAL
+    assert lib.nsg_rollout(h, acts.data_ptr(), 0, None, stream) == EINVAL
+    assert lib.nsg_seed_streams(h, acts.data_ptr(), 7, stream) == EINVAL
+    other = VecNSEnv(make("CartPole-v1"), tp, 256)          # not a planning copy
+    assert lib.nsg_fork(h, other._h, 1, 0, stream) == EINVAL and b"SIM_ENV" in lib.nsg_last_error()
+    copy = env.fork()
+    assert lib.nsg_fork(h, copy._h, 1, 2, stream) == EINVAL and b"theta_mode" in lib.nsg_last_error()
+    small = VecNSEnv(make("CartPole-v1"), tp, 96, is_sim_env=True)
+    assert lib.nsg_fork(h, small._h, 1, 0, stream) == EINVAL and b"whole number" in lib.nsg_last_error()
+    pend = VecNSEnv(make("Pendulum-v1"), {"m": IncrementUpdate(ContinuousScheduler(), k=0.01)}, 256, is_sim_env=True)
+    assert lib.nsg_fork(h, pend._h, 1, 0, stream) == EINVAL and b"same configuration" in lib.nsg_last_error()
+    hs = (C.c_void_p * 2)(h, None)
+    ap = (C.c_void_p * 2)(acts.data_ptr(), acts.data_ptr())
+    assert lib.nsg_step_group(hs, 2, ap, stream) == ENOTBOUND
+    # none of the refused calls launched anything or disturbed the handle
+    before = env.t.clone()
+    env.step(acts)
+    assert torch.equal(env.t, before + 1)
+    for e in (env, other, copy, small, pend):
+        e.close()
