@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Long-horizon parity soak: a BASELINE config stepped T times (tens of thousands of steps, thousands of autoresets per env)
+on the GPU and by the oracle's OpenMP stepper, every compared row checked every `--every` steps.
+    python tools/soak.py --spec c2_cartpole_gravity_rw --n 65536 --steps 20000"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from oracle.oracle import OracleVecEnv
+from ns_gym_amd.vec_env import VecNSEnv
+from tests.util import TRAJ_SPECS, GpuView, OracleView, compare_views, make_env_from_spec
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--spec", default="c2_cartpole_gravity_rw")
+ap.add_argument("--n", type=int, default=65536)
+ap.add_argument("--steps", type=int, default=20000)
+ap.add_argument("--every", type=int, default=1000)
+args = ap.parse_args()
+spec = TRAJ_SPECS[args.spec]
+is_fl = spec["env_id"] == "FrozenLake-v1"
+env = make_env_from_spec(lambda *a, **k: VecNSEnv(*a, **k), spec, n=args.n, track_returns=True, specialize=True)
+orc = make_env_from_spec(OracleVecEnv, spec, n=args.n, track_returns=True)
+seeds = np.arange(args.n, dtype=np.uint64) + np.uint64(777)
+env.reset(seed=seeds)
+orc.reset(seed=seeds)
+g = torch.Generator(device="cuda").manual_seed(3)
+threads = min(16, os.cpu_count() or 1)
+t0 = time.time()
+for k in range(args.steps):
+    a = (torch.rand(args.n, device="cuda", generator=g) * 4 - 2) if env.action_is_float else \
+        torch.randint(0, env.n_actions, (args.n,), dtype=torch.int32, device="cuda", generator=g)
+    env.step(a)
+    orc.step_mt(a.cpu().numpy(), threads)
+    if (k + 1) % args.every == 0 or k == args.steps - 1:
+        compare_views(GpuView(env)._out(), OracleView(orc)._out(), is_fl, f"{args.spec}: step {k}")
+        print(f"step {k + 1}: all {args.n} envs agree ({env.counters()['episodes']:,} episodes so far, {time.time() - t0:.0f} s)", flush=True)
+print("soak ok")
