@@ -20,6 +20,7 @@ ap.add_argument("--spec", default="c2_cartpole_gravity_rw")
 ap.add_argument("--n", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=20000)
 ap.add_argument("--every", type=int, default=1000)
+ap.add_argument("--rollout", type=int, default=0, help="drive the GPU side through nsg_rollout, K fused steps per launch")
 args = ap.parse_args()
 spec = TRAJ_SPECS[args.spec]
 is_fl = spec["env_id"] == "FrozenLake-v1"
@@ -31,12 +32,20 @@ orc.reset(seed=seeds)
 g = torch.Generator(device="cuda").manual_seed(3)
 threads = min(16, os.cpu_count() or 1)
 t0 = time.time()
-for k in range(args.steps):
-    a = (torch.rand(args.n, device="cuda", generator=g) * 4 - 2) if env.action_is_float else \
-        torch.randint(0, env.n_actions, (args.n,), dtype=torch.int32, device="cuda", generator=g)
-    env.step(a)
-    orc.step_mt(a.cpu().numpy(), threads)
-    if (k + 1) % args.every == 0 or k == args.steps - 1:
+K = max(args.rollout, 1)
+for k0 in range(0, args.steps, K):
+    shape = (K, args.n)
+    acts = (torch.rand(shape, device="cuda", generator=g) * 4 - 2) if env.action_is_float else \
+        torch.randint(0, env.n_actions, shape, dtype=torch.int32, device="cuda", generator=g)
+    if args.rollout:
+        env.rollout(acts, record=("reward",))
+    else:
+        env.step(acts[0])
+    host = acts.cpu().numpy()
+    for j in range(K):
+        orc.step_mt(host[j], threads)
+    k = k0 + K - 1
+    if (k + 1) % args.every < K or k >= args.steps - 1:
         compare_views(GpuView(env)._out(), OracleView(orc)._out(), is_fl, f"{args.spec}: step {k}")
         print(f"step {k + 1}: all {args.n} envs agree ({env.counters()['episodes']:,} episodes so far, {time.time() - t0:.0f} s)", flush=True)
 print("soak ok")
