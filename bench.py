@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs-per-gpu", type=int, default=N_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall time of the CPU-baseline sample (default ~10 s)")
     ap.add_argument("--generic", action="store_true",
                     help="time the generic kernels instead of the config-specialised ones (nsg_specialize)")
     args = ap.parse_args()
@@ -215,7 +216,7 @@ def main():
             # timed sample is ~10 s of wall time on the host share (never more than 20 s)
             n_cpu = 1 << 18
             rate, _ = cpu_baseline(n_cpu, 40, threads)
-            steps_cpu = int(min(max(10.0 * rate / n_cpu, 40), 20.0 * rate / n_cpu, 200000))
+            steps_cpu = int(min(max(args.cpu_seconds * rate / n_cpu, 40), 2 * args.cpu_seconds * rate / n_cpu, 200000))
             v, secs = cpu_baseline(n_cpu, steps_cpu, threads)
             out["cpu_baseline"] = {
                 "value": v, "unit": "env-steps/s", "cores": threads, "kind": "port",

@@ -1,0 +1,48 @@
+"""bench.py's output contract, exercised the way the driver calls it: one JSON line on stdout with the agreed keys - as a
+single process, and as two ranks under torch.distributed.run (both on the one GPU of a test box, collectives through
+gloo: the rehearsal mode bench.py documents; the driver's real runs use one GPU per rank and RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline"}
+
+
+def _line(out):
+    lines = [ln for ln in out.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_process_line():
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "60", "--warmup", "10", "--envs-per-gpu", "65536", "--cpu-seconds", "0.5"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert KEYS <= set(d) and "cpu_baseline" in d
+    assert d["n_gpus"] == 1 and d["steps"] == 60 and d["warmup"] == 10 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "env-steps/s" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert abs(d["value"] - 65536 * 60 / (d["ms_per_step"] * 60 / 1e3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - 120 * 65536 / (r["avg_launch_us"] * 1e-6) / 1e9) / r["achieved"] < 1e-6
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and "workload" in d["config"]
+
+
+def test_two_ranks_aggregate_line():
+    env = dict(os.environ, NSG_BENCH_SINGLE_DEVICE="1", NSG_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29571", "bench.py", "--gpus", "2", "--steps", "60", "--warmup", "10", "--envs-per-gpu", "65536"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert KEYS <= set(d) and "cpu_baseline" not in d            # the CPU leg runs on rank 0 of an N = 1 run only
+    assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 2 * 65536 and d["config"]["gathered_returns"] == 2 * 65536
+    assert abs(d["value"] - 2 * 65536 * 60 / (d["ms_per_step"] * 60 / 1e3)) / d["value"] < 1e-6   # whole-job aggregate
