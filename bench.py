@@ -121,7 +121,7 @@ def main():
     for k in range(args.warmup):
         env.step(pool[k % 8])
     if dist is not None:
-        all_gather_returns(env)  # warm the RCCL communicator
+        all_gather_returns(env, sizes=[n] * world)  # warm the RCCL communicator
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -132,7 +132,7 @@ def main():
     for k in range(args.steps):
         env.step(pool[k % 8])
     e1.record()
-    gathered = all_gather_returns(env) if dist is not None else env.episode_returns()[0]
+    gathered = all_gather_returns(env, sizes=[n] * world) if dist is not None else env.episode_returns()[0]
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()

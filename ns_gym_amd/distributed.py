@@ -24,19 +24,21 @@ def shard_seeds(base_seed: int, total_envs: int, rank: int, world: int):
     return np.arange(lo, hi, dtype=np.uint64) + np.uint64(base_seed)
 
 
-def all_gather_returns(env, group=None) -> torch.Tensor:
-    """All-gather of the last finished episode return of every env (one collective, 4 B/env)."""
+def all_gather_returns(env, group=None, sizes=None) -> torch.Tensor:
+    """All-gather of the last finished episode return of every env (one collective, 4 B/env).  `sizes`: the per-rank
+    shard sizes when the caller knows them (e.g. `shard_range` for every rank) - otherwise they are exchanged first."""
     import torch.distributed as dist
 
     local = env.episode_returns()[0]
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
-    sizes = [None] * world
-    n_local = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
-    all_n = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(all_n, n_local, group=group)
-    sizes = [int(x.item()) for x in all_n]
+    if sizes is None:
+        n_local = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+        all_n = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(all_n, n_local, group=group)
+        sizes = [int(x.item()) for x in all_n]
+    assert len(sizes) == world and sizes[dist.get_rank(group)] == local.numel()
     if len(set(sizes)) == 1:
         out = torch.empty(world * sizes[0], dtype=local.dtype, device=local.device)
         if dist.get_backend(group) == "gloo":   # gloo has no all_gather_into_tensor for device tensors
