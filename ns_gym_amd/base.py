@@ -13,7 +13,6 @@ from typing import Any, Union
 
 import numpy as np
 
-from . import _abi as A
 
 
 @dataclass(frozen=True)

@@ -13,7 +13,7 @@ import math
 import numpy as np
 
 from . import _abi as A
-from .base import Scheduler, TableBuilder, UpdateDistributionFn, UpdateFn
+from .base import TableBuilder, UpdateDistributionFn, UpdateFn
 from .envs import BaseEnvSpec, from_gym_env
 
 _INF = "inf"

@@ -17,7 +17,6 @@ from typing import Any, Union
 import numpy as np
 import torch
 
-from . import _abi as A
 from .base import Reward
 from .envs import BaseEnvSpec, from_gym_env
 from .vec_env import ConstraintViolationWarning, VecNSEnv
