@@ -367,8 +367,10 @@ int nsg_calib_copy_f64(const double* src_dev, double* dst_dev, int64_t n, void* 
  * on it at run time — the device-side equivalent of the reference's per-step Python dispatch over
  * Scheduler / UpdateFn objects (ns_gym/base.py:124-149, classic_control.py:60-100).  nsg_specialize()
  * compiles the SAME kernel bodies with the handle's nsg_config as a compile-time constant (hiprtc,
- * sources embedded in the library, ~2-3 s once per distinct config per process; NSG_SPEC_CACHE=<dir>
- * keeps the code objects on disk) and routes nsg_step / nsg_rollout of this handle through them.
+ * sources embedded in the library, ~1 s once per distinct config; the code objects persist in
+ * NSG_SPEC_CACHE=<dir>, by default $XDG_CACHE_HOME/ns_gym_amd or $HOME/.cache/ns_gym_amd, "off" for none,
+ * keyed by config, kernel sources, compile options and HIP version; an unusable cached object is rebuilt)
+ * and routes nsg_step / nsg_rollout of this handle through them.
  * Results are bit-identical to the generic kernels.  Returns NSG_EUNSUPPORTED (generic path stays in
  * force) when libhiprtc is missing or the compilation fails.
  * nsg_spec_build compiles only (no GPU needed; arch e.g. "gfx950"): *code_out is a malloc'ed code

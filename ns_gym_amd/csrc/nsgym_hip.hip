@@ -1,6 +1,7 @@
 // nsgym_hip.hip — C-ABI host side of libnsgym_hip.so (see include/nsgym_hip.h).
 // Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
 #include <hip/hip_runtime.h>
+#include <sys/stat.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -130,15 +131,44 @@ struct nsg_handle {
 
 namespace {
 
+#define NSG_STR2(x) #x
+#define NSG_STR(x) NSG_STR2(x)
+#define HIP_VERSION_STR NSG_STR(HIP_VERSION_MAJOR) "." NSG_STR(HIP_VERSION_MINOR) "." NSG_STR(HIP_VERSION_PATCH)
+
 uint64_t spec_source_hash() {
   uint64_t h1 = 0x9e3779b97f4a7c15ull;
   for (const char* src : {nsg_src_abi, nsg_src_math, nsg_src_rng, nsg_src_theta, nsg_src_envs, nsg_src_kernels, nsg_src_rollout})
     h1 = nsg_spec::fnv1a(src, strlen(src), h1);
   if (const char* e = getenv("NSG_SPEC_FLAGS")) h1 = nsg_spec::fnv1a(e, strlen(e), h1);  // extra compile options are part of the key
+  // so are the fixed options of nsg_spec::compile_source (keep this literal in step with them) and the toolchain the
+  // library was built with: code objects persist on disk between processes (spec_cache_dir)
+  static const char kFixed[] = "-O3 -std=c++17 -ffp-contract=off -Wno-unused-function hip " HIP_VERSION_STR;
+  h1 = nsg_spec::fnv1a(kFixed, sizeof(kFixed), h1);
   return h1;
 }
 
-// Look a code object up in the process cache, then in NSG_SPEC_CACHE=<dir>, else compile it; load it.
+// Where compiled units persist between processes: NSG_SPEC_CACHE=<dir>, or "off" / "0" / "" for none; unset = the user's
+// cache directory ($XDG_CACHE_HOME or $HOME/.cache)/ns_gym_amd.  Created on demand; any failure just means no disk cache.
+std::string spec_cache_dir() {
+  std::string dir;
+  if (const char* e = getenv("NSG_SPEC_CACHE")) {
+    if (!*e || !strcmp(e, "off") || !strcmp(e, "0")) return "";
+    dir = e;
+  } else if (const char* x = getenv("XDG_CACHE_HOME")) {
+    if (*x) dir = std::string(x) + "/ns_gym_amd";
+  }
+  if (dir.empty()) {
+    const char* home = getenv("HOME");
+    if (!home || !*home) return "";
+    dir = std::string(home) + "/.cache";
+    (void)mkdir(dir.c_str(), 0755);
+    dir += "/ns_gym_amd";
+  }
+  (void)mkdir(dir.c_str(), 0755);
+  return dir;
+}
+
+// Look a code object up in the process cache, then in the disk cache (spec_cache_dir), else compile it; load it.
 template <typename Compile>
 int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, const nsg_spec::Module** out) {
   const uint64_t h1 = spec_source_hash();
@@ -149,10 +179,11 @@ int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, cons
   if (it == cache.end()) {
     std::vector<char> code;
     std::string path;
-    if (const char* dir = getenv("NSG_SPEC_CACHE")) {
+    const std::string dir = spec_cache_dir();
+    if (!dir.empty()) {
       char name[64];
       snprintf(name, sizeof(name), "/nsg_%016llx_%016llx.hsaco", (unsigned long long)h0, (unsigned long long)h1);
-      path = std::string(dir) + name;
+      path = dir + name;
       if (FILE* f = fopen(path.c_str(), "rb")) {
         fseek(f, 0, SEEK_END);
         const long n = ftell(f);
@@ -164,22 +195,37 @@ int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, cons
         fclose(f);
       }
     }
+    auto store = [&]() {  // through a temporary file + rename: concurrent processes (one per GPU) never see a partial object
+      if (path.empty()) return;
+      const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+      if (FILE* f = fopen(tmp.c_str(), "wb")) {
+        const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+        fclose(f);
+        if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
+      }
+    };
+    bool compiled_now = false;
     if (code.empty()) {
       std::string err;
       code = compile(err);
       if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
-      if (!path.empty()) {
-        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-        if (FILE* f = fopen(tmp.c_str(), "wb")) {
-          const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
-          fclose(f);
-          if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
-        }
-      }
+      compiled_now = true;
+      store();
     }
     nsg_spec::Module m;
     m.h0 = h0;
-    HIP_TRY(hipModuleLoadData(&m.mod, code.data()));
+    const bool from_disk = !code.empty() && !path.empty() && !compiled_now;
+    hipError_t le = hipModuleLoadData(&m.mod, code.data());
+    if (le != hipSuccess && from_disk) {  // an unusable cached object (other GPU generation, damaged file): rebuild it
+      (void)hipGetLastError();
+      remove(path.c_str());
+      std::string err;
+      code = compile(err);
+      if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
+      store();
+      le = hipModuleLoadData(&m.mod, code.data());
+    }
+    if (le != hipSuccess) return fail(NSG_EHIP, "hipModuleLoadData: %s", hipGetErrorString(le));
     if (group) {
       HIP_TRY(hipModuleGetFunction(&m.group, m.mod, "nsg_spec_group"));
     } else {

@@ -49,7 +49,7 @@ class VecNSEnv:
                  violation_mask: bool = False, specialize: bool | None = None,
                  **kwargs):
         """`specialize=True` compiles config-specialised step / rollout kernels for this batch (hiprtc, once per
-        distinct configuration per process, ~0.6 s; `NSG_SPEC_CACHE=<dir>` keeps them on disk): same results bit
+        distinct configuration, ~0.6 s; the code objects persist in `NSG_SPEC_CACHE=<dir>`, default the user's cache directory): same results bit
         for bit, 10-35 % less time per step.  `False`: the precompiled generic kernels.  `None` (default): specialise
         batches of >= 65 536 envs when the runtime compiler is available, silently stay generic otherwise."""
         self.lib = _lib.load()

@@ -131,6 +131,39 @@ def test_code_objects_are_shared_and_cached_on_disk(tmp_path, monkeypatch):
     a.close(); b.close()
 
 
+def test_default_cache_directory_off_switch_and_damaged_objects(tmp_path, monkeypatch):
+    """Unset NSG_SPEC_CACHE = the user's cache directory; "off" = no disk cache; a cached object that does not load
+    (damaged file, other GPU generation) is rebuilt in place instead of failing the handle."""
+    import os
+    import subprocess
+    import sys
+
+    spec = TRAJ_SPECS["c4_pendulum_m_inc"]
+    cache = tmp_path / "ns_gym_amd"
+    monkeypatch.delenv("NSG_SPEC_CACHE", raising=False)
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path))
+    monkeypatch.setenv("NSG_SPEC_FLAGS", "-DNSG_TEST_CACHE_KEY=2")
+    # another process builds the unit first: this process then has to find it on disk
+    child = ("from tests.util import TRAJ_SPECS, make_env_from_spec\n"
+             "from ns_gym_amd.vec_env import VecNSEnv\n"
+             "e = make_env_from_spec(lambda *a, **k: VecNSEnv(*a, **k), TRAJ_SPECS['c4_pendulum_m_inc'], n=256, specialize=True)\n"
+             "assert e.specialized\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", child], cwd=root, check=True, env=dict(os.environ), timeout=300)
+    files = list(cache.glob("nsg_*.hsaco"))
+    assert len(files) == 1 and files[0].stat().st_size > 4096
+    files[0].write_bytes(b"not a code object " * 64)               # damaged on disk
+    a = make_env_from_spec(_vec, spec, n=256, specialize=True)      # same key: found, does not load, rebuilt
+    assert a.specialized
+    assert files[0].stat().st_size > 4096 and not files[0].read_bytes().startswith(b"not a code object")
+    a.close()
+    monkeypatch.setenv("NSG_SPEC_CACHE", "off")
+    monkeypatch.setenv("NSG_SPEC_FLAGS", "-DNSG_TEST_CACHE_KEY=3")
+    b = make_env_from_spec(_vec, spec, n=256, specialize=True)
+    assert b.specialized and len(list(cache.glob("nsg_*.hsaco"))) == 1      # nothing new on disk
+    b.close()
+
+
 def test_specialised_group_launch_equals_generic_group_launch():
     """nsg_step_group over specialised members runs ONE unit compiled for the ordered tuple of their
     configs (BASELINE C4: Pendulum + Acrobot, plus a FrozenLake and a full-engine CartPole segment)."""
