@@ -831,7 +831,7 @@ __device__ __forceinline__ void step_block(const nsg_config& cfg, const nsg_buff
 // kernels, scalar loads) or a compile-time constant of a config-specialised build (nsg_spec.hip.h).
 template <int ENV, bool FULL>
 __device__ __forceinline__ void step_body(const nsg_config& cfg, const Segment& sg, const void* __restrict__ actions,
-                                          const int block_rel, const int block_count) {
+                                          const int block_rel, const int block_count, const int reverse = 0) {
   LdsTables lds;
   Tables tb;
   ZigLds zg;
@@ -842,14 +842,23 @@ __device__ __forceinline__ void step_body(const nsg_config& cfg, const Segment& 
   const StepOut out = default_out(b);
   const int64_t chunks = (N + kBlock - 1) / kBlock;
   int parity = 0;
-  for (int64_t c = block_rel; c < chunks; c += block_count, parity ^= 1)
-    step_block<ENV, FULL>(cfg, b, N, tb, zg, actions, out, c * kBlock, parity, lds, wc);
+  // XCD-aware traversal.  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so chunk c is always
+  // stepped by XCD c mod 8 - and what a launch wrote last is what those L2s still hold when the next launch starts.
+  // Every other launch (`reverse`, nsg_step alternates it per handle) therefore walks the groups of 8 chunks back to
+  // front, each chunk staying on its XCD: the state rows it reads first are the ones the previous launch wrote last.
+  // Measured at 2^20 envs: C1 26.4 -> 25.0 us, C2 35.5 -> 33.4, C3 22.4 -> 20.1, Pendulum 20.8 -> 20.1, Acrobot 61.5 -> 59.5.
+  // (A ragged tail of fewer than 8 chunks keeps its place.)  Results do not depend on the order.
+  const int64_t groups = chunks >> 3;
+  for (int64_t c = block_rel; c < chunks; c += block_count, parity ^= 1) {
+    const int64_t ce = (reverse && (c >> 3) < groups) ? ((groups - 1 - (c >> 3)) << 3) + (c & 7) : c;
+    step_block<ENV, FULL>(cfg, b, N, tb, zg, actions, out, ce * kBlock, parity, lds, wc);
+  }
   flush_counts(b.counters, block_rel, wc);
 }
 
 template <int ENV, bool FULL>
-__global__ __launch_bounds__(kBlock, NSG_MIN_WAVES) void step_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions) {
-  step_body<ENV, FULL>(seg->cfg, *seg, actions, (int)blockIdx.x, (int)gridDim.x);
+__global__ __launch_bounds__(kBlock, NSG_MIN_WAVES) void step_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions, int reverse) {
+  step_body<ENV, FULL>(seg->cfg, *seg, actions, (int)blockIdx.x, (int)gridDim.x, reverse);
 }
 
 // Heterogeneous launch: block ranges are assigned to env-type segments, so the env-type switch
@@ -862,20 +871,20 @@ __device__ __forceinline__ int group_segment_of_block(const Segment* __restrict_
 }
 
 template <bool FULL>
-__global__ __launch_bounds__(kBlock) void step_group_kernel(const Segment* __restrict__ segs, int nseg, ActionPtrs acts) {
+__global__ __launch_bounds__(kBlock) void step_group_kernel(const Segment* __restrict__ segs, int nseg, ActionPtrs acts, int reverse) {
   const int sidx = group_segment_of_block(segs, nseg);
   const Segment& sg = segs[sidx];
   const void* actions = acts.p[sidx];
   const int rel = (int)blockIdx.x - sg.block_begin;
   switch (sg.cfg.env_type) {
-    case NSG_ENV_CARTPOLE: step_body<NSG_ENV_CARTPOLE, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
-    case NSG_ENV_PENDULUM: step_body<NSG_ENV_PENDULUM, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
-    case NSG_ENV_ACROBOT: step_body<NSG_ENV_ACROBOT, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
-    case NSG_ENV_MOUNTAINCAR: step_body<NSG_ENV_MOUNTAINCAR, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
-    case NSG_ENV_MOUNTAINCAR_CONT: step_body<NSG_ENV_MOUNTAINCAR_CONT, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
-    case NSG_ENV_FROZENLAKE: step_body<NSG_ENV_FROZENLAKE, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
-    case NSG_ENV_CLIFFWALKING: step_body<NSG_ENV_CLIFFWALKING, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
-    default: step_body<NSG_ENV_BRIDGE, FULL>(sg.cfg, sg, actions, rel, sg.block_count); break;
+    case NSG_ENV_CARTPOLE: step_body<NSG_ENV_CARTPOLE, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
+    case NSG_ENV_PENDULUM: step_body<NSG_ENV_PENDULUM, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
+    case NSG_ENV_ACROBOT: step_body<NSG_ENV_ACROBOT, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
+    case NSG_ENV_MOUNTAINCAR: step_body<NSG_ENV_MOUNTAINCAR, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
+    case NSG_ENV_MOUNTAINCAR_CONT: step_body<NSG_ENV_MOUNTAINCAR_CONT, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
+    case NSG_ENV_FROZENLAKE: step_body<NSG_ENV_FROZENLAKE, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
+    case NSG_ENV_CLIFFWALKING: step_body<NSG_ENV_CLIFFWALKING, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
+    default: step_body<NSG_ENV_BRIDGE, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
   }
 }
 

@@ -104,8 +104,8 @@ inline std::string spec_source(const nsg_config& cfg, bool full) {
   const std::string targs = buf;
   s += "#define NSG_SPEC_CFG (*reinterpret_cast<const nsg_config*>(nsg::kCfgWords))\n"
        "extern \"C\" __global__ __launch_bounds__(256) void nsg_spec_step(const nsg::Segment* __restrict__ seg,\n"
-       "                                                                const void* __restrict__ actions) {\n"
-       "  nsg::step_body<" + targs + ">(NSG_SPEC_CFG, *seg, actions, (int)blockIdx.x, (int)gridDim.x);\n"
+       "                                                                const void* __restrict__ actions, int reverse) {\n"
+       "  nsg::step_body<" + targs + ">(NSG_SPEC_CFG, *seg, actions, (int)blockIdx.x, (int)gridDim.x, reverse);\n"
        "}\n"
        "extern \"C\" __global__ __launch_bounds__(256) void nsg_spec_rollout(const nsg::Segment* __restrict__ seg,\n"
        "                                                                   const void* __restrict__ actions, int k_steps,\n"
@@ -142,7 +142,7 @@ inline std::string group_source(const nsg_config* const* cfgs, const bool* full,
   for (int k = 0; k < n; k++) emit_cfg_words(s, *cfgs[k], k);
   s += "}  // namespace nsg\n"
        "extern \"C\" __global__ __launch_bounds__(256) void nsg_spec_group(const nsg::Segment* __restrict__ segs, int nseg,\n"
-       "                                                                 nsg::ActionPtrs acts) {\n"
+       "                                                                 nsg::ActionPtrs acts, int reverse) {\n"
        "  const int sidx = nsg::group_segment_of_block(segs, nseg);\n"
        "  const nsg::Segment& sg = segs[sidx];\n"
        "  const int rel = (int)blockIdx.x - sg.block_begin;\n"
@@ -151,7 +151,7 @@ inline std::string group_source(const nsg_config* const* cfgs, const bool* full,
   for (int k = 0; k < n; k++) {
     snprintf(buf, sizeof(buf),
              "    case %d: nsg::step_body<%d, %s>(*reinterpret_cast<const nsg_config*>(nsg::kCfgWords%d), sg, acts.p[%d], rel, "
-             "sg.block_count); break;\n",
+             "sg.block_count, reverse); break;\n",
              k, (int)cfgs[k]->env_type, full[k] ? "true" : "false", k, k);
     s += buf;
   }

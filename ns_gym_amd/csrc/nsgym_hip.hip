@@ -127,6 +127,7 @@ struct nsg_handle {
   bool bound;
   int device;
   const nsg_spec::Module* spec;  // config-specialised step / rollout kernels (nsg_specialize), or NULL
+  unsigned launches = 0;
 };
 
 namespace {
@@ -404,6 +405,13 @@ int nsg_reset(nsg_handle* h, const uint64_t* seeds_dev, const uint8_t* mask_dev,
   return NSG_OK;
 }
 
+// Every other step launch of a handle walks its chunks back to front (step_body: the previous launch's last writes are
+// still in the XCDs' L2s).  NSG_ALT_ORDER=0 keeps every launch front to back.
+static int next_traversal(nsg_handle* h) {
+  static const bool alternate = [] { const char* e = getenv("NSG_ALT_ORDER"); return !(e && e[0] == '0'); }();
+  return alternate ? (int)(h->launches++ & 1u) : 0;
+}
+
 int nsg_step(nsg_handle* h, const void* actions_dev, void* stream) {
   if (!h) return fail(NSG_EINVAL, "handle is NULL");
   if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
@@ -411,15 +419,16 @@ int nsg_step(nsg_handle* h, const void* actions_dev, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int grid = grid_for(h->n);
   const size_t lds = (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp);
+  int reverse = next_traversal(h);
   if (h->spec) {
-    void* args[] = {(void*)&h->dev, (void*)&actions_dev};
+    void* args[] = {(void*)&h->dev, (void*)&actions_dev, (void*)&reverse};
     HIP_TRY(hipModuleLaunchKernel(h->spec->step, grid, 1, 1, kBlock, 1, 1, (unsigned)lds, s, args, nullptr));
   } else if (h->host.simple_theta) {
     DISPATCH_ENV(h->host.cfg.env_type,
-                 hipLaunchKernelGGL((step_kernel<E, false>), dim3(grid), dim3(kBlock), lds, s, h->dev, actions_dev));
+                 hipLaunchKernelGGL((step_kernel<E, false>), dim3(grid), dim3(kBlock), lds, s, h->dev, actions_dev, reverse));
   } else {
     DISPATCH_ENV(h->host.cfg.env_type,
-                 hipLaunchKernelGGL((step_kernel<E, true>), dim3(grid), dim3(kBlock), lds, s, h->dev, actions_dev));
+                 hipLaunchKernelGGL((step_kernel<E, true>), dim3(grid), dim3(kBlock), lds, s, h->dev, actions_dev, reverse));
   }
   HIP_TRY(hipGetLastError());
   return NSG_OK;
@@ -541,11 +550,12 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
     if (!actions_dev[k]) return fail(NSG_EINVAL, "actions_dev[%d] is NULL", k);
     ap.p[k] = actions_dev[k];
   }
+  int reverse = next_traversal(hs[0]);   // the members of a group alternate together
   if (group_spec) {
-    void* args[] = {(void*)&d_group, (void*)&n_handles, (void*)&ap};
+    void* args[] = {(void*)&d_group, (void*)&n_handles, (void*)&ap, (void*)&reverse};
     HIP_TRY(hipModuleLaunchKernel(group_spec->group, total_blocks, 1, 1, kBlock, 1, 1, (unsigned)group_lds, (hipStream_t)stream, args, nullptr));
-  } else if (all_simple) hipLaunchKernelGGL(step_group_kernel<false>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, d_group, n_handles, ap);
-  else hipLaunchKernelGGL(step_group_kernel<true>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, d_group, n_handles, ap);
+  } else if (all_simple) hipLaunchKernelGGL(step_group_kernel<false>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, d_group, n_handles, ap, reverse);
+  else hipLaunchKernelGGL(step_group_kernel<true>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, d_group, n_handles, ap, reverse);
   HIP_TRY(hipGetLastError());
   return NSG_OK;
 }
