@@ -405,8 +405,8 @@ int nsg_reset(nsg_handle* h, const uint64_t* seeds_dev, const uint8_t* mask_dev,
   return NSG_OK;
 }
 
-// Every other step launch of a handle walks its chunks back to front (step_body: the previous launch's last writes are
-// still in the XCDs' L2s).  NSG_ALT_ORDER=0 keeps every launch front to back.
+// Every other step launch of a handle walks its chunks back to front (step_body: it starts with the rows the previous
+// launch wrote last).  NSG_ALT_ORDER=0 keeps every launch front to back.
 static int next_traversal(nsg_handle* h) {
   static const bool alternate = [] { const char* e = getenv("NSG_ALT_ORDER"); return !(e && e[0] == '0'); }();
   return alternate ? (int)(h->launches++ & 1u) : 0;
