@@ -849,7 +849,7 @@ __device__ __forceinline__ void step_body(const nsg_config& cfg, const Segment& 
   // 2^20 envs, same box, three interleaved repetitions: C1 26.4 -> 25.0 us, C2 35.5 -> 33.4, C3 22.4 -> 20.1, Pendulum
   // 20.8 -> 20.1, Acrobot 61.5 -> 59.5 (generic kernels alike).  The XCD is what matters: a plain reversal (chunk c ->
   // chunks-1-c, which moves every chunk to another XCD) is SLOWER than no reversal at all - C1 27.3 vs 26.6 us, C3 22.5 vs
-  // 22.4 - so it is the per-XCD L2, not the memory-side Infinity Cache.  A ragged tail of fewer than 8 chunks keeps its
+  // 22.4 - so the effect is local to the XCD (its L2), not the memory-side Infinity Cache.  A ragged tail of fewer than 8 chunks keeps its
   // place.  Results do not depend on the order.
   const int64_t groups = chunks >> 3;
   for (int64_t c = block_rel; c < chunks; c += block_count, parity ^= 1) {
