@@ -842,14 +842,14 @@ __device__ __forceinline__ void step_body(const nsg_config& cfg, const Segment& 
   const StepOut out = default_out(b);
   const int64_t chunks = (N + kBlock - 1) / kBlock;
   int parity = 0;
-  // XCD-aware traversal.  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB L2, so chunk c is always
-  // stepped by XCD c mod 8 - and what a launch wrote last is what that XCD's L2 still holds when the next launch starts.
+  // XCD-aware traversal.  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2 and translation caches, so chunk c is
+  // always stepped by XCD c mod 8 - and what a launch touched last is what that XCD has warmest when the next launch starts.
   // Every other launch (`reverse`, nsg_step alternates it per handle) therefore walks the groups of 8 chunks back to front,
   // each chunk STAYING ON ITS XCD: the state rows it reads first are the ones the previous launch wrote last.  Measured at
   // 2^20 envs, same box, three interleaved repetitions: C1 26.4 -> 25.0 us, C2 35.5 -> 33.4, C3 22.4 -> 20.1, Pendulum
   // 20.8 -> 20.1, Acrobot 61.5 -> 59.5 (generic kernels alike).  The XCD is what matters: a plain reversal (chunk c ->
   // chunks-1-c, which moves every chunk to another XCD) is SLOWER than no reversal at all - C1 27.3 vs 26.6 us, C3 22.5 vs
-  // 22.4 - so the effect is local to the XCD (its L2), not the memory-side Infinity Cache.  A ragged tail of fewer than 8 chunks keeps its
+  // 22.4 - so the effect is local to the XCD, not the memory-side Infinity Cache (L2 hit / miss counters do not move: DESIGN.md section 4).  A ragged tail of fewer than 8 chunks keeps its
   // place.  Results do not depend on the order.
   const int64_t groups = chunks >> 3;
   for (int64_t c = block_rel; c < chunks; c += block_count, parity ^= 1) {
