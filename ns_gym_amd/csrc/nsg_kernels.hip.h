@@ -218,7 +218,13 @@ struct IoMode {  // wave-uniform
   bool store;  // write them back
   bool dirty;  // the LaneState's θ rows 0/1 may differ from memory (earlier fused steps did not store)
   bool lds_rng;  // the chunk's env PCG64 records are in LDS (fused rollouts): the reset hand-over has no global round trip
+  bool wt = false;  // single-step launches (nsg_step): persistent rows of the grid envs / Pendulum state leave through
+                    // agent-scope stores (stg_wt); fused rollouts keep plain stores (C3 rollout: 12.3 vs 14.6 us per step)
 };
+template <typename T> __device__ __forceinline__ void stg_p(bool wt, T* base, uint32_t byte_off, T v) {
+  if (wt) stg_wt(base, byte_off, v);
+  else stg(base, byte_off, v);
+}
 
 // Fire predicate of param p of env i.  Deterministic schedulers are pure functions of t; the
 // stochastic ones (FULL builds) advance their own PCG64 record and, for Memoryless, transition_time.
@@ -524,7 +530,12 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   if (active) {  // every row is written by its owner lane: fully coalesced stores
     if (io.store) {
 #pragma unroll
-      for (int k = 0; k < T::PHYS; k++) stg(b.phys, blk_off8(T::PHYS, k, i), s[k]);
+      for (int k = 0; k < T::PHYS; k++) {
+        // agent-scope (write-through) stores of the integrator state pay for Pendulum only (19.5 -> 18.8 us; CartPole and
+        // its full engine: +1 %), like for the grid envs' rows (nsg_rng.hip.h, stg_wt)
+        if constexpr (ENV == NSG_ENV_PENDULUM) stg_p(io.wt, b.phys, blk_off8(T::PHYS, k, i), s[k]);
+        else stg(b.phys, blk_off8(T::PHYS, k, i), s[k]);
+      }
     }
     float o[T::OBS];
     env_obs<ENV>(s, o);
@@ -669,13 +680,13 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, ur);
       upd_dist<ND, FULL>(pc, tb, zg, pp, t, cursor, ur, q);
       if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, ur);
-      if (has_cur && pc.upd_kind != NSG_UPD_D_LCBOUNDED) stg(b.cursor + (int64_t)pc.fn_slot * N, o4, cursor);
+      if (has_cur && pc.upd_kind != NSG_UPD_D_LCBOUNDED) stg_p(io.wt, b.cursor + (int64_t)pc.fn_slot * N, o4, cursor);
       delta = w1_n<ND>(pp, q);  // base.py:192-203
 #pragma unroll
       for (int k = 0; k < ND; k++) {
-        stg(b.theta + (int64_t)(p * ND + k) * N, o8, q[k]);
+        stg_p(io.wt, b.theta + (int64_t)(p * ND + k) * N, o8, q[k]);
         if constexpr (ENV != NSG_ENV_BRIDGE) {  // P re-weighted on a fire only
-          stg(b.table_prob, blk_off8(ND, k, i), q[k]);
+          stg_p(io.wt, b.table_prob, blk_off8(ND, k, i), q[k]);
           gl.tp[k] = q[k];
         }
       }
@@ -694,12 +705,12 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       }
     }
     if (pc.upd_kind == NSG_UPD_D_LCBOUNDED && do_step && theta_live)
-      stg(b.cursor + (int64_t)pc.fn_slot * N, o4, t + 1);  // UpdateFn.__call__ records prev_time = t, fired or not (base.py:143-148)
+      stg_p(io.wt, b.cursor + (int64_t)pc.fn_slot * N, o4, t + 1);  // UpdateFn.__call__ records prev_time = t, fired or not (base.py:143-148)
     if (do_reset && !persistent) {  // toy_text.py:206-209, 394-399, 657-666 (the P TABLE is not restored)
       const double* ini = grid_initial(cfg, p);
 #pragma unroll
-      for (int k = 0; k < ND; k++) stg(b.theta + (int64_t)(p * ND + k) * N, o8, ini[k]);
-      if (upd_uses_cursor(pc.upd_kind)) stg(b.cursor + (int64_t)pc.fn_slot * N, o4, 0);
+      for (int k = 0; k < ND; k++) stg_p(io.wt, b.theta + (int64_t)(p * ND + k) * N, o8, ini[k]);
+      if (upd_uses_cursor(pc.upd_kind)) stg_p(io.wt, b.cursor + (int64_t)pc.fn_slot * N, o4, 0);
       if (FULL && pc.upd_kind == NSG_UPD_D_LCBOUNDED && pc.uses_rng) {  // inner sampler rewound with the deepcopy
         Pcg r;
         if (pc.has_fn_seed) pcg_seed(r, pc.fn_seed, -1);
@@ -775,7 +786,7 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
     tnew = t + 1;
     trunc = cfg.max_episode_steps > 0 && (tnew - (sim ? ldg(b.t_fork, o4) : 0)) >= cfg.max_episode_steps;
   } else if (do_reset) {
-    if (sim) stg(b.t_fork, o4, 0);
+    if (sim) stg_p(io.wt, b.t_fork, o4, 0);
     cell = grid_start_state(cfg, desc);
   }
   const bool done = term || trunc;
@@ -790,19 +801,19 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
     if (track) {
       float er = return_is_last_reward ? (float)reward : do_reset ? 0.f : gl.er + (float)reward;
       if (done) {
-        stg(b.last_return, o4, er);
-        stg(b.last_length, o4, tnew);
+        stg_p(io.wt, b.last_return, o4, er);
+        stg_p(io.wt, b.last_length, o4, tnew);
         er = 0.f;
       }
       gl.er = er;
     }
     if (io.store) {  // last step of a launch: the persistent rows go back to memory
-      stg(b.cell, o4, cell);
-      stg(b.t, o4, tnew);
-      stg(b.status, o1, (uint8_t)gl.st);
-      if (b.prob) stg(b.prob, o4, (float)prob);
-      if (track && !return_is_last_reward) stg(b.ep_return, o4, gl.er);
-      pcg_store_state<true>(b.rng_env, N, i, gl.g);
+      stg_p(io.wt, b.cell, o4, (int32_t)cell);
+      stg_p(io.wt, b.t, o4, (int32_t)tnew);
+      stg_p(io.wt, b.status, o1, (uint8_t)gl.st);
+      if (b.prob) stg_p(io.wt, b.prob, o4, (float)prob);
+      if (track && !return_is_last_reward) stg_p(io.wt, b.ep_return, o4, gl.er);
+      if (io.wt) pcg_store_state<true, true>(b.rng_env, N, i, gl.g); else pcg_store_state<true>(b.rng_env, N, i, gl.g);
     }
   }
   const unsigned long long done_mask = __ballot(done);
@@ -820,10 +831,10 @@ __device__ __forceinline__ void step_block(const nsg_config& cfg, const nsg_buff
   if constexpr (ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE) {
     const int64_t i = base + threadIdx.x;
     GridLane<ENV == NSG_ENV_CLIFFWALKING ? 4 : 3> gl;
-    step_grid<ENV, FULL>(cfg, b, N, tb, zg, actions, out, i, i < N, wc, gl, IoMode{true, true, false, false});
+    step_grid<ENV, FULL>(cfg, b, N, tb, zg, actions, out, i, i < N, wc, gl, IoMode{true, true, false, false, true});
   } else {
     LaneState<ENV> ls;
-    step_chunk<ENV, FULL>(cfg, b, N, tb, zg, actions, out, base, parity, lds, wc, ls, IoMode{true, true, false, false});
+    step_chunk<ENV, FULL>(cfg, b, N, tb, zg, actions, out, base, parity, lds, wc, ls, IoMode{true, true, false, false, true});
   }
 }
 
