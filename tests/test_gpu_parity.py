@@ -227,7 +227,7 @@ def test_constraint_violation_mask():
         g.close()
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 257, 1000, 4097])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 257, 1000, 2048, 2305, 4096, 4097, 6145])   # 1..25 chunks: whole groups of 8 (walked both ways) and ragged tails
 def test_ragged_batch_sizes_match_oracle(n):
     """Batch sizes that are not multiples of the wavefront (64) or workgroup (256) size: partial waves,
     partial workgroups, single env."""
