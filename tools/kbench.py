@@ -22,6 +22,8 @@ WORK = {
            {"map_name": "8x8"}, 96),
     "pend": ("Pendulum-v1", lambda: {"m": IncrementUpdate(ContinuousScheduler(), k=0.01)}, {}, 83),
     "acro": ("Acrobot-v1", lambda: {"LINK_MASS_2": IncrementUpdate(ContinuousScheduler(), k=0.1)}, {}, 127),
+    "mcar": ("MountainCar-v0", lambda: {"force": IncrementUpdate(ContinuousScheduler(), k=1e-6)}, {}, 79),
+    "mcarc": ("MountainCarContinuous-v0", lambda: {"power": IncrementUpdate(ContinuousScheduler(), k=1e-6)}, {}, 79),
 }
 
 
