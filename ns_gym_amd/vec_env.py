@@ -170,6 +170,14 @@ class VecNSEnv:
         F = self.layout.phys_dim
         return self._phys_blocked.permute(1, 0, 2).reshape(F, -1)[:, : self.N].contiguous()
 
+    def set_phys(self, dense):
+        """Install a dense float64 [F, N] integrator state (the inverse of `phys`; the observation rows are NOT refreshed:
+        meant for transition-level tests that overwrite the state between `reset` and `step`)."""
+        F, nb = self.layout.phys_dim, self._phys_blocked.shape[0]
+        full = torch.zeros((F, nb * 256), dtype=torch.float64, device=self.device)
+        full[:, : self.N] = torch.as_tensor(dense, dtype=torch.float64, device=self.device).reshape(F, self.N)
+        self._phys_blocked.copy_(full.view(F, nb, 256).permute(1, 0, 2))
+
     @property
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -67,12 +67,11 @@ def test_subset_of_full_batch_equals_oracle(name, T):
 
 
 @pytest.mark.parametrize("name,n,T", [("c1_cartpole_masspole_inc", N, 200), ("c2_cartpole_gravity_rw", 65536, 1000),
-                                      ("c3_frozenlake_step50", N, 200), ("c4_pendulum_m_inc", 262144, 200),
-                                      ("c4_acrobot_mass2_inc", 262144, 100)])
+                                      ("c3_frozenlake_step50", N, 200), ("c4_pendulum_m_inc", 262144, 200)])
 def test_every_env_of_the_full_batch_equals_oracle(name, n, T):
     """Not a sample: ALL envs of the BASELINE configurations at BASELINE's own batch sizes and step counts (C1's config at
-    C5's per-GPU size; C2 65 536 x 1000; C3 2^20 x 200; C4 2^18 each, Acrobot over the horizon its float32 tolerance
-    holds for) against the oracle (its OpenMP stepper on the host's cores), every compared row at checkpoints and at the end."""
+    C5's per-GPU size; C2 65 536 x 1000; C3 2^20 x 200; C4's Pendulum half 2^18 x 200 - the Acrobot half has its own test
+    below) against the oracle (its OpenMP stepper on the host's cores), every compared row at checkpoints and at the end."""
     N = n
     import os
 
@@ -100,6 +99,64 @@ def test_every_env_of_the_full_batch_equals_oracle(name, n, T):
         orc.step_mt(a.cpu().numpy(), threads)
         if k % 50 == 0 or k == T - 1:
             compare_views(view._out(), oview._out(), is_fl, f"{name}: all {N} envs, step {k}")
+    env.close()
+
+
+ACROBOT_MAX_SPLITS = 16   # of 262 144 episodes over 200 steps; measured: 5
+
+
+def test_c4_acrobot_full_horizon_with_stated_allowance():
+    """C4's Acrobot half at BASELINE's own size and step count: 262 144 envs x 200 steps, EVERY env compared with the oracle
+    after EVERY step.  The bar for an env is the suite's usual one (float32 state |d| <= 1e-5 * max(1, |x|), flags / t exact,
+    theta 1e-5 relative).  Stated allowance: the double pendulum amplifies the last-ulp differences between the kernels' sincos
+    and libm's (both <= 1 ulp; 3 % of the evaluations differ) through RK4 at dt = 0.2 until, for a handful of envs, the
+    termination test `-cos(th1) - cos(th1 + th2) > 1.0` falls on different sides in the two implementations: such an env
+    terminates one step apart, resets one step apart, and its trajectories are unrelated from then on.  Asserted:
+      * at most ACROBOT_MAX_SPLITS envs ever leave the bar;
+      * each of them leaves it AT a termination boundary: on its first differing step the two `terminated` flags disagree
+        while its state still agrees within the bar (a numeric drift would show the other way round);
+      * every other env is within the bar after every one of the 200 steps."""
+    import os
+
+    import torch
+
+    from oracle.oracle import OracleVecEnv
+    from tests.util import STATE_ATOL, STATE_RTOL, THETA_RTOL
+
+    n, T = 262144, 200
+    spec = TRAJ_SPECS["c4_acrobot_mass2_inc"]
+    env = make_env_from_spec(_vec, spec, n=n, track_returns=True, specialize=True)
+    orc = make_env_from_spec(OracleVecEnv, spec, n=n, track_returns=True)
+    seeds = np.arange(n, dtype=np.uint64) + np.uint64(4242)
+    env.reset(seed=seeds)
+    orc.reset(seed=seeds)
+    g = torch.Generator(device="cuda").manual_seed(17)
+    threads = min(16, os.cpu_count() or 1)
+    split = np.zeros(n, dtype=bool)
+    first = {}
+    for k in range(T):
+        a = torch.randint(0, env.n_actions, (n,), dtype=torch.int32, device="cuda", generator=g)
+        env.step(a)
+        orc.step_mt(a.cpu().numpy(), threads)
+        st, so = env.state.cpu().numpy(), orc.a["obs"]
+        state_ok = (np.abs(st - so) <= STATE_ATOL + STATE_RTOL * np.abs(so)).all(axis=1)
+        th, tho = env.theta.cpu().numpy()[0], orc.a["theta"][0]
+        flags_ok = ((env.terminated.cpu().numpy().astype(np.uint8) == orc.a["terminated"])
+                    & (env.truncated.cpu().numpy().astype(np.uint8) == orc.a["truncated"]) & (env.t.cpu().numpy() == orc.a["t"])
+                    & (env.gt_env_change.cpu().numpy()[0] == orc.a["env_change"][0])
+                    & (np.abs(env.reward.cpu().numpy() - orc.a["reward"]) <= 1e-5)
+                    & (np.abs(th - tho) <= 1e-12 + THETA_RTOL * np.abs(tho)))
+        bad = ~(state_ok & flags_ok) & ~split
+        for i in np.nonzero(bad)[0]:
+            term_differs = bool(env.terminated[int(i)].item()) != bool(orc.a["terminated"][i])
+            first[int(i)] = (k, term_differs, bool(state_ok[i]))
+        split |= bad
+        assert split.sum() <= ACROBOT_MAX_SPLITS, f"step {k}: {int(split.sum())} envs have left the bar: {first}"
+    for i, (k, term_differs, state_agrees) in first.items():
+        assert term_differs and state_agrees, (f"env {i} left the bar at step {k} without a termination-boundary disagreement "
+                                               f"(terminated differs: {term_differs}, state within the bar: {state_agrees})")
+    print(f"Acrobot 2^18 x 200: {int(split.sum())} of {n} envs split at a termination boundary, at steps "
+          f"{sorted(v[0] for v in first.values())}; all others within the bar after every step")
     env.close()
 
 
