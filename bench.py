@@ -9,7 +9,11 @@ Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL); envs a
 contiguous index with no per-step collective; the only exchange is one all-gather of the
 per-env episode returns at rollout end, inside the timed region.
 
-Prints ONE JSON line on rank 0 (see the task contract) with `roofline` and `cpu_baseline`.
+`python bench.py --gpus N` without a torch.distributed launcher around it starts the N ranks ITSELF (one child per GPU under
+torch.distributed.run, before this process touches a GPU) and relays rank 0's line; under a launcher (WORLD_SIZE set) it is
+one rank and `--gpus` must equal WORLD_SIZE.  It refuses to run on fewer devices than ranks.
+
+Prints ONE JSON line on rank 0 (see the task contract) with `roofline`, `roofline_hbm_resident` and `cpu_baseline`.
 """
 import argparse
 import json
@@ -21,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_PER_GPU = 1 << 20
+N_HBM_RESIDENT = 1 << 24       # second roofline figure: a batch whose rows (2.5 GB) cannot live in the 256-MiB Infinity Cache
 BYTES_PER_ENV_STEP = 120       # C1/C5, fp64 internal state
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -48,6 +53,28 @@ def cpu_baseline(n_envs, steps, threads):
     return n_envs * steps / dt, dt
 
 
+def self_launch(args, argv):
+    """`--gpus N > 1` outside a launcher: run N ranks under torch.distributed.run as a child (this process never initialises a
+    GPU: device_count() does not), relay its output, exit with its code."""
+    import socket
+    import subprocess
+
+    import torch
+
+    single = os.environ.get("NSG_BENCH_SINGLE_DEVICE") == "1"    # rehearsal: every rank on cuda:0 (tests on a one-GPU box)
+    have = torch.cuda.device_count()
+    if have < (1 if single else args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this node exposes {have}; not running "
+                         f"(a run on fewer devices would not be an N = {args.gpus} measurement)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,19 +85,28 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall time of the CPU-baseline sample (default ~10 s)")
     ap.add_argument("--generic", action="store_true",
                     help="time the generic kernels instead of the config-specialised ones (nsg_specialize)")
+    ap.add_argument("--no-hbm-resident", action="store_true", help="skip the second roofline figure (2^24 envs)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args, sys.argv[1:])          # does not return
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); they must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
     # NSG_BENCH_SINGLE_DEVICE=1 + NSG_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a one-GPU box
     # (every rank on cuda:0, collectives through gloo); the driver's real runs use one GPU per rank + RCCL
     single = os.environ.get("NSG_BENCH_SINGLE_DEVICE") == "1"
     backend = os.environ.get("NSG_BENCH_BACKEND", "nccl")
+    if not single and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) on this node")
     dev_index = 0 if single else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
@@ -139,6 +175,7 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms = e0.elapsed_time(e1) / args.steps   # average launch duration incl. back-to-back gap
 
+    episodes_rank0 = env.counters()["episodes"]
     # secondary figure (not `value`): the same env-steps through nsg_rollout, K = 64 fused steps per launch
     # with the persistent rows held in registers (callers that supply K actions at once: planners' rollouts)
     K = 64
@@ -165,6 +202,28 @@ def main():
         other.close()
     except NsgError:
         pass
+
+    # second roofline figure (not `value`): the same kernel on a batch whose rows cannot live in the Infinity Cache
+    # (2^24 envs = 2.5 GB of rows against 256 MiB), i.e. streamed from HBM on every step.  Rank 0 of an N = 1 run only.
+    hbm = None
+    if world == 1 and not args.no_hbm_resident and not args.generic and n != N_HBM_RESIDENT:
+        try:
+            env.close()
+            big = VecNSEnv(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)}, N_HBM_RESIDENT,
+                           change_notification=True, delta_change_notification=True, track_returns=True, device=dev, specialize=True)
+            big.reset(seed=0)
+            ab = torch.randint(0, 2, (N_HBM_RESIDENT,), dtype=torch.int32, device=dev, generator=g)
+            for _ in range(20):
+                big.step(ab)
+            big_us = big.time_steps(ab, 200) * 1e3      # hipEvents on the launch stream around 200 back-to-back launches
+            big.close()
+            ach = BYTES_PER_ENV_STEP * N_HBM_RESIDENT / (big_us * 1e-6) / 1e9
+            hbm = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                   "envs": N_HBM_RESIDENT, "avg_launch_us": big_us, "launches": 200,
+                   "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP, "traffic": None,
+                   "note": "same kernel and config as `roofline`, 2^24 envs: every row streams from HBM each step"}
+        except (NsgError, RuntimeError) as e:     # e.g. not enough device memory next to another tenant
+            hbm = {"error": str(e)[:200]}
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -194,7 +253,7 @@ def main():
                 "envs_per_gpu": n, "total_envs": n * world,
                 "parallelism": f"env-sharded x{world}, no per-step collective; 1 all-gather of episode returns at rollout end"
                                if world > 1 else "single GPU",
-                "episodes_finished_rank0": env.counters()["episodes"],
+                "episodes_finished_rank0": episodes_rank0,
                 "gathered_returns": int(gathered.numel()),
                 "rollout_k64_env_steps_per_sec_per_gpu": rollout_rate,
                 "kernels": "generic (precompiled)" if args.generic else "config-specialised (nsg_specialize, hiprtc)",
@@ -203,11 +262,18 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(n),
+                "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of an "
+                                  "earlier run of this kernel, scaled per env; not measured in this run)",
+                "residency": f"{n} envs = {n * 150 / 1e6:.0f} MB of rows: "
+                             + ("inside the 256-MiB Infinity Cache - `achieved` is a rate out of that cache, not out of HBM; "
+                                "see roofline_hbm_resident" if n * 150 < 256 << 20 else "beyond the 256-MiB Infinity Cache"),
                 "kernel": "nsg::step_kernel<CARTPOLE,false>" if args.generic else "nsg_spec_step (nsg::step_body<CARTPOLE,false>, config folded)",
                 "avg_launch_us": kern_ms * 1e3,
                 "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
             },
         }
+        if hbm is not None:
+            out["roofline_hbm_resident"] = hbm
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported on rank 0 at N = 1 only
             # the GPU box exposes 256 logical CPUs but one GPU's share is 16 cores
             threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))

@@ -39,6 +39,19 @@ constexpr int kCntShards = NSG_CNT_SHARDS;
 #endif
 #endif
 template <bool FULL> constexpr bool kEarlyDraw = (NSG_EARLY_DRAW != 0) && !FULL;
+// Reset hand-over, where the resetting envs' PCG64 records come from (classic-control step):
+//   NSG_OWNER_LOAD 1: the OWNER lane requests its own record as soon as its status byte says "reset" - next to the
+//     workgroup's state loads, whose latency it shares - and parks it in LDS for the helper lanes; between the two
+//     barriers of the hand-over there is LDS traffic and arithmetic only.
+//   NSG_OWNER_LOAD 0: the helper lanes request the records after the first barrier (round 1): a dependent scattered
+//     global load on the workgroup's critical path, between its two barriers.
+#ifndef NSG_OWNER_LOAD
+#define NSG_OWNER_LOAD 1
+#endif
+// NSG_UNCOND_LOADS 1: the state / action loads do not wait for the status byte (a resetting lane's are discarded).
+#ifndef NSG_UNCOND_LOADS
+#define NSG_UNCOND_LOADS 1
+#endif
 #ifndef NSG_MIN_WAVES
 #define NSG_MIN_WAVES 1
 #endif
@@ -57,6 +70,8 @@ struct Segment {
   int32_t simple_theta;    // every update fn is plain arithmetic / table look-up (upd_kind_is_simple)
   int32_t block_begin;     // first block of this segment in a heterogeneous launch
   int32_t block_count;
+  int32_t nt_records;      // the handle's rows outgrow the Infinity Cache: its config-specialised kernels are built with NSG_NT_RECORDS (nsg_rng.hip.h)
+  int32_t reserved0;
 };
 
 struct ActionPtrs {
@@ -308,15 +323,25 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   const bool track = (cfg.flags & NSG_F_TRACK_RETURNS) != 0;
   const unsigned st = !active ? 0u : io.load ? ldg(b.status, o1) : ls.st;
   const int t = !active ? 0 : io.load ? ldg(b.t, o4) : ls.t;
+#ifdef NSG_X_INLINE_RESET  // TIMING ABLATION ONLY (wrong results): a finished env re-initialises in its own lane, no hand-over
+  const bool x_was_done = active && (st & NSG_ST_NEEDS_RESET);
+  const bool do_reset = false;
+#else
   const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);
+#endif
   const bool do_step = active && !do_reset;
   if (sim && io.load && active) ls.tf = ldg(b.t_fork, o4);
+  // the resetting env's own stream record, requested by its owner lane (NSG_OWNER_LOAD)
+  const bool own_load = (NSG_OWNER_LOAD != 0) && !io.lds_rng;
+  Pcg g = {0, 0, 0, 0};
+  if (own_load && do_reset) pcg_load_record(b.rng_env, i, g);
+  const bool ld_state = NSG_UNCOND_LOADS ? active : do_step;
   double s[T::PHYS];
 #pragma unroll
-  for (int k = 0; k < T::PHYS; k++) s[k] = !do_step ? 0.0 : io.load ? ldg(b.phys, blk_off8(T::PHYS, k, i)) : ls.s[k];
+  for (int k = 0; k < T::PHYS; k++) s[k] = !ld_state ? 0.0 : io.load ? ldg(b.phys, blk_off8(T::PHYS, k, i)) : ls.s[k];
   int ai = 0;
   float af = 0.f;
-  if (do_step) {
+  if (ld_state) {
     if constexpr (T::FLOAT_ACT) af = ldg((const float*)actions, o4);
     else ai = ldg((const int32_t*)actions, o4);
   }
@@ -332,12 +357,15 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   // overlaps that work instead of sitting behind it on the workgroup's critical path) or after it.
   int n_reset = 0, owner = 0;
   bool helper = false;
-  Pcg g = {0, 0, 0, 0};
   auto queue_resets = [&]() {
     int* rn = lds.reset_n + (parity & 1);
     if (do_reset) {
       const int q = atomicAdd(rn, 1);
       lds.reset_list[q] = (short)tid;
+      if (own_load) {  // the record travels through the owner's reset_state slot (the helper replaces it with the drawn state)
+        uint64_t* rec = reinterpret_cast<uint64_t*>(lds.reset_state) + tid * 4;
+        rec[0] = g.sh; rec[1] = g.sl; rec[2] = g.ih; rec[3] = g.il;
+      }
     }
     __syncthreads();
     n_reset = *rn;
@@ -348,12 +376,15 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
       if (io.lds_rng) {
         const uint64_t* rec = lds.streams + owner * 4;
         g.sh = rec[0]; g.sl = rec[1]; g.ih = rec[2]; g.il = rec[3];
+      } else if (own_load) {
+        const uint64_t* rec = reinterpret_cast<const uint64_t*>(lds.reset_state) + owner * 4;
+        g.sh = rec[0]; g.sl = rec[1]; g.ih = rec[2]; g.il = rec[3];
       } else {
-        pcg_load(b.rng_env, N, base + owner, g);
+        pcg_load_record(b.rng_env, base + owner, g);
       }
     }
   };
-  const bool early_draw = kEarlyDraw<FULL> && !io.lds_rng;  // LDS-resident records: no latency to hide
+  const bool early_draw = kEarlyDraw<FULL> && !io.lds_rng && !own_load;  // LDS-resident / owner-loaded records: no latency to hide
   if (early_draw) queue_resets();
 
   double th[T::NTHETA + T::NDERIVED];
@@ -491,8 +522,23 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     }
   }
   if (do_step) {
+#ifdef NSG_X_FAKE_STEP  // TIMING ABLATION ONLY (wrong results): no integrator arithmetic, same episode-end rate
+#pragma unroll
+    for (int k = 0; k < T::PHYS; k++) s[k] = s[k] * 0.999 + th[0] * 1e-6;
+    term = (((uint32_t)i * 2654435761u + (uint32_t)t * 40503u) >> 22) < 46u;
+    reward = 1.0;
+#else
     term = env_step<ENV>(th, s, ai, af, reward);
+#endif
+#ifdef NSG_X_INLINE_RESET
+    if (x_was_done) {
+#pragma unroll
+      for (int k = 0; k < T::PHYS; k++) s[k] = 0.01 * (k + 1);
+    }
+    tnew = x_was_done ? 0 : t + 1;
+#else
     tnew = t + 1;  // base.py:314
+#endif
     // TimeLimit [UPSTREAM] counts the steps of ITS env: a planning copy restarts at the fork
     const int elapsed = tnew - (sim ? ls.tf : 0);
     trunc = cfg.max_episode_steps > 0 && elapsed >= cfg.max_episode_steps;
@@ -503,7 +549,18 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   }
   const bool done = term || trunc;
 
-  // ---- compacted resets: queue -> helper lanes draw -> owners read back ----------------------
+  // ---- resets ---------------------------------------------------------------------------------
+#if defined(NSG_X_RESET_INLANE)  // EXPERIMENT: every resetting lane draws its own initial state (no queue, no barriers)
+  if (!io.lds_rng) {
+    if (do_reset) {
+      env_reset_draw<ENV>(g, s);
+      pcg_store_record_state(b.rng_env, i, g);
+    }
+  } else {
+#else
+  {
+#endif
+  // compacted resets: queue -> helper lanes draw -> owners read back
   if (!early_draw) queue_resets();
   if (helper) {  // gymnasium reset(): np_random draws of the initial state [UPSTREAM]
     double r0[T::PHYS];
@@ -512,7 +569,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
       uint64_t* rec = lds.streams + owner * 4;
       rec[0] = g.sh; rec[1] = g.sl;
     } else {
-      pcg_store_state(b.rng_env, N, base + owner, g);
+      pcg_store_record_state(b.rng_env, base + owner, g);
     }
 #pragma unroll
     for (int k = 0; k < T::PHYS; k++) lds.reset_state[owner * 4 + k] = r0[k];
@@ -521,6 +578,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   if (do_reset) {
 #pragma unroll
     for (int k = 0; k < T::PHYS; k++) s[k] = lds.reset_state[tid * 4 + k];
+  }
   }
 
 #pragma unroll

@@ -180,6 +180,10 @@ typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 //   rows (ROWS = true): chunk-blocked [ceil(N/256)][4][256] u64 - the env streams of the grid envs, where EVERY lane
 //     draws one uniform per step: four fully coalesced 8-byte rows instead of 16-byte accesses at a 32-byte
 //     stride (FrozenLake-shaped skeleton, tools/layout_probe.hip: 19.1 us vs 23.0 us per 2^20 envs).
+template <typename T> __device__ __forceinline__ T ldg_nt(const T* base, uint32_t byte_off) {
+  const NSG_GLOBAL char* p = (const NSG_GLOBAL char*)pin_sgpr((uint64_t)base);
+  return __builtin_nontemporal_load((const NSG_GLOBAL T*)(p + byte_off));
+}
 template <bool ROWS = false>
 __device__ __forceinline__ void pcg_load(const uint64_t* base, int64_t N, int64_t i, Pcg& r) {
   if constexpr (ROWS) {
@@ -191,6 +195,34 @@ __device__ __forceinline__ void pcg_load(const uint64_t* base, int64_t N, int64_
     const u64x2 c = ldg(reinterpret_cast<const u64x2*>(base), o + 16u);
     r.sh = a.x; r.sl = a.y; r.ih = c.x; r.il = c.y;
   }
+}
+// The env stream RECORDS of the classic-control envs are touched only by the few lanes whose env resets: 32 bytes of a
+// 128-byte line per touch, yet over a few steps every line of the record array (128 MB at 2^22 envs) passes through the
+// caches and displaces the densely re-read state rows.  `nt` requests and writes them with the non-temporal policy instead.
+// It is a COMPILE-TIME choice (NSG_NT_RECORDS; a run-time select between the two load flavours - even one whose condition
+// folds to a constant after inlining - is merged into one plain load by the compiler): the config-specialised kernels of a handle whose rows outgrow the 256-MiB Infinity Cache are built with
+// it (nsg_specialize, Segment::nt_records), the precompiled generic kernels never.  Measured, C1, specialised kernels:
+// 2^22 envs 124 -> 113.5 us, 2^24 envs 499 -> 465 us; at 2^20 envs (everything cache-resident) the same policy COSTS
+// 25.7 -> 30.3 us, hence the switch by size.
+#ifndef NSG_NT_RECORDS
+#define NSG_NT_RECORDS 0
+#endif
+constexpr bool kNtRecords = NSG_NT_RECORDS != 0;
+__device__ __forceinline__ void pcg_load_record(const uint64_t* base, int64_t i, Pcg& r) {
+  const uint32_t o = (uint32_t)i * 32u;
+  u64x2 a, c;
+  if constexpr (kNtRecords) {
+    a = ldg_nt(reinterpret_cast<const u64x2*>(base), o);
+    c = ldg_nt(reinterpret_cast<const u64x2*>(base), o + 16u);
+  } else {
+    a = ldg(reinterpret_cast<const u64x2*>(base), o);
+    c = ldg(reinterpret_cast<const u64x2*>(base), o + 16u);
+  }
+  r.sh = a.x; r.sl = a.y; r.ih = c.x; r.il = c.y;
+}
+__device__ __forceinline__ void pcg_store_record_state(uint64_t* base, int64_t i, const Pcg& r) {
+  if constexpr (kNtRecords) stg_out(reinterpret_cast<u64x2*>(base), (uint32_t)i * 32u, u64x2{r.sh, r.sl});
+  else stg(reinterpret_cast<u64x2*>(base), (uint32_t)i * 32u, u64x2{r.sh, r.sl});
 }
 template <bool ROWS = false, bool WT = false>
 __device__ __forceinline__ void pcg_store_state(uint64_t* base, int64_t N, int64_t i, const Pcg& r) {

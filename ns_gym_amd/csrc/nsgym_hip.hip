@@ -349,6 +349,21 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
   return NSG_OK;
 }
 
+// Bytes of all rows of a handle (what one step streams through the caches, give or take the rows a config never touches).
+static int64_t layout_bytes(const nsg_layout& l) {
+  return 8 * (l.phys + l.theta + l.table_prob + l.derived + l.rng_env + l.rng_upd + l.rng_sched + l.done_bits) +
+         4 * (l.cell + l.t + l.t_fork + l.sched_next + l.cursor + l.obs + l.reward + l.delta_change + l.prob + l.ep_return + l.ep_length +
+              l.last_return + l.last_length) +
+         (l.status + l.terminated + l.truncated + l.env_change + l.violation);
+}
+// Rows well beyond the 256-MiB Infinity Cache: the sparsely touched env stream records take the non-temporal path in the handle's
+// config-specialised kernels (nsg_rng.hip.h).  Measured on C1 (rows: 157 MB per 2^20 envs), nt against plain: 2^20 envs 29.4 vs
+// 25.2 us, 2^21 55.0 vs 47.0, 2^22 106.1 vs 112.4, 2^24 520 vs 530 - the switch sits at twice the cache.  NSG_NT_RECORDS=0/1 forces it.
+static int nt_records_for(const nsg_layout& l) {
+  if (const char* e = getenv("NSG_NT_RECORDS")) return e[0] == '1';
+  return layout_bytes(l) > (512LL << 20);
+}
+
 static int grid_cap() {  // tuning knob (tools/kbench.py sweeps it); default from measurements
   static int cap = 0;
   if (!cap) {
@@ -375,6 +390,7 @@ int nsg_bind(nsg_handle* h, const nsg_buffers* bufs) {
   NEED(ep_return); NEED(ep_length); NEED(last_return); NEED(last_length);
 #undef NEED
   h->host.buf = *bufs;
+  h->host.nt_records = nt_records_for(lay);
   HIP_TRY(hipMemcpy(h->dev, &h->host, sizeof(Segment), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(init_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, 0, h->dev);
   HIP_TRY(hipGetLastError());
@@ -531,15 +547,18 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
       uint64_t h0 = 0x67726f7570ull;  // "group"
       const nsg_config* cfgs[NSG_MAX_SEGMENTS];
       bool full[NSG_MAX_SEGMENTS];
+      bool nt = false;
       for (int k = 0; k < n_handles; k++) {
         h0 = nsg_spec::fnv1a(&hs[k]->spec->h0, sizeof(uint64_t), h0);
         cfgs[k] = &hs[k]->host.cfg;
         full[k] = !hs[k]->host.simple_theta;
+        nt = nt || hs[k]->host.nt_records != 0;
       }
+      h0 = nsg_spec::fnv1a(&nt, sizeof(nt), h0);
       hipDeviceProp_t prop;
       HIP_TRY(hipGetDeviceProperties(&prop, hs[0]->device));
       const int rc = get_spec_module(hs[0]->device, h0, true,
-                                     [&](std::string& err) { return nsg_spec::group_compile(cfgs, full, n_handles, prop.gcnArchName, err); },
+                                     [&](std::string& err) { return nsg_spec::group_compile(cfgs, full, n_handles, prop.gcnArchName, err, nt); },
                                      &group_spec);
       if (rc) group_spec = nullptr;  // the generic group kernel stays in force
     }
@@ -684,7 +703,8 @@ int nsg_spec_build(const nsg_config* cfg, const char* arch, void** code_out, siz
   for (int p = 0; p < cfg->n_params; p++)
     if (!upd_kind_is_simple(cfg->params[p].upd_kind) || sched_is_stochastic(cfg->params[p].sched_kind)) full = true;
   std::string err;
-  std::vector<char> code = nsg_spec::spec_compile(*cfg, full, arch && *arch ? arch : "gfx950", err);
+  const char* ntenv = getenv("NSG_NT_RECORDS");  // the record policy of the unit (nsg_specialize derives it from the handle's size)
+  std::vector<char> code = nsg_spec::spec_compile(*cfg, full, arch && *arch ? arch : "gfx950", err, ntenv && ntenv[0] == '1');
   if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
   void* p = malloc(code.size());
   if (!p) return fail(NSG_ENOMEM, "out of host memory");
@@ -705,10 +725,12 @@ int nsg_specialize(nsg_handle* h) {
   // key: config bytes + engine variant + target (+ the kernel sources this library was built from)
   uint64_t h0 = nsg_spec::fnv1a(&h->host.cfg, sizeof(nsg_config));
   h0 = nsg_spec::fnv1a(&full, sizeof(full), h0);
+  const bool nt = h->host.nt_records != 0;  // rows beyond the Infinity Cache: stream records take the non-temporal path
+  h0 = nsg_spec::fnv1a(&nt, sizeof(nt), h0);
   h0 = nsg_spec::fnv1a(prop.gcnArchName, strlen(prop.gcnArchName), h0);
   if (const char* e = getenv("NSG_SPEC_FLAGS")) h0 = nsg_spec::fnv1a(e, strlen(e), h0);
   return get_spec_module(h->device, h0, false,
-                         [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err); }, &h->spec);
+                         [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err, nt); }, &h->spec);
 }
 
 int nsg_is_specialized(const nsg_handle* h) { return h && h->spec ? 1 : 0; }

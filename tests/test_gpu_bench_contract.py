@@ -34,6 +34,10 @@ def test_single_process_line():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert abs(r["achieved"] - 120 * 65536 / (r["avg_launch_us"] * 1e-6) / 1e9) / r["achieved"] < 1e-6
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and "workload" in d["config"]
+    assert "static" in r["traffic_source"] and "Infinity Cache" in r["residency"]
+    h = d["roofline_hbm_resident"]                      # the same kernel on 2^24 envs: rows stream from HBM
+    assert h["envs"] == 1 << 24 and h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / 8000.0) < 1e-9
+    assert abs(h["achieved"] - 120 * (1 << 24) / (h["avg_launch_us"] * 1e-6) / 1e9) / h["achieved"] < 1e-6
 
 
 def test_two_ranks_aggregate_line():
@@ -46,3 +50,32 @@ def test_two_ranks_aggregate_line():
     assert KEYS <= set(d) and "cpu_baseline" not in d            # the CPU leg runs on rank 0 of an N = 1 run only
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 2 * 65536 and d["config"]["gathered_returns"] == 2 * 65536
     assert abs(d["value"] - 2 * 65536 * 60 / (d["ms_per_step"] * 60 / 1e3)) / d["value"] < 1e-6   # whole-job aggregate
+
+
+def test_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (here both on the one GPU of the test box,
+    collectives through gloo) and prints ONE line with n_gpus = 2."""
+    env = dict(os.environ, NSG_BENCH_SINGLE_DEVICE="1", NSG_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "40", "--warmup", "10", "--envs-per-gpu", "65536"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 2 * 65536 and d["config"]["gathered_returns"] == 2 * 65536
+
+
+def test_more_ranks_than_gpus_is_refused():
+    """A one-GPU box must not answer `--gpus 8` with an N = 1 line."""
+    import torch
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NSG_BENCH_SINGLE_DEVICE")}
+    want = torch.cuda.device_count() + 7
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", str(want), "--steps", "5"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode != 0 and "n_gpus" not in p.stdout and f"--gpus {want} needs {want} GPUs" in p.stderr
+    # and a launcher that started a different number of ranks than --gpus says is refused as well
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5"], cwd=ROOT, env=env2, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode != 0 and "they must agree" in p.stderr and "n_gpus" not in p.stdout

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of library builds (one subprocess per variant per round, same box).
 
-    tools/ab.py VARIANTS [WORK] [ROUNDS]
+    tools/ab.py VARIANTS [WORK] [ROUNDS] [N_ENVS] [ITERS]
     VARIANT = <build>[:spec[:<hiprtc flags>]]   build = tools/exp_<build>.so ("lib" = the in-tree library)
 e.g.  tools/ab.py lib,lib:spec,lib:spec:-DNSG_BATCH_LOADS=0 c1 3
 """
@@ -9,6 +9,8 @@ import json, os, subprocess, sys
 variants = sys.argv[1].split(",")
 work = sys.argv[2] if len(sys.argv) > 2 else "c1"
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+n_envs = sys.argv[4] if len(sys.argv) > 4 else str(1 << 20)
+iters = sys.argv[5] if len(sys.argv) > 5 else "300"
 res = {b: [] for b in variants}
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for r in range(rounds):
@@ -17,7 +19,7 @@ for r in range(rounds):
         env = dict(os.environ)
         if parts[0] != "lib":
             env["NSG_LIB"] = os.path.join(root, "tools", f"exp_{parts[0]}.so")
-        cmd = [sys.executable, os.path.join(root, "tools", "kbench.py"), "--work", work, "--iters", "300"]
+        cmd = [sys.executable, os.path.join(root, "tools", "kbench.py"), "--work", work, "--iters", iters, "--n", n_envs]
         if len(parts) > 1 and parts[1] == "spec":
             cmd.append("--spec")
             if len(parts) > 2:
@@ -28,4 +30,4 @@ for r in range(rounds):
                 res[v].append(json.loads(line.split(" ", 1)[1])["us"])
 for v in variants:
     x = sorted(res[v])
-    print(v, "min %.2f med %.2f" % (x[0], x[len(x) // 2]) if x else "no result", ["%.1f" % y for y in res[v]])
+    print(f"n={n_envs} {work}", v, "min %.2f med %.2f" % (x[0], x[len(x) // 2]) if x else "no result", ["%.1f" % y for y in res[v]], flush=True)

@@ -133,6 +133,165 @@ __global__ __launch_bounds__(256) void skel(Bufs r, int64_t N) {
   }
 }
 
+
+// ---- latency-chain probe: the lib-layout skeleton plus W dependent float64 FMAs per lane (the integrator's place), optionally two
+// workgroup barriers (the reset hand-over's), optionally the NEXT chunk's rows requested before this chunk's arithmetic ----
+struct RowsIn { unsigned st; int t; double s[4]; int a; double th; };
+__device__ __forceinline__ RowsIn load_rows(const Bufs& r, int64_t c, int l) {
+  RowsIn x;
+  const int64_t i = c * 256 + l;
+  const double* bp = r.phys + c * 1024;
+  x.st = r.status[i]; x.t = r.t[i];
+#pragma unroll
+  for (int k = 0; k < 4; k++) x.s[k] = bp[k * 256 + l];
+  x.a = r.action[i]; x.th = r.theta[i];
+  return x;
+}
+template <int W, bool BARRIERS, bool PREFETCH>
+__global__ __launch_bounds__(256) void chain(Bufs r, int64_t N) {
+  __shared__ double hand[256];
+  const int64_t chunks = N / 256;
+  const int l = threadIdx.x;
+  int64_t c = blockIdx.x;
+  if (c >= chunks) return;
+  RowsIn cur = load_rows(r, c, l);
+  for (; c < chunks; c += gridDim.x) {
+    const int64_t cn = c + gridDim.x;
+    RowsIn nxt = cur;
+    if (PREFETCH && cn < chunks) nxt = load_rows(r, cn, l);
+    const int64_t i = c * 256 + l;
+    double s[4] = {cur.s[0], cur.s[1], cur.s[2], cur.s[3]};
+    double th = cur.th; int t = cur.t; unsigned st = cur.st;
+    f32x4 o; float rew, delta; unsigned term, trunc, flag;
+    compute(s, th, t, st, cur.a, o, rew, term, trunc, flag, delta);
+    double acc = s[1];
+#pragma unroll 8
+    for (int w = 0; w < W; w++) acc = acc * 0.999999 + s[w & 3] * 1e-9;   // dependent chain: W x (mul + add), not contracted away
+    s[1] = acc;
+    if (BARRIERS) {
+      hand[l] = s[0];
+      __syncthreads();
+      if (l < 13) hand[l * 7] = hand[l * 3] * 0.5 + 1e-3;
+      __syncthreads();
+      if (st) s[0] = hand[l];
+    }
+    double* bp = r.phys + c * 1024;
+    r.theta[i] = th;
+#pragma unroll
+    for (int k = 0; k < 4; k++) bp[k * 256 + l] = s[k];
+    r.t[i] = t; r.status[i] = (uint8_t)st;
+    st_out<true>(r.obs + i, o); st_out<true>(r.reward + i, rew); st_out<true>(r.delta + i, delta);
+    st_out<true>(r.term + i, (uint8_t)term); st_out<true>(r.trunc + i, (uint8_t)trunc); st_out<true>(r.flag + i, (uint8_t)flag);
+    if (PREFETCH) cur = nxt;
+    else if (cn < chunks) cur = load_rows(r, cn, l);
+  }
+}
+template <int W, bool BARRIERS, bool PREFETCH> void run_chain(const Bufs& r, int64_t N, int grid, int iters) {
+  const int64_t chunks = N / 256;
+  const int g = (int)(chunks < grid ? chunks : grid);
+  float us = time_it([&] { hipLaunchKernelGGL((chain<W, BARRIERS, PREFETCH>), dim3(g), dim3(256), 0, 0, r, N); }, iters);
+  printf("{\"n_log2\": %d, \"variant\": \"chain\", \"fma_pairs\": %d, \"barriers\": %d, \"prefetch\": %d, \"grid\": %d, \"us\": %.2f, \"algorithmic_GBs\": %.0f}\n",
+         (int)__builtin_ctzll((unsigned long long)N), W, (int)BARRIERS, (int)PREFETCH, g, us, 120.0 * N / us / 1e3);
+  fflush(stdout);
+}
+
+
+// ---- scattered-record probe: the lib-layout skeleton plus, for ~5 % of the lanes (hash of env index and launch number), a
+// 32-byte record read (two 16-B loads) and / or a 16-B write-back into a [N][4] u64 array: the reset path's stream accesses ----
+typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+template <int MODE>   // 0 none, 1 load+store, 2 load only, 3 store only, 4 load+store of 64-B aligned records ([N][8] u64), 5 = 1 with 4-B scattered stores too
+__global__ __launch_bounds__(256) void scat(Bufs r, int64_t N, u64x2_t* rec, float* lastr, unsigned launch) {
+  const int64_t chunks = N / 256;
+  const int l = threadIdx.x;
+  for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const int64_t i = c * 256 + l;
+    RowsIn cur = load_rows(r, c, l);
+    const bool hit = (((uint32_t)i * 2654435761u + launch * 40503u) >> 22) < 52u;   // ~5 %
+    u64x2_t a = {0, 0}, b = {0, 0};
+    const int64_t ri = MODE == 4 ? 4 * i : 2 * i;
+    if (hit && (MODE == 1 || MODE == 2 || MODE == 4 || MODE == 5)) { a = rec[ri]; b = rec[ri + 1]; }
+    double s[4] = {cur.s[0], cur.s[1], cur.s[2], cur.s[3]};
+    double th = cur.th; int t = cur.t; unsigned st = cur.st;
+    f32x4 o; float rew, delta; unsigned term, trunc, flag;
+    compute(s, th, t, st, cur.a, o, rew, term, trunc, flag, delta);
+    if (hit) {
+      a.x = a.x * 6364136223846793005ull + b.x; a.y = a.y * 6364136223846793005ull + b.y + 1;
+      s[0] += (double)(a.x >> 11) * 1e-30;
+      if (MODE == 1 || MODE == 3 || MODE == 4 || MODE == 5) rec[ri] = a;
+      if (MODE == 5) { lastr[i] = (float)t; lastr[N + i] = (float)t; }
+    }
+    double* bp = r.phys + c * 1024;
+    r.theta[i] = th;
+#pragma unroll
+    for (int k = 0; k < 4; k++) bp[k * 256 + l] = s[k];
+    r.t[i] = t; r.status[i] = (uint8_t)st;
+    st_out<true>(r.obs + i, o); st_out<true>(r.reward + i, rew); st_out<true>(r.delta + i, delta);
+    st_out<true>(r.term + i, (uint8_t)term); st_out<true>(r.trunc + i, (uint8_t)trunc); st_out<true>(r.flag + i, (uint8_t)flag);
+  }
+}
+template <int MODE> void run_scat(const Bufs& r, int64_t N, int iters, u64x2_t* rec, float* lastr, const char* tag) {
+  unsigned launch = 0;
+  float us = time_it([&] { hipLaunchKernelGGL((scat<MODE>), dim3(4096), dim3(256), 0, 0, r, N, rec, lastr, launch++); }, iters);
+  printf("{\"n_log2\": %d, \"variant\": \"scattered records: %s\", \"us\": %.2f, \"algorithmic_GBs\": %.0f}\n",
+         (int)__builtin_ctzll((unsigned long long)N), tag, us, 120.0 * N / us / 1e3);
+  fflush(stdout);
+}
+
+
+// ---- in-block records: the chunk's persistent rows AND its 256 stream records in one contiguous block
+//   [phys 8192 | theta 2048 | t 1024 | epi 1024 (needs-reset bit + last episode length: replaces status + the two sparse 4-B stores) | records 8192]
+// so that the sparse record accesses fall next to the bytes the workgroup streams anyway (same DRAM neighbourhood).
+template <int RECS_IN_BLOCK, int DENSE_EPI>
+__global__ __launch_bounds__(256) void inblk(Bufs r, int64_t N, unsigned char* blk_base, u64x2_t* rec_far, float* lastr, unsigned launch) {
+  const int64_t chunks = N / 256;
+  const int l = threadIdx.x;
+  constexpr int STRIDE = 8192 + 2048 + 1024 + 1024 + 8192;
+  for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const int64_t i = c * 256 + l;
+    unsigned char* blk = blk_base + c * STRIDE;
+    double* bp = (double*)blk;
+    double* bth = (double*)(blk + 8192) + l;
+    int32_t* bt = (int32_t*)(blk + 10240) + l;
+    int32_t* be = (int32_t*)(blk + 11264) + l;
+    u64x2_t* rec = RECS_IN_BLOCK ? (u64x2_t*)(blk + 12288) + 2 * l : rec_far + 2 * i;
+    int t = *bt;
+    int epi = DENSE_EPI ? *be : (int)r.status[i];
+    unsigned st = epi & 1;
+    double s[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) s[k] = bp[k * 256 + l];
+    const int a = r.action[i];
+    double th = *bth;
+    const bool hit = (((uint32_t)i * 2654435761u + launch * 40503u) >> 22) < 52u;   // ~5 %
+    u64x2_t ra = {0, 0}, rb = {0, 0};
+    if (hit) { ra = rec[0]; rb = rec[1]; }
+    f32x4 o; float rew, delta; unsigned term, trunc, flag;
+    compute(s, th, t, st, a, o, rew, term, trunc, flag, delta);
+    if (hit) {
+      ra.x = ra.x * 6364136223846793005ull + rb.x; ra.y = ra.y * 6364136223846793005ull + rb.y + 1;
+      s[0] += (double)(ra.x >> 11) * 1e-30;
+      rec[0] = ra;
+      if (DENSE_EPI) epi = (t << 1);
+      else { lastr[i] = (float)t; lastr[N + i] = (float)t; }
+    }
+    *bth = th;
+#pragma unroll
+    for (int k = 0; k < 4; k++) bp[k * 256 + l] = s[k];
+    *bt = t;
+    if (DENSE_EPI) *be = (epi & ~1) | (int)st;
+    else r.status[i] = (uint8_t)st;
+    st_out<true>(r.obs + i, o); st_out<true>(r.reward + i, rew); st_out<true>(r.delta + i, delta);
+    st_out<true>(r.term + i, (uint8_t)term); st_out<true>(r.trunc + i, (uint8_t)trunc); st_out<true>(r.flag + i, (uint8_t)flag);
+  }
+}
+template <int RECS_IN_BLOCK, int DENSE_EPI> void run_inblk(const Bufs& r, int64_t N, int iters, unsigned char* blk, u64x2_t* rec, float* lastr, const char* tag) {
+  unsigned launch = 0;
+  float us = time_it([&] { hipLaunchKernelGGL((inblk<RECS_IN_BLOCK, DENSE_EPI>), dim3(4096), dim3(256), 0, 0, r, N, blk, rec, lastr, launch++); }, iters);
+  printf("{\"n_log2\": %d, \"variant\": \"blocked state, %s\", \"us\": %.2f, \"algorithmic_GBs\": %.0f}\n",
+         (int)__builtin_ctzll((unsigned long long)N), tag, us, 120.0 * N / us / 1e3);
+  fflush(stdout);
+}
+
 // pure copy of the same byte count, 16-B accesses (ceiling of the memory system for this footprint and grid)
 __global__ __launch_bounds__(256) void copy16_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n16) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
@@ -214,6 +373,44 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&src, copy_bytes));
     CHECK(hipMalloc(&dst, copy_bytes));
     CHECK(hipMemset(src, 0, copy_bytes));
+    if (getenv("PROBE_SCAT")) {
+      u64x2_t* rec; float* lastr;
+      CHECK(hipMalloc(&rec, (size_t)N * 64)); CHECK(hipMemset(rec, 1, (size_t)N * 64));
+      CHECK(hipMalloc(&lastr, (size_t)N * 8)); CHECK(hipMemset(lastr, 0, (size_t)N * 8));
+      for (int rep = 0; rep < 2; rep++) {
+        run_scat<0>(r, N, iters, rec, lastr, "none");
+        run_scat<1>(r, N, iters, rec, lastr, "32-B read + 16-B write-back");
+        run_scat<2>(r, N, iters, rec, lastr, "32-B read only");
+        run_scat<3>(r, N, iters, rec, lastr, "16-B write only");
+        run_scat<4>(r, N, iters, rec, lastr, "64-B aligned records, 32-B read + 16-B write-back");
+        run_scat<5>(r, N, iters, rec, lastr, "32-B read + 16-B write-back + two 4-B stores");
+      }
+      unsigned char* blk;
+      CHECK(hipMalloc(&blk, (size_t)chunks * 20480)); CHECK(hipMemset(blk, 0, (size_t)chunks * 20480));
+      for (int rep = 0; rep < 2; rep++) {
+        run_inblk<0, 0>(r, N, iters, blk, rec, lastr, "far records, sparse last-return stores");
+        run_inblk<1, 0>(r, N, iters, blk, rec, lastr, "IN-BLOCK records, sparse last-return stores");
+        run_inblk<0, 1>(r, N, iters, blk, rec, lastr, "far records, dense epi row");
+        run_inblk<1, 1>(r, N, iters, blk, rec, lastr, "IN-BLOCK records, dense epi row");
+      }
+      CHECK(hipFree(blk));
+      CHECK(hipFree(rec)); CHECK(hipFree(lastr));
+      continue;
+    }
+    if (getenv("PROBE_CHAIN")) {
+      for (int G : {4096, 2048}) {
+        run_chain<0, false, false>(r, N, G, iters); run_chain<0, false, true>(r, N, G, iters);
+        run_chain<0, true, false>(r, N, G, iters); run_chain<0, true, true>(r, N, G, iters);
+        run_chain<100, false, false>(r, N, G, iters); run_chain<100, false, true>(r, N, G, iters);
+        run_chain<100, true, false>(r, N, G, iters); run_chain<100, true, true>(r, N, G, iters);
+        run_chain<200, false, false>(r, N, G, iters); run_chain<200, false, true>(r, N, G, iters);
+        run_chain<200, true, false>(r, N, G, iters); run_chain<200, true, true>(r, N, G, iters);
+        run_chain<400, false, false>(r, N, G, iters); run_chain<400, false, true>(r, N, G, iters);
+        run_chain<400, true, false>(r, N, G, iters); run_chain<400, true, true>(r, N, G, iters);
+      }
+      run_chain<200, true, false>(r, N, 16384, iters); run_chain<200, false, false>(r, N, 16384, iters);
+      continue;
+    }
     for (int rep = 0; rep < 2; rep++) {
       const int G = 4096;
       run<0, 0, 0, 1, true>(r, N, G, iters, "lib: phys blocked, flat rows, nt outputs");
