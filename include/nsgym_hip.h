@@ -64,7 +64,8 @@ enum {
   NSG_SCHED_PERIODIC = 1,   /* :77-89   i0 = period                                         */
   NSG_SCHED_BURST = 2,      /* :119-140 i0 = on, i1 = off                                   */
   NSG_SCHED_TABLE = 3,      /* Discrete :56-74, Window :180-198, Custom :31-43 compiled to a
-                               bit table over t (tab_off, tab_len bits; i0 = value beyond)   */
+                               bit table over t (tab_off, tab_len bits; i0 = value beyond the table:
+                               0 / 1, or 2 = unknown - a sampled callable: no fire, NSG_CNT_SCHED_OVERRUN) */
   NSG_SCHED_RANDOM = 4,     /* :9-28    p0 = probability, own PCG64 stream                  */
   NSG_SCHED_DECAYING = 5,   /* :143-177 p0 = initial probability, p1 = decay rate            */
   NSG_SCHED_MEMORYLESS = 6  /* :92-116  p0 = p (geometric gaps)                             */
@@ -129,7 +130,13 @@ enum {
   NSG_CNT_FIRED = 1,      /* (env,param) updates applied (notification flags raised)    */
   NSG_CNT_VIOLATION = 2,  /* (env,param) updates rejected by the constraint checker     */
   NSG_CNT_STEPS = 3,      /* env transitions executed (autoreset lanes excluded)        */
-  NSG_CNT_COUNT = 4
+  /* conditions for which the reference RAISES; a kernel cannot, so it counts them and the host turns a non-zero count into the
+   * reference's exception when it polls (VecNSEnv.check_errors, the N = 1 adaptors after every step):                        */
+  NSG_CNT_LC_EXHAUSTED = 4,   /* LCBoundedDistrubutionUpdate found no Lipschitz-continuous candidate in 1e5 tries: ValueError
+                                 (ns_gym/update_functions/distribution.py:168-182); the distribution was left unchanged       */
+  NSG_CNT_SCHED_OVERRUN = 5,  /* a CustomScheduler was asked about a t beyond the horizon its callable was sampled over
+                                 (the reference calls event_function(t) for any t, ns_gym/schedulers.py:31-43); it did not fire */
+  NSG_CNT_COUNT = 6
 };
 #define NSG_CNT_SHARDS 16384
 #define NSG_MAX_ENVS (1LL << 27) /* envs per handle: rows are addressed with 32-bit byte offsets */

@@ -38,8 +38,8 @@ F_IN_SIM_CHANGE = 0x80
 
 ST_NEEDS_RESET = 0x1
 
-CNT_DONE, CNT_FIRED, CNT_VIOLATION, CNT_STEPS = 0, 1, 2, 3
-CNT_COUNT = 4
+CNT_DONE, CNT_FIRED, CNT_VIOLATION, CNT_STEPS, CNT_LC_EXHAUSTED, CNT_SCHED_OVERRUN = 0, 1, 2, 3, 4, 5
+CNT_COUNT = 6
 CNT_SHARDS = 16384
 
 

@@ -68,14 +68,20 @@ struct Segment {
   int32_t uses_normal;     // some update fn draws normals -> stage the normal ziggurat tables
   int32_t uses_exp;        // Memoryless (p < 1/3) / RandomCategorical -> stage the exponential ziggurat tables
   int32_t simple_theta;    // every update fn is plain arithmetic / table look-up (upd_kind_is_simple)
-  int32_t block_begin;     // first block of this segment in a heterogeneous launch
-  int32_t block_count;
   int32_t nt_records;      // the handle's rows outgrow the Infinity Cache: its config-specialised kernels are built with NSG_NT_RECORDS (nsg_rng.hip.h)
   int32_t reserved0;
 };
 
 struct ActionPtrs {
   const void* p[NSG_MAX_SEGMENTS];
+};
+// Heterogeneous launch (nsg_step_group): every member's OWN device-resident Segment (kept current by nsg_bind) plus the block
+// range it takes in this launch, all by value in the kernel arguments - nothing shared between launches that a later call
+// could overwrite under a launch still in flight.
+struct GroupArgs {
+  const Segment* seg[NSG_MAX_SEGMENTS];
+  int32_t block_begin[NSG_MAX_SEGMENTS];
+  int32_t block_count[NSG_MAX_SEGMENTS];
 };
 
 // Dynamic LDS layout (sized per handle at launch: a batch with tiny tables must not pay 22 KB of
@@ -160,14 +166,15 @@ __device__ __forceinline__ StepOut default_out(const nsg_buffers& b) {
 
 // Per-wavefront running counts (lane-uniform), added to the wavefront's own counter shard when it retires.
 struct WaveCounts {
-  unsigned done = 0, fired = 0, viol = 0, steps = 0;
+  unsigned done = 0, fired = 0, viol = 0, steps = 0, lc_exhausted = 0, sched_overrun = 0;
 };
 
 // `block_rel` = workgroup index within the handle's launch range (< NSG_CNT_SHARDS / 4).
 __device__ __forceinline__ void flush_counts(uint64_t* counters, int block_rel, const WaveCounts& wc) {
   const int lane = threadIdx.x & 63;
   if (counters && lane < NSG_CNT_COUNT) {
-    const unsigned v = lane == NSG_CNT_DONE ? wc.done : lane == NSG_CNT_FIRED ? wc.fired : lane == NSG_CNT_VIOLATION ? wc.viol : wc.steps;
+    const unsigned v = lane == NSG_CNT_DONE ? wc.done : lane == NSG_CNT_FIRED ? wc.fired : lane == NSG_CNT_VIOLATION ? wc.viol
+                     : lane == NSG_CNT_STEPS ? wc.steps : lane == NSG_CNT_LC_EXHAUSTED ? wc.lc_exhausted : wc.sched_overrun;
     // fire-and-forget add (no return value requested): the wavefront retires without waiting for a
     // read-modify-write round trip; the shard has a single owner per launch, so there is no contention
     if (v) atomicAdd((unsigned long long*)&counters[(int64_t)lane * kCntShards + block_rel * (kBlock / 64) + (threadIdx.x >> 6)],
@@ -247,8 +254,9 @@ template <typename T> __device__ __forceinline__ void stg_p(bool wt, T* base, ui
 // rest of the deep-copied init_initial_params (base.py:381-384).
 template <bool FULL>
 __device__ __forceinline__ bool fire_param(const nsg_config& cfg, const nsg_buffers& b, const Tables& tb, const ZigLds& zg,
-                                           int64_t N, int64_t i, int p, int t, bool eval, bool rewind) {
+                                           int64_t N, int64_t i, int p, int t, bool eval, bool rewind, unsigned& overrun) {
   const nsg_param_cfg& pc = cfg.params[p];
+  if (eval && sched_overrun(pc, t)) overrun = 1u;
   if constexpr (FULL) {
     if (sched_is_stochastic(pc.sched_kind)) {
       bool f = false;
@@ -390,7 +398,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   double th[T::NTHETA + T::NDERIVED];
 #pragma unroll
   for (int k = 0; k < T::NTHETA; k++) th[k] = cfg.base_theta[k];
-  unsigned n_fired = 0, n_viol = 0;
+  unsigned n_fired = 0, n_viol = 0, n_overrun = 0;
 
   if constexpr (ENV != NSG_ENV_ACROBOT) {
     // ---- single pass: propose, check, commit (classic_control.py:80-92) ----------------------
@@ -399,7 +407,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
       const int slot = pc.theta_slot;
       const double c = !active ? cfg.base_theta[slot] : p == 0 ? pre0 : p == 1 ? pre1 : ldg(b.theta + (int64_t)p * N, o8);
       double n = c;
-      bool fired = fire_param<FULL>(cfg, b, tb, zg, N, i, p, t, do_step && theta_live, do_reset && !persistent);
+      bool fired = fire_param<FULL>(cfg, b, tb, zg, N, i, p, t, do_step && theta_live, do_reset && !persistent, n_overrun);
       if (fired) {
         Pcg r = {0, 0, 0, 0};
         int cursor = 0;
@@ -448,7 +456,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
       const int slot = pc.theta_slot;
       const double c = !active ? cfg.base_theta[slot] : p == 0 ? pre0 : p == 1 ? pre1 : ldg(b.theta + (int64_t)p * N, o8);
       double n = c;
-      if (fire_param<FULL>(cfg, b, tb, zg, N, i, p, t, do_step && theta_live, do_reset && !persistent)) {
+      if (fire_param<FULL>(cfg, b, tb, zg, N, i, p, t, do_step && theta_live, do_reset && !persistent, n_overrun)) {
         Pcg r = {0, 0, 0, 0};
         int cursor = 0;
         const bool has_cur = upd_uses_cursor(pc.upd_kind);
@@ -631,6 +639,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     wc.fired += __popcll(__ballot((n_fired >> bit) & 1u)) << bit;
     wc.viol += __popcll(__ballot((n_viol >> bit) & 1u)) << bit;
   }
+  wc.sched_overrun += __popcll(__ballot(n_overrun != 0));
 }
 
 // ============================================================================================
@@ -704,7 +713,7 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
   if (do_step || (do_reset && ENV != NSG_ENV_BRIDGE)) r = pcg_double(gl.g);
 
   // ---- θ: every distribution parameter (toy_text.py:178-185, 362-366, 605-631) ---------------
-  unsigned n_fired = 0;
+  unsigned n_fired = 0, n_overrun = 0, n_exhausted = 0;
   double pt[ND];  // the probabilities the transition samples from
 #pragma unroll
   for (int k = 0; k < ND; k++) pt[k] = cfg.initial_prob[0][k];
@@ -723,7 +732,7 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
   }
   for (int p = 0; p < P; p++) {
     const nsg_param_cfg& pc = cfg.params[p];
-    const bool fired = fire_param<FULL>(cfg, b, tb, zg, N, i, p, t, do_step && theta_live, do_reset && !persistent);
+    const bool fired = fire_param<FULL>(cfg, b, tb, zg, N, i, p, t, do_step && theta_live, do_reset && !persistent, n_overrun);
     double delta = 0.0;
     double q[ND];
     bool have_q = false;
@@ -736,7 +745,9 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       if (has_cur) cursor = ldg(b.cursor + (int64_t)pc.fn_slot * N, o4);
       Pcg ur = {0, 0, 0, 0};
       if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, ur);
-      upd_dist<ND, FULL>(pc, tb, zg, pp, t, cursor, ur, q);
+      bool exhausted;
+      upd_dist<ND, FULL>(pc, tb, zg, pp, t, cursor, ur, q, exhausted);
+      n_exhausted |= exhausted ? 1u : 0u;
       if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, ur);
       if (has_cur && pc.upd_kind != NSG_UPD_D_LCBOUNDED) stg_p(io.wt, b.cursor + (int64_t)pc.fn_slot * N, o4, cursor);
       delta = w1_n<ND>(pp, q);  // base.py:192-203
@@ -879,6 +890,8 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
   wc.done += __popcll(done_mask);
   wc.steps += __popcll(__ballot(do_step));
   for (unsigned bit = 0; bit < 2; bit++) wc.fired += __popcll(__ballot((n_fired >> bit) & 1u)) << bit;
+  wc.sched_overrun += __popcll(__ballot(n_overrun != 0));
+  wc.lc_exhausted += __popcll(__ballot(n_exhausted != 0));
 }
 
 // One chunk of kBlock envs of any env type (block-level call: contains workgroup barriers).
@@ -935,28 +948,29 @@ __global__ __launch_bounds__(kBlock, NSG_MIN_WAVES) void step_kernel(const Segme
 
 // Heterogeneous launch: block ranges are assigned to env-type segments, so the env-type switch
 // is uniform per workgroup (no intra-wave divergence between Pendulum and Acrobot lanes).
-__device__ __forceinline__ int group_segment_of_block(const Segment* __restrict__ segs, int nseg) {
+__device__ __forceinline__ int group_segment_of_block(const GroupArgs& ga, int nseg) {
   int sidx = 0;  // block ranges are disjoint but not ordered by member index (the host places long-running env types first)
   for (int k = 1; k < nseg; k++)
-    if ((int)blockIdx.x >= segs[k].block_begin && (int)blockIdx.x < segs[k].block_begin + segs[k].block_count) sidx = k;
+    if ((int)blockIdx.x >= ga.block_begin[k] && (int)blockIdx.x < ga.block_begin[k] + ga.block_count[k]) sidx = k;
   return sidx;
 }
 
 template <bool FULL>
-__global__ __launch_bounds__(kBlock) void step_group_kernel(const Segment* __restrict__ segs, int nseg, ActionPtrs acts, int reverse) {
-  const int sidx = group_segment_of_block(segs, nseg);
-  const Segment& sg = segs[sidx];
+__global__ __launch_bounds__(kBlock) void step_group_kernel(GroupArgs ga, int nseg, ActionPtrs acts, int reverse) {
+  const int sidx = group_segment_of_block(ga, nseg);
+  const Segment& sg = *ga.seg[sidx];
   const void* actions = acts.p[sidx];
-  const int rel = (int)blockIdx.x - sg.block_begin;
+  const int rel = (int)blockIdx.x - ga.block_begin[sidx];
+  const int cnt = ga.block_count[sidx];
   switch (sg.cfg.env_type) {
-    case NSG_ENV_CARTPOLE: step_body<NSG_ENV_CARTPOLE, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
-    case NSG_ENV_PENDULUM: step_body<NSG_ENV_PENDULUM, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
-    case NSG_ENV_ACROBOT: step_body<NSG_ENV_ACROBOT, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
-    case NSG_ENV_MOUNTAINCAR: step_body<NSG_ENV_MOUNTAINCAR, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
-    case NSG_ENV_MOUNTAINCAR_CONT: step_body<NSG_ENV_MOUNTAINCAR_CONT, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
-    case NSG_ENV_FROZENLAKE: step_body<NSG_ENV_FROZENLAKE, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
-    case NSG_ENV_CLIFFWALKING: step_body<NSG_ENV_CLIFFWALKING, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
-    default: step_body<NSG_ENV_BRIDGE, FULL>(sg.cfg, sg, actions, rel, sg.block_count, reverse); break;
+    case NSG_ENV_CARTPOLE: step_body<NSG_ENV_CARTPOLE, FULL>(sg.cfg, sg, actions, rel, cnt, reverse); break;
+    case NSG_ENV_PENDULUM: step_body<NSG_ENV_PENDULUM, FULL>(sg.cfg, sg, actions, rel, cnt, reverse); break;
+    case NSG_ENV_ACROBOT: step_body<NSG_ENV_ACROBOT, FULL>(sg.cfg, sg, actions, rel, cnt, reverse); break;
+    case NSG_ENV_MOUNTAINCAR: step_body<NSG_ENV_MOUNTAINCAR, FULL>(sg.cfg, sg, actions, rel, cnt, reverse); break;
+    case NSG_ENV_MOUNTAINCAR_CONT: step_body<NSG_ENV_MOUNTAINCAR_CONT, FULL>(sg.cfg, sg, actions, rel, cnt, reverse); break;
+    case NSG_ENV_FROZENLAKE: step_body<NSG_ENV_FROZENLAKE, FULL>(sg.cfg, sg, actions, rel, cnt, reverse); break;
+    case NSG_ENV_CLIFFWALKING: step_body<NSG_ENV_CLIFFWALKING, FULL>(sg.cfg, sg, actions, rel, cnt, reverse); break;
+    default: step_body<NSG_ENV_BRIDGE, FULL>(sg.cfg, sg, actions, rel, cnt, reverse); break;
   }
 }
 
@@ -1044,7 +1058,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
       b.ep_return[i] = 0.f;
       b.ep_length[i] = 0;
     }
-    if (b.done_bits && (i & 63) == 0) b.done_bits[i >> 6] = 0;
+    // clear THIS env's bit of the ballot word only: a masked reset must neither wipe the bits of envs that are done but were
+    // not reset nor leave the bit of a reset env standing (nsg_compact_done reads these words)
+    if (b.done_bits) atomicAnd((unsigned long long*)&b.done_bits[i >> 6], ~(1ULL << (i & 63)));
   }
 }
 
@@ -1165,12 +1181,13 @@ __global__ __launch_bounds__(kBlock) void theta_trace_kernel(const Segment* __re
   for (int k = 0; k < T; k++) {
     const int t = t0 + k;
     const bool fired = stoch ? sched_fire_stoch(pc, zg, t, sr, snext) : sched_fire(pc, tb, t);
+    bool raised = sched_overrun(pc, t);  // the reference would have raised / needed an answer the table does not hold
     double delta = 0.0;
     if (fired) {
       if (dist) {
         double q[4] = {0, 0, 0, 0};
-        if (nd == 4) { upd_dist<4, true>(pc, tb, zg, th, t, cursor, r, q); delta = w1_n<4>(th, q); }
-        else { upd_dist<3, true>(pc, tb, zg, th, t, cursor, r, q); delta = w1_n<3>(th, q); }
+        if (nd == 4) { upd_dist<4, true>(pc, tb, zg, th, t, cursor, r, q, raised); delta = w1_n<4>(th, q); }
+        else { upd_dist<3, true>(pc, tb, zg, th, t, cursor, r, q, raised); delta = w1_n<3>(th, q); }
         for (int c = 0; c < nd; c++) th[c] = q[c];
       } else {
         double nvv = upd_scalar<true>(pc, tb, zg, th[0], t, r, cursor);
@@ -1184,7 +1201,7 @@ __global__ __launch_bounds__(kBlock) void theta_trace_kernel(const Segment* __re
     } else {
       theta_out[(int64_t)k * n + i] = th[0];
     }
-    fired_out[(int64_t)k * n + i] = fired ? 1 : 0;
+    fired_out[(int64_t)k * n + i] = raised ? (pc.upd_kind == NSG_UPD_D_LCBOUNDED && !sched_overrun(pc, t) ? 0xFF : 0xFE) : fired ? 1 : 0;
     delta_out[(int64_t)k * n + i] = delta;
   }
   if (pc.uses_rng && rng_state) pcg_store_all(rng_state, n, i, r);

@@ -34,11 +34,18 @@ __device__ __forceinline__ bool sched_fire(const nsg_param_cfg& pc, const Tables
     case NSG_SCHED_BURST: return (t % (int)(pc.sched_i0 + pc.sched_i1)) < (int)pc.sched_i0;
     case NSG_SCHED_TABLE: {
       if (t < 0) return false;
-      if (t >= pc.sched_tab_len) return pc.sched_i0 != 0;
+      if (t >= pc.sched_tab_len) return pc.sched_i0 == 1;  // 2: a sampled CustomScheduler beyond its horizon (sched_overrun)
       return (tb.bits(pc.sched_tab_off)[t >> 5] >> (t & 31)) & 1u;
     }
     default: return false;
   }
+}
+
+// A CustomScheduler is a Python callable sampled into a bit table over a horizon; asked about a later t (inside its
+// start / end gate) the table has no answer: the kernels count that (NSG_CNT_SCHED_OVERRUN) and the host raises.
+__device__ __forceinline__ bool sched_overrun(const nsg_param_cfg& pc, int t) {
+  const double td = (double)t;
+  return pc.sched_kind == NSG_SCHED_TABLE && pc.sched_i0 == 2 && t >= pc.sched_tab_len && pc.sched_start <= td && td <= pc.sched_end;
 }
 
 __host__ __device__ inline bool sched_is_stochastic(int k) {
@@ -182,7 +189,8 @@ template <int ND> __device__ __forceinline__ double w1_n(const double* a, const 
 // UpdateDistributionFn._update for the slip distributions of the grid wrappers (ND = 3 or 4).
 template <int ND, bool FULL>
 __device__ inline void upd_dist(const nsg_param_cfg& pc, const Tables& tb, const ZigLds& zg, const double* p, int t, int& cursor,
-                                Pcg& rng, double* q) {
+                                Pcg& rng, double* q, bool& exhausted) {
+  exhausted = false;
   const double* u = pc.u;
   const double td = (double)t;
 #pragma unroll
@@ -243,6 +251,7 @@ __device__ inline void upd_dist(const nsg_param_cfg& pc, const Tables& tb, const
       if constexpr (FULL) {
         const double d = u[0] * fabs(td - (double)(cursor - 1));
         if (u[1] != 0.0) break;  // inner DistributionNoUpdate: W1 = 0 <= d, accepted at once
+        exhausted = true;
         for (int tries = 0; tries < 100000; tries++) {  // max_trys = int(1e5); bounded, so the wave always drains
           double cand[ND], acc = 0.0;
 #pragma unroll
@@ -253,9 +262,10 @@ __device__ inline void upd_dist(const nsg_param_cfg& pc, const Tables& tb, const
           if (w1_n<ND>(p, cand) <= d) {
 #pragma unroll
             for (int k = 0; k < ND; k++) q[k] = cand[k];
+            exhausted = false;
             break;
           }
-        }  // exhausted: the reference raises ValueError; here the distribution stays unchanged
+        }  // exhausted: the reference raises ValueError (:178-182); here the distribution stays unchanged and the caller counts it
       }
       break;
     }

@@ -1,15 +1,20 @@
 // nsgym_hip.hip — C-ABI host side of libnsgym_hip.so (see include/nsgym_hip.h).
 // Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
 #include <hip/hip_runtime.h>
+#include <dirent.h>
 #include <sys/stat.h>
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <new>
+#include <sys/time.h>
 #include <unistd.h>
+
+#include <algorithm>
 
 #include "nsg_zig_tables.inc"
 #include "nsgym_hip.h"
@@ -23,7 +28,9 @@ using namespace nsg;
 namespace {
 
 thread_local char g_err[512] = "";
-thread_local unsigned long long g_generation = 0;  // bumped by nsg_destroy: invalidates cached group tables
+// Bumped whenever a handle's launch-relevant state changes (nsg_bind, nsg_specialize, nsg_destroy) - by any thread: what
+// nsg_step_group remembers about a member list (block ranges, the group's specialised unit) is valid for one generation.
+std::atomic<unsigned long long> g_generation{0};
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -165,8 +172,38 @@ std::string spec_cache_dir() {
     (void)mkdir(dir.c_str(), 0755);
     dir += "/ns_gym_amd";
   }
-  (void)mkdir(dir.c_str(), 0755);
+  (void)mkdir(dir.c_str(), 0700);   // code objects are loaded onto the GPU: nobody else gets to put files here
+  // refuse a directory that somebody else owns or can write to (a shared NSG_SPEC_CACHE must not let another user plant device code)
+  struct stat st;
+  if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return "";
   return dir;
+}
+
+// A cached object is used only if it is a regular file of this user that no one else may write.
+bool spec_cache_file_ok(const char* path) {
+  struct stat st;
+  return lstat(path, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && !(st.st_mode & (S_IWGRP | S_IWOTH));
+}
+
+// Keep the disk cache bounded: every distinct configuration (constructor seeds and update constants included - they are folded
+// into the unit) adds a ~60-KB file.  Beyond kSpecCacheMaxFiles the least recently used ones go (a cache hit refreshes a
+// file's timestamp).
+constexpr size_t kSpecCacheMaxFiles = 256;
+void spec_cache_evict(const std::string& dir) {
+  std::vector<std::pair<time_t, std::string>> files;
+  if (DIR* d = opendir(dir.c_str())) {
+    while (struct dirent* e = readdir(d)) {
+      const std::string name = e->d_name;
+      if (name.size() < 10 || name.compare(0, 4, "nsg_") != 0 || name.compare(name.size() - 6, 6, ".hsaco") != 0) continue;
+      struct stat st;
+      const std::string path = dir + "/" + name;
+      if (lstat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode)) files.emplace_back(st.st_mtime, path);
+    }
+    closedir(d);
+  }
+  if (files.size() <= kSpecCacheMaxFiles) return;
+  std::sort(files.begin(), files.end());
+  for (size_t k = 0; k + kSpecCacheMaxFiles < files.size(); k++) (void)remove(files[k].second.c_str());
 }
 
 // Look a code object up in the process cache, then in the disk cache (spec_cache_dir), else compile it; load it.
@@ -185,7 +222,7 @@ int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, cons
       char name[64];
       snprintf(name, sizeof(name), "/nsg_%016llx_%016llx.hsaco", (unsigned long long)h0, (unsigned long long)h1);
       path = dir + name;
-      if (FILE* f = fopen(path.c_str(), "rb")) {
+      if (FILE* f = spec_cache_file_ok(path.c_str()) ? fopen(path.c_str(), "rb") : nullptr) {
         fseek(f, 0, SEEK_END);
         const long n = ftell(f);
         fseek(f, 0, SEEK_SET);
@@ -194,6 +231,7 @@ int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, cons
           if (fread(code.data(), 1, (size_t)n, f) != (size_t)n) code.clear();
         }
         fclose(f);
+        if (!code.empty()) (void)utimes(path.c_str(), nullptr);   // least-recently-used eviction goes by this
       }
     }
     auto store = [&]() {  // through a temporary file + rename: concurrent processes (one per GPU) never see a partial object
@@ -202,7 +240,9 @@ int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, cons
       if (FILE* f = fopen(tmp.c_str(), "wb")) {
         const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
         fclose(f);
+        (void)chmod(tmp.c_str(), 0600);
         if (!ok || rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
+        else spec_cache_evict(dir);
       }
     };
     bool compiled_now = false;
@@ -314,11 +354,20 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
   if (!h) return fail(NSG_ENOMEM, "out of host memory");
   memset(h, 0, sizeof(*h));
   h->n = n;
-  HIP_TRY(hipGetDevice(&h->device));
+  // any failure below releases what was allocated so far (nsg_destroy frees the three device blocks and the handle)
+#define HIP_TRY_H(expr)                                                          \
+  do {                                                                           \
+    hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess) {                                                      \
+      (void)nsg_destroy(h);                                                      \
+      return fail(NSG_EHIP, "%s: %s", #expr, hipGetErrorString(e_));             \
+    }                                                                            \
+  } while (0)
+  HIP_TRY_H(hipGetDevice(&h->device));
   const size_t tb = ((table_bytes + 7) / 8) * 8 + 8;
-  HIP_TRY(hipMalloc((void**)&h->d_tables, tb));
-  HIP_TRY(hipMemset(h->d_tables, 0, tb));
-  if (table_bytes) HIP_TRY(hipMemcpy(h->d_tables, tables, table_bytes, hipMemcpyHostToDevice));
+  HIP_TRY_H(hipMalloc((void**)&h->d_tables, tb));
+  HIP_TRY_H(hipMemset(h->d_tables, 0, tb));
+  if (table_bytes) HIP_TRY_H(hipMemcpy(h->d_tables, tables, table_bytes, hipMemcpyHostToDevice));
   uint64_t zig[1536];
   memcpy(zig, NSG_ZIG_KI, 2048);
   memcpy(zig + 256, NSG_ZIG_WI_BITS, 2048);
@@ -326,9 +375,10 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
   memcpy(zig + 768, NSG_ZIGE_KE, 2048);
   memcpy(zig + 1024, NSG_ZIGE_WE_BITS, 2048);
   memcpy(zig + 1280, NSG_ZIGE_FE_BITS, 2048);
-  HIP_TRY(hipMalloc((void**)&h->d_zig, sizeof(zig)));
-  HIP_TRY(hipMemcpy(h->d_zig, zig, sizeof(zig), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc((void**)&h->dev, sizeof(Segment)));
+  HIP_TRY_H(hipMalloc((void**)&h->d_zig, sizeof(zig)));
+  HIP_TRY_H(hipMemcpy(h->d_zig, zig, sizeof(zig), hipMemcpyHostToDevice));
+  HIP_TRY_H(hipMalloc((void**)&h->dev, sizeof(Segment)));
+#undef HIP_TRY_H
   h->host.cfg = *cfg;
   h->host.N = n;
   h->host.tables = h->d_tables;
@@ -343,8 +393,6 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
     if (pc.upd_kind == NSG_UPD_D_RANDOMCAT || pc.upd_kind == NSG_UPD_D_LCBOUNDED || pc.sched_kind == NSG_SCHED_MEMORYLESS) h->host.uses_exp = 1;
     if (!upd_kind_is_simple(pc.upd_kind) || sched_is_stochastic(pc.sched_kind)) h->host.simple_theta = 0;
   }
-  h->host.block_begin = 0;
-  h->host.block_count = 0;
   *out = h;
   return NSG_OK;
 }
@@ -358,10 +406,11 @@ static int64_t layout_bytes(const nsg_layout& l) {
 }
 // Rows well beyond the 256-MiB Infinity Cache: the sparsely touched env stream records take the non-temporal path in the handle's
 // config-specialised kernels (nsg_rng.hip.h).  Measured on C1 (rows: 157 MB per 2^20 envs), nt against plain: 2^20 envs 29.4 vs
-// 25.2 us, 2^21 55.0 vs 47.0, 2^22 106.1 vs 112.4, 2^24 520 vs 530 - the switch sits at twice the cache.  NSG_NT_RECORDS=0/1 forces it.
+// 25.2 us, 2^21 (252 MB of rows) 55.0 vs 47.0, 2^22 (503 MB) 106.1 vs 112.4, 2^24 520 vs 530 - the switch sits at 1.5 x the cache.
+// NSG_NT_RECORDS=0/1 forces it.
 static int nt_records_for(const nsg_layout& l) {
   if (const char* e = getenv("NSG_NT_RECORDS")) return e[0] == '1';
-  return layout_bytes(l) > (512LL << 20);
+  return layout_bytes(l) > (384LL << 20);
 }
 
 static int grid_cap() {  // tuning knob (tools/kbench.py sweeps it); default from measurements
@@ -391,6 +440,7 @@ int nsg_bind(nsg_handle* h, const nsg_buffers* bufs) {
 #undef NEED
   h->host.buf = *bufs;
   h->host.nt_records = nt_records_for(lay);
+  g_generation++;
   HIP_TRY(hipMemcpy(h->dev, &h->host, sizeof(Segment), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(init_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, 0, h->dev);
   HIP_TRY(hipGetLastError());
@@ -491,24 +541,28 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
 
 int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* actions_dev, void* stream) {
   if (!hs || !actions_dev || n_handles <= 0 || n_handles > NSG_MAX_SEGMENTS) return fail(NSG_EINVAL, "bad group arguments");
-  // The group's segment table lives next to the first handle's device segment; it is
-  // (re)built only when the membership changes.
-  static thread_local Segment* d_group = nullptr;
-  static thread_local nsg_handle* members[NSG_MAX_SEGMENTS];
-  static thread_local int n_members = 0;
-  static thread_local unsigned long long built_at = ~0ULL;
-  static thread_local int total_blocks = 0;
-  static thread_local int all_simple = 0;
-  static thread_local int group_lds = 0;
-  static thread_local const nsg_spec::Module* group_spec = nullptr;
-  bool same = n_members == n_handles && built_at == g_generation;
-  for (int k = 0; same && k < n_handles; k++) same = members[k] == hs[k];
+  // Every launch carries its members' device segments and block ranges in its kernel arguments (GroupArgs): there is no
+  // table shared between launches.  What the calling thread remembers between calls is host-side only - the block ranges
+  // and the group's specialised unit for the last member list - and valid for one generation of the library's handles.
+  struct Plan {
+    nsg_handle* members[NSG_MAX_SEGMENTS];
+    int n_members = 0;
+    unsigned long long built_at = ~0ULL;
+    GroupArgs ga;
+    int total_blocks = 0, all_simple = 0, group_lds = 0, device = -1;
+    const nsg_spec::Module* group_spec = nullptr;
+  };
+  static thread_local Plan plan;
+  const unsigned long long gen = g_generation.load();
+  bool same = plan.n_members == n_handles && plan.built_at == gen;
+  for (int k = 0; same && k < n_handles; k++) same = plan.members[k] == hs[k];
   if (!same) {
-    Segment tmp[NSG_MAX_SEGMENTS];
     int order[NSG_MAX_SEGMENTS];
     for (int k = 0; k < n_handles; k++) {
       if (!hs[k] || !hs[k]->bound) return fail(NSG_ENOTBOUND, "group member %d is not bound", k);
-      tmp[k] = hs[k]->host;
+      if (hs[k]->device != hs[0]->device) return fail(NSG_EINVAL, "group member %d lives on device %d, member 0 on device %d", k, hs[k]->device, hs[0]->device);
+      for (int j = 0; j < k; j++)
+        if (hs[j] == hs[k]) return fail(NSG_EINVAL, "group member %d is listed twice", k);
       order[k] = k;
     }
     // workgroups are dispatched in block order: the members with the longest-running workgroups get the
@@ -519,30 +573,31 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
     };
     for (int a = 1; a < n_handles; a++)
       for (int b = a; b > 0 && cost(order[b]) > cost(order[b - 1]); b--) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+    memset(&plan.ga, 0, sizeof(plan.ga));
     int begin = 0;
     for (int j = 0; j < n_handles; j++) {
       const int k = order[j];
-      tmp[k].block_begin = begin;
-      tmp[k].block_count = grid_for(hs[k]->n);
-      begin += tmp[k].block_count;
+      plan.ga.seg[k] = hs[k]->dev;
+      plan.ga.block_begin[k] = begin;
+      plan.ga.block_count[k] = grid_for(hs[k]->n);
+      begin += plan.ga.block_count[k];
     }
-    if (!d_group) HIP_TRY(hipMalloc((void**)&d_group, sizeof(Segment) * NSG_MAX_SEGMENTS));
-    HIP_TRY(hipMemcpy(d_group, tmp, sizeof(Segment) * n_handles, hipMemcpyHostToDevice));
-    for (int k = 0; k < n_handles; k++) members[k] = hs[k];
-    n_members = n_handles;
-    built_at = g_generation;
-    total_blocks = begin;
-    all_simple = 1;
-    group_lds = 0;
+    for (int k = 0; k < n_handles; k++) plan.members[k] = hs[k];
+    plan.n_members = n_handles;
+    plan.built_at = gen;
+    plan.total_blocks = begin;
+    plan.device = hs[0]->device;
+    plan.all_simple = 1;
+    plan.group_lds = 0;
     bool all_spec = true;
     for (int k = 0; k < n_handles; k++) {
-      all_simple &= hs[k]->host.simple_theta;
+      plan.all_simple &= hs[k]->host.simple_theta;
       all_spec = all_spec && hs[k]->spec != nullptr;
       const int l = lds_bytes_for(hs[k]->host.table_bytes, hs[k]->host.uses_normal, hs[k]->host.uses_exp);
-      if (l > group_lds) group_lds = l;
+      if (l > plan.group_lds) plan.group_lds = l;
     }
     // every member runs config-specialised kernels: so does the group (one unit for the ordered tuple of configs)
-    group_spec = nullptr;
+    plan.group_spec = nullptr;
     if (all_spec) {
       uint64_t h0 = 0x67726f7570ull;  // "group"
       const nsg_config* cfgs[NSG_MAX_SEGMENTS];
@@ -559,8 +614,8 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
       HIP_TRY(hipGetDeviceProperties(&prop, hs[0]->device));
       const int rc = get_spec_module(hs[0]->device, h0, true,
                                      [&](std::string& err) { return nsg_spec::group_compile(cfgs, full, n_handles, prop.gcnArchName, err, nt); },
-                                     &group_spec);
-      if (rc) group_spec = nullptr;  // the generic group kernel stays in force
+                                     &plan.group_spec);
+      if (rc) plan.group_spec = nullptr;  // the generic group kernel stays in force
     }
   }
   ActionPtrs ap;
@@ -570,11 +625,12 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
     ap.p[k] = actions_dev[k];
   }
   int reverse = next_traversal(hs[0]);   // the members of a group alternate together
-  if (group_spec) {
-    void* args[] = {(void*)&d_group, (void*)&n_handles, (void*)&ap, (void*)&reverse};
-    HIP_TRY(hipModuleLaunchKernel(group_spec->group, total_blocks, 1, 1, kBlock, 1, 1, (unsigned)group_lds, (hipStream_t)stream, args, nullptr));
-  } else if (all_simple) hipLaunchKernelGGL(step_group_kernel<false>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, d_group, n_handles, ap, reverse);
-  else hipLaunchKernelGGL(step_group_kernel<true>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, d_group, n_handles, ap, reverse);
+  GroupArgs ga = plan.ga;
+  if (plan.group_spec) {
+    void* args[] = {(void*)&ga, (void*)&n_handles, (void*)&ap, (void*)&reverse};
+    HIP_TRY(hipModuleLaunchKernel(plan.group_spec->group, plan.total_blocks, 1, 1, kBlock, 1, 1, (unsigned)plan.group_lds, (hipStream_t)stream, args, nullptr));
+  } else if (plan.all_simple) hipLaunchKernelGGL(step_group_kernel<false>, dim3(plan.total_blocks), dim3(kBlock), (size_t)plan.group_lds, (hipStream_t)stream, ga, n_handles, ap, reverse);
+  else hipLaunchKernelGGL(step_group_kernel<true>, dim3(plan.total_blocks), dim3(kBlock), (size_t)plan.group_lds, (hipStream_t)stream, ga, n_handles, ap, reverse);
   HIP_TRY(hipGetLastError());
   return NSG_OK;
 }
@@ -667,20 +723,20 @@ int nsg_rng_fill(int32_t kind, const uint64_t* seeds_dev, int32_t n, int32_t spa
 int nsg_time_steps(nsg_handle* h, const void* actions_dev, int32_t iters, void* stream, float* ms_avg) {
   if (!h || !ms_avg || iters <= 0) return fail(NSG_EINVAL, "bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  hipEvent_t e0, e1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
-  HIP_TRY(hipEventRecord(e0, s));
-  for (int k = 0; k < iters; k++) {
-    int rc = nsg_step(h, actions_dev, stream);
-    if (rc) return rc;
-  }
-  HIP_TRY(hipEventRecord(e1, s));
-  HIP_TRY(hipEventSynchronize(e1));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  int rc = NSG_OK;
+  hipError_t he = hipEventCreate(&e0);
+  if (he == hipSuccess) he = hipEventCreate(&e1);
+  if (he == hipSuccess) he = hipEventRecord(e0, s);
+  for (int k = 0; he == hipSuccess && rc == NSG_OK && k < iters; k++) rc = nsg_step(h, actions_dev, stream);
+  if (he == hipSuccess && rc == NSG_OK) he = hipEventRecord(e1, s);
+  if (he == hipSuccess && rc == NSG_OK) he = hipEventSynchronize(e1);
+  if (he == hipSuccess && rc == NSG_OK) he = hipEventElapsedTime(&ms, e0, e1);
+  if (e0) (void)hipEventDestroy(e0);   // on every path
+  if (e1) (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  if (he != hipSuccess) return fail(NSG_EHIP, "nsg_time_steps: %s", hipGetErrorString(he));
   *ms_avg = ms / (float)iters;
   return NSG_OK;
 }
@@ -729,8 +785,10 @@ int nsg_specialize(nsg_handle* h) {
   h0 = nsg_spec::fnv1a(&nt, sizeof(nt), h0);
   h0 = nsg_spec::fnv1a(prop.gcnArchName, strlen(prop.gcnArchName), h0);
   if (const char* e = getenv("NSG_SPEC_FLAGS")) h0 = nsg_spec::fnv1a(e, strlen(e), h0);
-  return get_spec_module(h->device, h0, false,
-                         [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err, nt); }, &h->spec);
+  const int rc = get_spec_module(h->device, h0, false,
+                                 [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err, nt); }, &h->spec);
+  g_generation++;   // a group that contains this handle re-plans (its specialised unit depends on every member's)
+  return rc;
 }
 
 int nsg_is_specialized(const nsg_handle* h) { return h && h->spec ? 1 : 0; }

@@ -1,11 +1,24 @@
-"""Episode harness with the reference's result format (ns_gym/evaluate/run_experiment.py:91-148,
-206-217), batched: one episode per env instance, all stepped by the fused kernel.
+"""Episode harness with the reference's result format (ns_gym/evaluate/run_experiment.py:91-148, 206-217), batched and
+device-side: one episode per env instance, N episodes in lock-step on the GPU.
 
-The reference runs `run_episode(env, agent, seed, ...)` in a `multiprocessing.Pool` (one process per
-episode) and streams rows `[total_reward, SARNS, num_steps, seed, sample_id, time]` to a CSV.  Here
-the N episodes of a batch run in lock-step on the GPU; a finished env is masked out (the kernel's
-next-step autoreset keeps it stepping, its later steps are ignored), and the rows are written in the
-same column order with the same header.
+The reference runs `run_episode(env, agent, seed, ...)` in a `multiprocessing.Pool` (one process per episode): reset(seed),
+then `while not done and not truncated: act, step, append reward, num_steps += 1` with a break at `max_steps + 1`
+(run_experiment.py:108-129), and streams rows `[total_reward, SARNS, num_steps, seed, sample_id, time]` to a CSV (:133-141,
+206-217).  Here:
+
+  * open-loop action sources - the default uniform-random policy (the rollout policy of MCTS.py:162-181 and of BASELINE's
+    "random-action rollouts") or a caller-supplied `actions[T, N]` table - run through `nsg_rollout`: K wrapper steps per
+    launch with the env state in registers, the per-step outputs landing in `[K, N]` slices;
+  * the alive mask ("this env's episode has not ended yet"), the per-env reward sum and step count are computed ON THE DEVICE
+    from those slices (a cumulative sum over the K done flags): a finished env keeps stepping through the kernel's next-step
+    autoreset and is simply masked out, exactly like an env whose `while` loop has exited;
+  * there is NO host synchronisation per step: whether every episode has ended is read back once per K-step chunk, one chunk
+    late (the flag is copied to pinned memory asynchronously and looked at after the NEXT chunk has been enqueued), so the
+    host never stalls the device;
+  * a closed-loop `policy(state) -> actions` (it needs the observation of step k to choose action k) cannot be fused into a
+    K-step launch; it runs through `step()` with the same device-side masking and the same lagged, chunked end test.
+
+Rows come out in the reference's column order with the reference's header.
 """
 from __future__ import annotations
 
@@ -22,43 +35,125 @@ CSV_HEADER = ["total_reward", "State-Action-Reward-NextState", "num_steps", "see
 
 
 def random_policy(env) -> Callable:
-    """Uniform random actions generated on the device (the rollout policy of MCTS.py:162-181)."""
+    """Uniform random actions generated on the device (the rollout policy of MCTS.py:162-181).  Open-loop: `run_episodes`
+    recognises it and draws whole `[K, N]` chunks at once."""
+    f = _random_actions(env)
+
+    def policy(obs):
+        return f(1)[0]
+
+    policy._nsg_open_loop = f
+    return policy
+
+
+def _random_actions(env) -> Callable:
+    """k -> actions[k, N] on the device."""
     if env.action_is_float:
         lo, hi = env.spec.env_type.action_low, env.spec.env_type.action_high
-        return lambda obs: torch.rand(env.num_envs, device=env.device) * (hi - lo) + lo
-    return lambda obs: torch.randint(0, env.n_actions, (env.num_envs,), dtype=torch.int32, device=env.device)
+        return lambda k: torch.rand((k, env.num_envs), device=env.device) * (hi - lo) + lo
+    return lambda k: torch.randint(0, env.n_actions, (k, env.num_envs), dtype=torch.int32, device=env.device)
+
+
+class _LaggedFlag:
+    """`alive.any()` without stalling: the flag of chunk j is copied to pinned memory asynchronously and read once chunk j + 1
+    has been enqueued (by then the copy has long landed; the wait, if any, overlaps the queued work)."""
+
+    def __init__(self, device):
+        self.host = torch.ones(2, dtype=torch.bool).pin_memory()
+        self.events = [None, None]
+        self.device = device
+        self.j = 0
+
+    def push(self, alive_any: torch.Tensor) -> None:
+        slot = self.j & 1
+        self.host[slot:slot + 1].copy_(alive_any.reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.events[slot] = ev
+        self.j += 1
+
+    def previous_says_all_done(self) -> bool:
+        if self.j < 2:
+            return False
+        slot = self.j & 1          # the flag pushed one chunk ago
+        self.events[slot].synchronize()
+        return not bool(self.host[slot])
 
 
 def run_episodes(env, policy: Optional[Callable] = None, seed: int = 0, max_steps: Optional[int] = None,
-                 record_sarns: bool = False, sample_id=None) -> list:
-    """One episode per env of `env` (a VecNSEnv).  `policy(state_tensor) -> action tensor [N]`.
-    Returns rows `[total_reward, SARNS, num_steps, seed, sample_id, time]` (run_experiment.py:133-141);
-    SARNS is a list of (state, action, reward, next_state) tuples when `record_sarns`, else []."""
-    n = env.num_envs
-    policy = policy or random_policy(env)
+                 record_sarns: bool = False, sample_id=None, actions: Optional[torch.Tensor] = None, chunk: int = 64) -> list:
+    """One episode per env of `env` (a VecNSEnv).
+
+    `actions`: open-loop action table `[T, N]` (device tensor; step k of every env takes `actions[k]`), or
+    `policy`: `policy(state_tensor) -> action tensor [N]` (closed loop), or neither: uniform random actions.
+    Returns rows `[total_reward, SARNS, num_steps, seed, sample_id, time]` (run_experiment.py:133-141); SARNS is a list of
+    (state, action, reward, next_state) tuples per env when `record_sarns`, else []."""
+    n, dev = env.num_envs, env.device
     limit = max_steps if max_steps is not None else (env.cfg.max_episode_steps or 10_000)
+    total_steps = limit + 1                      # the reference breaks at num_steps == max_steps + 1 (run_experiment.py:127-129)
+    source = None                                # open-loop: k -> actions[k, N]
+    if actions is not None:
+        assert policy is None, "give either `actions` or `policy`"
+        table = actions.to(dev)
+        assert table.dim() == 2 and table.shape[1] == n and table.shape[0] >= 1
+        total_steps = min(total_steps, int(table.shape[0]))
+    elif policy is None:
+        source = _random_actions(env)
+    elif getattr(policy, "_nsg_open_loop", None) is not None:
+        source = policy._nsg_open_loop
     obs, _ = env.reset(seed=seed)
-    state = obs["state"].clone()
-    alive = torch.ones(n, dtype=torch.bool, device=env.device)
-    total = torch.zeros(n, dtype=torch.float64, device=env.device)
-    steps = torch.zeros(n, dtype=torch.int64, device=env.device)
-    traj = []
+    alive = torch.ones(n, dtype=torch.bool, device=dev)
+    total = torch.zeros(n, dtype=torch.float64, device=dev)
+    steps = torch.zeros(n, dtype=torch.int64, device=dev)
+    flag = _LaggedFlag(dev)
+    traj = []                                    # record_sarns: (state[K,N,..], action[K,N], reward[K,N], next_state[K,N,..], alive[K,N])
     t0 = time.time()
-    for _ in range(limit + 1):     # the reference breaks at max_steps + 1 (run_experiment.py:127-129)
-        a = policy(state)
-        obs, r, term, trunc, _info = env.step(a)
-        nxt = obs["state"]
-        total += torch.where(alive, r.to(torch.float64), torch.zeros_like(total))
-        steps += alive.to(torch.int64)
-        if record_sarns:
-            traj.append((state.cpu().numpy(), torch.as_tensor(a).cpu().numpy(), r.cpu().numpy().copy(),
-                         nxt.cpu().numpy().copy(), alive.cpu().numpy().copy()))
-        alive = alive & ~(term | trunc)
-        state = nxt.clone()
-        if not bool(alive.any()):
-            break
+    done_steps = 0
+    if actions is not None or source is not None:
+        # ---- open loop: K fused steps per launch (nsg_rollout), masks and sums from the [K, N] slices --------------------
+        state = obs["state"].clone() if record_sarns else None
+        while done_steps < total_steps:
+            k = min(int(chunk), total_steps - done_steps)
+            a = table[done_steps:done_steps + k] if actions is not None else source(k)
+            out = env.rollout(a, record=("obs", "reward", "terminated", "truncated") if record_sarns else ("reward", "terminated", "truncated"))
+            done = out["terminated"] | out["truncated"]                                   # [k, N]
+            ended_before = torch.cumsum(done.to(torch.int32), dim=0) - done.to(torch.int32)  # episodes ended strictly before step j
+            live = alive.unsqueeze(0) & (ended_before == 0)                                 # step j still belongs to the episode
+            total += (out["reward"].to(torch.float64) * live).sum(dim=0)
+            steps += live.sum(dim=0)
+            if record_sarns:
+                prev = torch.cat([state.unsqueeze(0), out["obs"][:-1]], dim=0)
+                traj.append((prev.cpu().numpy(), a.cpu().numpy(), out["reward"].cpu().numpy(), out["obs"].cpu().numpy(), live.cpu().numpy()))
+                state = out["obs"][-1].clone()
+            alive = alive & ~done.any(dim=0)
+            done_steps += k
+            flag.push(alive.any())
+            if flag.previous_says_all_done():
+                break
+    else:
+        # ---- closed loop: the policy needs step k's observation; step() per step, same device-side masking, lagged end test ----
+        state = obs["state"].clone()
+        while done_steps < total_steps:
+            k = min(int(chunk), total_steps - done_steps)
+            for _ in range(k):
+                a = policy(state)
+                obs, r, term, trunc, _info = env.step(a)
+                nxt = obs["state"]
+                total += torch.where(alive, r.to(torch.float64), torch.zeros_like(total))
+                steps += alive.to(torch.int64)
+                if record_sarns:
+                    traj.append((state.cpu().numpy()[None], torch.as_tensor(a).cpu().numpy()[None], r.cpu().numpy()[None].copy(),
+                                 nxt.cpu().numpy()[None].copy(), alive.cpu().numpy()[None].copy()))
+                alive = alive & ~(term | trunc)
+                state = nxt.clone()
+            done_steps += k
+            flag.push(alive.any())
+            if flag.previous_says_all_done():
+                break
+    total, steps = total.cpu().numpy(), steps.cpu().numpy()      # the one synchronisation the results need
     wall = time.time() - t0
-    total, steps = total.cpu().numpy(), steps.cpu().numpy()
+    if env.may_raise:
+        env.check_errors()
     seeds = (np.arange(n) + int(seed)) if np.isscalar(seed) else np.asarray(seed)
     ids = list(range(n)) if sample_id is None else list(sample_id)
     rows = []
@@ -66,8 +161,9 @@ def run_episodes(env, policy: Optional[Callable] = None, seed: int = 0, max_step
         sarns = []
         if record_sarns:
             for s, a, r, s2, al in traj:
-                if al[i]:
-                    sarns.append((np.asarray(s[i]).tolist(), np.asarray(a[i]).tolist(), float(r[i]), np.asarray(s2[i]).tolist()))
+                for j in range(s.shape[0]):
+                    if al[j, i]:
+                        sarns.append((np.asarray(s[j, i]).tolist(), np.asarray(a[j, i]).tolist(), float(r[j, i]), np.asarray(s2[j, i]).tolist()))
         rows.append([float(total[i]), sarns, int(steps[i]), int(seeds[i]), ids[i], wall])
     return rows
 

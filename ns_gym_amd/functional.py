@@ -50,7 +50,8 @@ def theta_trace(fn: UpdateFn, theta0, t0: int = 0, T: int = 1, n: int = 1, seeds
     nd = len(theta0) if dist else 0          # 3: FrozenLake / Bridge support, 4: CliffWalking
     env = (make("CliffWalking-v1") if nd == 4 else make("FrozenLake-v1")) if dist else make("CartPole-v1")
     kw = {"initial_prob_dist": [1.0] + [0.0] * (nd - 1)} if dist else {}
-    cfg, tables, _, _ = compile_config(env, {"P" if dist else "gravity": fn}, **kw)
+    # a sampled (Custom) scheduler must hold an answer for every t this trace asks about
+    cfg, tables, _, _ = compile_config(env, {"P" if dist else "gravity": fn}, table_horizon=int(t0) + int(T) + 1, **kw)
     h = C.c_void_p()
     _lib.check(lib.nsg_create(C.byref(cfg), tables, len(tables), max(n, 1), C.byref(h)), "nsg_create")
     try:
@@ -84,7 +85,12 @@ def theta_trace(fn: UpdateFn, theta0, t0: int = 0, T: int = 1, n: int = 1, seeds
                                                     fired.data_ptr(), delta.data_ptr(), stream), "nsg_theta_trace_stateful")
             state["started"] = True
         torch.cuda.synchronize(dev)
-        return th.cpu().numpy(), fired.cpu().numpy(), delta.cpu().numpy()
+        f = fired.cpu().numpy()
+        if (f == 0xFF).any():   # the reference raises from LCBoundedDistrubutionUpdate._update (distribution.py:178-182)
+            raise ValueError(f"Could not find a Lipschitz-continuous update after {int(1e5)} attempts (L={getattr(fn, 'L', None)})")
+        if (f == 0xFE).any():
+            raise ValueError("CustomScheduler asked about a t beyond the horizon its event function was sampled over")
+        return th.cpu().numpy(), f, delta.cpu().numpy()
     finally:
         lib.nsg_destroy(h)
 

@@ -11,7 +11,6 @@ import numpy as np
 from . import _abi as A
 from .base import Scheduler
 
-_DEFAULT_TABLE_HORIZON = 4096
 
 
 class ContinuousScheduler(Scheduler):
@@ -96,9 +95,16 @@ class WindowScheduler(Scheduler):
 
 
 class CustomScheduler(Scheduler):
-    """User-defined event function of t (ns_gym/schedulers.py:31-43).  An arbitrary Python
-    callable cannot run in the kernel; it is sampled once over the episode horizon
-    (TimeLimit's max_episode_steps, or `horizon=`) into a bit table."""
+    """User-defined event function of t (ns_gym/schedulers.py:31-43).  An arbitrary Python callable cannot run in the
+    kernel: it is sampled once into a bit table over t = 0 .. horizon.  The reference calls `event_function(t)` for ANY t,
+    so the table must cover every t the batch can reach:
+      * `horizon=` given: that many steps;
+      * env with a TimeLimit: 2 x max_episode_steps (an episode ends at max_episode_steps; a planning copy taken late in an
+        episode keeps the source's t while its own TimeLimit restarts, classic_control.py:168-180, so it can reach
+        t_src + max_episode_steps - 1);
+      * env WITHOUT a TimeLimit and no `horizon=`: refused at construction (ValueError) - t is unbounded there.
+    A t beyond the table (a copy of a copy, a `reset`-less run) is not answered silently: the scheduler does not fire, the
+    kernels count it (NSG_CNT_SCHED_OVERRUN) and `VecNSEnv.check_errors()` / the N = 1 adaptors raise."""
 
     def __init__(self, event_function, start=0, end=np.inf, horizon: int | None = None) -> None:
         super().__init__(start, end)
@@ -106,10 +112,18 @@ class CustomScheduler(Scheduler):
         self.horizon = horizon
 
     def _compile(self, tables, horizon):
-        h = self.horizon or horizon or _DEFAULT_TABLE_HORIZON
-        bits = np.array([1 if self.event_function(t) else 0 for t in range(int(h) + 1)], dtype=np.uint8)
+        if self.horizon is not None:
+            h = int(self.horizon)
+        elif horizon:
+            h = int(horizon)      # compile_config passes 2 x max_episode_steps, or the t a host-side call asks about
+        else:
+            raise ValueError("CustomScheduler: this env has no TimeLimit, so t is unbounded; pass horizon=<largest t the "
+                             "event function will be asked about> (the callable is sampled into a table, it cannot run on the GPU)")
+        if h + 1 > 8 * 12288:
+            raise ValueError(f"CustomScheduler: a horizon of {h} steps does not fit the kernels' 16-KiB constant tables")
+        bits = np.array([1 if self.event_function(t) else 0 for t in range(h + 1)], dtype=np.uint8)
         off, ln = tables.add_bits(bits)
-        return {"sched_kind": A.SCHED_TABLE, "sched_tab_off": off, "sched_tab_len": ln, "sched_i0": 0,
+        return {"sched_kind": A.SCHED_TABLE, "sched_tab_off": off, "sched_tab_len": ln, "sched_i0": 2,
                 **self._range()}
 
 

@@ -20,7 +20,8 @@ _INF = "inf"
 
 
 def compile_config(env, tunable_params: dict, *, change_notification=False, delta_change_notification=False,
-                   in_sim_change=False, scalar_reward=True, persistent_params=False, track_returns=False, initial_prob_dist=None, modified_rewards=None, is_sim_env=False, terminal_cliff=False, violation_mask=False):
+                   in_sim_change=False, scalar_reward=True, persistent_params=False, track_returns=False, initial_prob_dist=None, modified_rewards=None, is_sim_env=False, terminal_cliff=False, violation_mask=False,
+                   table_horizon=None):
     """Returns (Config, tables_blob: bytes, BaseEnvSpec, param_names)."""
     spec: BaseEnvSpec = from_gym_env(env)
     et = spec.env_type
@@ -127,7 +128,9 @@ def compile_config(env, tunable_params: dict, *, change_notification=False, delt
         pc.sched_slot = first_sched[id(fn.scheduler)]
         pc.sched_end = float("inf")
         fields = {}
-        fields.update(fn.scheduler._compile(tables, cfg.max_episode_steps or None))
+        # `table_horizon`: how far sampled (Custom) schedulers must reach when the caller knows the t it will ask about
+        # (host-side `scheduler(t)` / `fn(param, t)` calls); a batch derives it from its TimeLimit
+        fields.update(fn.scheduler._compile(tables, table_horizon or (2 * cfg.max_episode_steps if cfg.max_episode_steps > 0 else None)))
         fields.update(fn._compile(tables))
         for key, val in fields.items():
             if key == "u":

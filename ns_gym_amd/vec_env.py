@@ -122,6 +122,7 @@ class VecNSEnv:
         self._spaces = None   # built on first use: planning copies are made per simulation and rarely look at them
         self._zero_flags = None
         self._viol_seen = 0
+        self._err_seen = [0, 0]
 
     def specialize(self):
         """Route this batch's step()/rollout() through kernels compiled for ITS configuration (nsg_specialize)."""
@@ -314,7 +315,35 @@ class VecNSEnv:
         """Running totals produced by the kernels' wavefront ballots (synchronises)."""
         c = self.buf["counters"].view(A.CNT_COUNT, A.CNT_SHARDS).sum(dim=1).tolist()
         return {"episodes": int(c[A.CNT_DONE]), "updates_applied": int(c[A.CNT_FIRED]),
-                "constraint_violations": int(c[A.CNT_VIOLATION]), "env_steps": int(c[A.CNT_STEPS])}
+                "constraint_violations": int(c[A.CNT_VIOLATION]), "env_steps": int(c[A.CNT_STEPS]),
+                "lc_exhausted": int(c[A.CNT_LC_EXHAUSTED]), "scheduler_overruns": int(c[A.CNT_SCHED_OVERRUN])}
+
+    @property
+    def may_raise(self) -> bool:
+        """This configuration contains an update function / scheduler for which the reference can raise mid-run
+        (LCBounded's rejection loop, a sampled CustomScheduler): the kernels count such events, `check_errors` raises."""
+        return any(self.cfg.params[p].upd_kind == A.UPD_D_LCBOUNDED
+                   or (self.cfg.params[p].sched_kind == A.SCHED_TABLE and self.cfg.params[p].sched_i0 == 2)
+                   for p in range(self.cfg.n_params))
+
+    def check_errors(self) -> None:
+        """Raise what the reference would have raised inside `step()` (synchronises).  A kernel cannot raise, so it counts:
+          * LCBoundedDistrubutionUpdate found no candidate within its Lipschitz bound in 1e5 tries -> ValueError
+            (ns_gym/update_functions/distribution.py:168-182);
+          * a CustomScheduler was asked about a t beyond the horizon its callable was sampled over (the reference would
+            simply have called it, ns_gym/schedulers.py:31-43) -> ValueError naming the remedy.
+        `step()` itself never synchronises; the N = 1 adaptors call this after every step, `run_episodes` at its end, a
+        training loop whenever it reads results back."""
+        c = self.counters()
+        if c["lc_exhausted"] > self._err_seen[0]:
+            n, self._err_seen[0] = c["lc_exhausted"] - self._err_seen[0], c["lc_exhausted"]
+            L = [self.cfg.params[p].u[0] for p in range(self.cfg.n_params) if self.cfg.params[p].upd_kind == A.UPD_D_LCBOUNDED]
+            raise ValueError(f"Could not find a Lipschitz-continuous update after {int(1e5)} attempts (L={L[0] if L else None}) "
+                             f"in {n} (env, step) case(s); those distributions were left unchanged")
+        if c["scheduler_overruns"] > self._err_seen[1]:
+            n, self._err_seen[1] = c["scheduler_overruns"] - self._err_seen[1], c["scheduler_overruns"]
+            raise ValueError(f"a CustomScheduler was asked {n} time(s) about a t beyond the horizon its event function was sampled "
+                             f"over (it did not fire there); construct it with horizon=<largest t reached>")
 
     def check_constraints(self) -> int:
         """Aggregated ConstraintViolationWarning (the reference warns per violation,

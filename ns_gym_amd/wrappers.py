@@ -150,6 +150,8 @@ class _NSSingle:
         self._act.fill_(float(np.asarray(action, dtype=np.float64).reshape(-1)[0]) if v.action_is_float else int(action))
         v.step(self._act)
         o, inf = self._scalars()
+        if v.may_raise:      # what the reference raises inside step() (LCBounded exhaustion, see VecNSEnv.check_errors)
+            v.check_errors()
         h = self._host
         r = float(h["reward"][0])
         terminated, truncated = bool(h["terminated"][0]), bool(h["truncated"][0])

@@ -191,7 +191,7 @@ static int sched_fire(const nsg_param_cfg* pc, const uint8_t* tables, int t) {
     case NSG_SCHED_BURST: return (t % (pc->sched_i0 + pc->sched_i1)) < pc->sched_i0; /* :139-140 */
     case NSG_SCHED_TABLE: {                                       /* :73-74, :197-198, :42-43 */
       if (t < 0) return 0;
-      if (t >= pc->sched_tab_len) return (int)pc->sched_i0;
+      if (t >= pc->sched_tab_len) return pc->sched_i0 == 1; /* 2 = a sampled callable beyond its horizon: the reference would call it; no answer here */
       const uint32_t* bits = (const uint32_t*)tables + pc->sched_tab_off;
       return (bits[t >> 5] >> (t & 31)) & 1;
     }

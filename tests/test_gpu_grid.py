@@ -39,7 +39,7 @@ def test_grid_hip_matches_oracle_at_scale(name):
         compare_views(g.step(acts[k]), o.step(acts[k]), True, f"step {k}")
     c = g.env.counters()
     oc = o.env.a["counters"].sum(axis=1)
-    assert [c["episodes"], c["updates_applied"], c["constraint_violations"], c["env_steps"]] == [int(x) for x in oc]
+    assert [c["episodes"], c["updates_applied"], c["constraint_violations"], c["env_steps"]] == [int(x) for x in oc[:4]]
     g.env.close()
 
 

@@ -1,0 +1,138 @@
+"""Host-side robustness of the heterogeneous launch (nsg_step_group) and of the done-mask words under a masked reset.
+
+nsg_step_group carries its members' device segments and block ranges in the kernel arguments of every launch; what the
+library remembers about a member list is invalidated whenever a handle is bound, specialised or destroyed - by any thread.
+These tests drive exactly the sequences that a cached, shared table got wrong: alternating member lists on a side stream
+without synchronising, specialising a member after the group's first launch, destroying a member and creating a new env
+(whose handle may reuse the address), and a destroy from another thread."""
+import threading
+
+import numpy as np
+import pytest
+
+from tests.util import TRAJ_SPECS, make_env_from_spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _vec(*a, **k):
+    from ns_gym_amd.vec_env import VecNSEnv
+
+    return VecNSEnv(*a, **k)
+
+
+def _acts(env, T, seed):
+    import torch
+
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    if env.action_is_float:
+        return torch.rand((T, env.N), device="cuda", generator=g) * 4 - 2
+    return torch.randint(0, env.n_actions, (T, env.N), dtype=torch.int32, device="cuda", generator=g)
+
+
+def _same(a, b):
+    import torch
+
+    for row in ("theta", "t", "reward", "terminated", "truncated", "status", "obs", "cell"):
+        if a.buf[row] is not None:
+            assert torch.equal(a.buf[row], b.buf[row]), row
+
+
+def _pair(name, n, **kw):
+    a, b = (make_env_from_spec(_vec, TRAJ_SPECS[name], n=n, **kw) for _ in range(2))
+    a.reset(seed=3); b.reset(seed=3)
+    return a, b
+
+
+def test_alternating_groups_on_a_side_stream_without_sync():
+    import torch
+
+    from ns_gym_amd.vec_env import step_group
+
+    T = 40
+    (p, p_ref), (a, a_ref) = _pair("c4_pendulum_m_inc", 40000, specialize=False), _pair("c4_acrobot_mass2_inc", 30000, specialize=False)
+    (c, c_ref), (f, f_ref) = _pair("c1_cartpole_masspole_inc", 50000, specialize=False), _pair("c3_frozenlake_step50", 20000, specialize=False)
+    acts = {e: _acts(e, T, k) for k, e in enumerate((p, a, c, f))}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for k in range(T):   # two member lists alternate back to back: no launch may see the other's segments
+            step_group([p, a], [acts[p][k], acts[a][k]])
+            step_group([f, c, a], [acts[f][k], acts[c][k], acts[a][k]]) if k % 2 else step_group([c, f], [acts[c][k], acts[f][k]])
+    side.synchronize()
+    for k in range(T):
+        p_ref.step(acts[p][k]); a_ref.step(acts[a][k]); c_ref.step(acts[c][k]); f_ref.step(acts[f][k])
+        if k % 2:
+            a_ref.step(acts[a][k])
+    torch.cuda.synchronize()
+    for x, y in ((p, p_ref), (a, a_ref), (c, c_ref), (f, f_ref)):
+        _same(x, y)
+    for e in (p, a, c, f, p_ref, a_ref, c_ref, f_ref):
+        e.close()
+
+
+def test_group_follows_specialise_destroy_and_recreate():
+    import torch
+
+    from ns_gym_amd.vec_env import step_group
+
+    T = 12
+    (p, p_ref), (c, c_ref) = _pair("c4_pendulum_m_inc", 9000, specialize=False), _pair("c1_cartpole_masspole_inc", 7000, specialize=False)
+    ap, ac = _acts(p, 3 * T, 1), _acts(c, 3 * T, 2)
+    for k in range(T):
+        step_group([p, c], [ap[k], ac[k]])
+    p.specialize(); c.specialize()           # after the group's first launches: the group must pick the new units up
+    for k in range(T, 2 * T):
+        step_group([p, c], [ap[k], ac[k]])
+    for k in range(2 * T):
+        p_ref.step(ap[k]); c_ref.step(ac[k])
+    _same(p, p_ref); _same(c, c_ref)
+    # destroy a member from ANOTHER thread, create a new env (its handle may land on the freed address): the remembered
+    # plan for [p, c] must not be applied to [p, c2]
+    th = threading.Thread(target=c.close)
+    th.start(); th.join()
+    c2 = make_env_from_spec(_vec, TRAJ_SPECS["c3_frozenlake_step50"], n=5000, specialize=False)
+    c2_ref = make_env_from_spec(_vec, TRAJ_SPECS["c3_frozenlake_step50"], n=5000, specialize=False)
+    c2.reset(seed=9); c2_ref.reset(seed=9)
+    a2 = _acts(c2, T, 5)
+    for k in range(T):
+        step_group([p, c2], [ap[2 * T + k], a2[k]])
+        p_ref.step(ap[2 * T + k]); c2_ref.step(a2[k])
+    torch.cuda.synchronize()
+    _same(p, p_ref); _same(c2, c2_ref)
+    for e in (p, p_ref, c_ref, c2, c2_ref):
+        e.close()
+
+
+def test_group_refuses_duplicates():
+    from ns_gym_amd._lib import NsgError
+    from ns_gym_amd.vec_env import step_group
+
+    p = make_env_from_spec(_vec, TRAJ_SPECS["c4_pendulum_m_inc"], n=1000, specialize=False)
+    p.reset(seed=0)
+    a = _acts(p, 1, 0)
+    with pytest.raises(NsgError, match="listed twice"):
+        step_group([p, p], [a[0], a[0]])
+    p.close()
+
+
+@pytest.mark.parametrize("name", ["c1_cartpole_masspole_inc", "c3_frozenlake_step50"])
+def test_masked_reset_keeps_the_other_envs_done_bits(name):
+    """nsg_reset(mask): the ballot words that nsg_compact_done expands must lose exactly the bits of the envs that were reset."""
+    import torch
+
+    n = 10007
+    env = make_env_from_spec(_vec, TRAJ_SPECS[name], n=n, specialize=False)
+    env.reset(seed=1)
+    acts = _acts(env, 40, 3)
+    for k in range(40):
+        env.step(acts[k])
+    done = (env.terminated | env.truncated).cpu().numpy()
+    assert done.sum() > 50
+    rng = np.random.default_rng(0)
+    mask = rng.random(n) < 0.5                      # resets done and not-done envs alike, lane 0 of a wavefront or not
+    env.reset(mask=torch.from_numpy(mask).cuda())
+    want = np.flatnonzero(done & ~mask)
+    got = np.sort(env.done_indices().cpu().numpy())
+    np.testing.assert_array_equal(got, want)
+    env.close()

@@ -161,7 +161,7 @@ def test_hip_matches_oracle_at_scale(name):
     # counters (wavefront ballot reductions) against the oracle's serial counts
     c = g.env.counters()
     oc = o.env.a["counters"].sum(axis=1)
-    assert [c["episodes"], c["updates_applied"], c["constraint_violations"], c["env_steps"]] == [int(x) for x in oc]
+    assert [c["episodes"], c["updates_applied"], c["constraint_violations"], c["env_steps"]] == [int(x) for x in oc[:4]]
     # episode returns of the last finished episodes
     lr, ll = g.env.episode_returns()
     np.testing.assert_array_equal(ll.cpu().numpy(), o.env.a["last_length"])

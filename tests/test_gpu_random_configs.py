@@ -137,7 +137,7 @@ def test_random_configuration_matches_oracle(case):
     c = g.env.counters()
     oc = o.env.a["counters"].sum(axis=1)
     if spec["env_id"] != "Acrobot-v1":
-        assert [c["episodes"], c["updates_applied"], c["constraint_violations"], c["env_steps"]] == [int(x) for x in oc], tag
+        assert [c["episodes"], c["updates_applied"], c["constraint_violations"], c["env_steps"]] == [int(x) for x in oc[:4]], tag
     g.env.close()
 
 
@@ -228,5 +228,5 @@ def test_random_configuration_fused_rollout_matches_oracle(case):
         k += K
         compare_views(g._out(), o._out(), is_grid, tag + f" after {k} steps")
     c = env.counters()
-    assert [c["episodes"], c["updates_applied"], c["constraint_violations"], c["env_steps"]] == [int(x) for x in o.env.a["counters"].sum(axis=1)], tag
+    assert [c["episodes"], c["updates_applied"], c["constraint_violations"], c["env_steps"]] == [int(x) for x in o.env.a["counters"].sum(axis=1)[:4]], tag
     env.close()

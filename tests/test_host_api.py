@@ -111,7 +111,18 @@ def test_table_schedulers_compile_to_reference_fire_patterns():
     assert (pc.sched_start, pc.sched_end) == (3.0, 50.0)
     cfg, blob, _, _ = mk(CustomScheduler(lambda t: t % 7 == 3))
     bits, pc = _table_bits(cfg, blob)
-    assert pc.sched_tab_len == 501 and [t for t, b in enumerate(bits) if b][:3] == [3, 10, 17]  # horizon = TimeLimit 500
+    # sampled over 2 x TimeLimit (a planning copy taken late in an episode runs on to t_src + 500 - 1); beyond it: "unknown" (2)
+    assert pc.sched_tab_len == 1001 and [t for t, b in enumerate(bits) if b][:3] == [3, 10, 17] and pc.sched_i0 == 2
+    cfg, blob, _, _ = mk(CustomScheduler(lambda t: t == 2, horizon=64))
+    assert cfg.params[0].sched_tab_len == 65
+    # an env without a TimeLimit has no bound on t: the callable cannot be sampled without being told how far (reference: it is
+    # simply called with any t, ns_gym/schedulers.py:31-43)
+    from ns_gym_amd.update_functions import DistributionNoUpdate
+    with pytest.raises(ValueError, match="no TimeLimit"):
+        compile_config(make("CliffWalking-v1", max_episode_steps=None), {"P": DistributionNoUpdate(CustomScheduler(lambda t: t == 2))},
+                       initial_prob_dist=[1, 0, 0, 0])
+    compile_config(make("CliffWalking-v1", max_episode_steps=None), {"P": DistributionNoUpdate(CustomScheduler(lambda t: t == 2, horizon=5000))},
+                   initial_prob_dist=[1, 0, 0, 0])
     cfg, _, _, _ = mk(BurstScheduler(3, 2, start=1))
     assert (cfg.params[0].sched_kind, cfg.params[0].sched_i0, cfg.params[0].sched_i1) == (A.SCHED_BURST, 3, 2)
 
