@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NSG_ABI_VERSION 2
+#define NSG_ABI_VERSION 3
 #define NSG_MAX_PARAMS 8 /* tunable params per env (Acrobot has 8: ns_gym/base.py:622-631) */
 #define NSG_MAX_THETA 8
 #define NSG_MAX_SEGMENTS 8 /* env-type segments of one heterogeneous launch */
@@ -116,8 +116,13 @@ enum {
 #define NSG_F_SIM_ENV 0x40u        /* planning copy: is_sim_env (base.py:270, classic_control.py:184)   */
 #define NSG_F_IN_SIM_CHANGE 0x80u  /* in_sim_change: θ keeps evolving inside planning copies            */
 
-/* per-env status byte (buffers.status) */
+/* per-env status: grid envs keep a byte (buffers.status); classic-control envs keep an episode WORD (buffers.episode):
+ * bit 0 = NSG_ST_NEEDS_RESET, bits 1-31 = how many resets the env has drawn from its np_random stream so far (= the index of
+ * its next episode in that stream, see buffers.rng_env) */
 #define NSG_ST_NEEDS_RESET 0x1u
+#define NSG_EP_COUNT_SHIFT 1
+/* classic-control env streams: descriptor word 0 of buffers.rng_env (see there) */
+#define NSG_STREAM_AFFINE (1ULL << 63)
 
 /* device-side counters: uint64 running totals, one shard per wavefront slot of a launch.
  * buffers.counters is [NSG_CNT_COUNT][NSG_CNT_SHARDS]; a total is the sum over its shards.
@@ -213,10 +218,23 @@ typedef struct nsg_buffers {
   int32_t* t_fork;       /* [N]    planning copies only: t at fork time.  __deepcopy__ builds a fresh
                             gym.make() env, so TimeLimit's elapsed count restarts at 0 while the
                             wrapper's t is preserved (classic_control.py:168-180)              */
-  uint8_t* status;       /* [N]    NSG_ST_* bits                                          */
-  uint64_t* rng_env;     /* env np_random PCG64 streams: state_hi,state_lo,inc_hi,inc_lo.  Classic-control envs:
-                            [N][4], one 32-byte record per env (touched by the few lanes that reset);
-                            grid envs: chunk-blocked rows [ceil(N/256)][4][256] (every lane draws one uniform per step) */
+  uint8_t* status;       /* [N]    grid envs: NSG_ST_* bits (classic-control envs: NULL, see episode)          */
+  int32_t* episode;      /* [N]    classic-control envs: NSG_ST_NEEDS_RESET | resets drawn so far << 1.  A dense row that every
+                            step reads and rewrites; with it the env's np_random needs NO per-env stream state (rng_env)  */
+  uint64_t* rng_env;     /* env np_random (gymnasium seeding [UPSTREAM]; PCG64(SeedSequence(seed))).
+                            Grid envs draw one uniform per env per step: chunk-blocked state rows [ceil(N/256)][4][256]
+                            (state_hi, state_lo, inc_hi, inc_lo).
+                            Classic-control envs draw ONLY in reset() (D doubles: CartPole / Acrobot 4, Pendulum 2,
+                            MountainCar 1), so episode e of env i starts from draws [D*e, D*e + D) of the stream seeded
+                            with seed_i - a pure function of (seed_i, e) that the kernels re-derive by PCG64 jump-ahead
+                            instead of round-tripping a 32-byte record through HBM at every reset (measured: those records
+                            cost a 2^22-env CartPole step 24 %, nsg_rng.hip.h).  Layout [N + 1][2]:
+                              [0]      stream descriptor: word 0 = NSG_STREAM_AFFINE | (uint32) spawn key, word 1 = base seed.
+                                       AFFINE: env i is seeded base + i (gymnasium's vector-env convention; what
+                                       nsg_reset_seeded, nsg_bind and nsg_fork install) and records 1.. are not read;
+                              [1 + i]  (seed_i, spawn key_i) of env i, read by the few lanes that reset, when the streams are
+                                       not affine (nsg_reset / nsg_seed_streams with an arbitrary seed array).
+                            Spawn key -1 = none: SeedSequence(seed); k >= 0: SeedSequence(seed, spawn_key=(k,))              */
   uint64_t* rng_upd;     /* [P][N][4] update-fn PCG64 streams (only rows with uses_rng)   */
   uint64_t* rng_sched;   /* [P][N][4] PCG64 records of stochastic schedulers (Random, DecayingProbability,
                             Memoryless).  A scheduler lives inside the deep-copied init_initial_params, so a
@@ -250,7 +268,7 @@ typedef struct nsg_layout {
   int64_t n;
   int32_t phys_dim, obs_dim, n_params, n_theta_rows, action_is_float;
   int32_t n_actions;           /* discrete action count, 0 for continuous                  */
-  int64_t phys, cell, theta, table_prob, derived, t, t_fork, status, rng_env, rng_upd, rng_sched, sched_next, cursor, obs, reward, terminated,
+  int64_t phys, cell, theta, table_prob, derived, t, t_fork, status, episode, rng_env, rng_upd, rng_sched, sched_next, cursor, obs, reward, terminated,
       truncated, env_change, delta_change, violation, prob, ep_return, ep_length, last_return, last_length,
       counters, done_bits;
 } nsg_layout;
@@ -281,6 +299,16 @@ int nsg_bind(nsg_handle* h, const nsg_buffers* bufs);
  * (mask NULL = all).  seeds_dev NULL = reset(seed=None): env and update-fn streams
  * continue; otherwise env i is seeded with seeds_dev[i] exactly like reset(seed=seeds[i]). */
 int nsg_reset(nsg_handle* h, const uint64_t* seeds_dev, const uint8_t* mask_dev, void* stream);
+
+/* reset(seed=s) for ALL envs with gymnasium's vector-env convention: env i is seeded base_seed + i, exactly like
+ * nsg_reset with seeds_dev[i] = base_seed + i.  For the classic-control envs this keeps the streams in their affine form
+ * (buffers.rng_env): no per-env seed record is read when an env resets. */
+int nsg_reset_seeded(nsg_handle* h, uint64_t base_seed, void* stream);
+
+/* Host-side construction of the PCG64 jump-ahead table the kernels use (nsg_rng.hip.h): 5 x 256 x 4 uint64 words
+ * (A_hi, A_lo, G_hi, G_lo for the exponent v * 256^d).  No GPU needed; exported so that the table can be checked against
+ * plain big-integer arithmetic (tests/test_jump_table_cpu.py). */
+void nsg_pcg64_jump_table(uint64_t* out_words);
 
 /* Replaces NSClassicControlWrapper.step / NSFrozenLakeWrapper.step -> NSWrapper.step ->
  * gymnasium step (classic_control.py:60-100, toy_text.py:342-380, base.py:296-363) for all

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-NSG_ABI_VERSION = 2
+NSG_ABI_VERSION = 3
 NSG_MAX_PARAMS = 8
 NSG_MAX_THETA = 8
 NSG_MAX_SEGMENTS = 8
@@ -37,6 +37,8 @@ F_SIM_ENV = 0x40
 F_IN_SIM_CHANGE = 0x80
 
 ST_NEEDS_RESET = 0x1
+EP_COUNT_SHIFT = 1          # episode word of the classic-control envs: resets drawn so far << 1 | needs-reset
+STREAM_AFFINE = 1 << 63     # descriptor word 0 of buffers.rng_env (classic-control envs)
 
 CNT_DONE, CNT_FIRED, CNT_VIOLATION, CNT_STEPS, CNT_LC_EXHAUSTED, CNT_SCHED_OVERRUN = 0, 1, 2, 3, 4, 5
 CNT_COUNT = 6
@@ -90,7 +92,7 @@ class Config(C.Structure):
 
 BUFFER_FIELDS = [
     ("phys", C.c_double), ("cell", C.c_int32), ("theta", C.c_double), ("table_prob", C.c_double), ("derived", C.c_double), ("t", C.c_int32), ("t_fork", C.c_int32),
-    ("status", C.c_uint8), ("rng_env", C.c_uint64), ("rng_upd", C.c_uint64), ("rng_sched", C.c_uint64), ("sched_next", C.c_int32), ("cursor", C.c_int32),
+    ("status", C.c_uint8), ("episode", C.c_int32), ("rng_env", C.c_uint64), ("rng_upd", C.c_uint64), ("rng_sched", C.c_uint64), ("sched_next", C.c_int32), ("cursor", C.c_int32),
     ("obs", C.c_float), ("reward", C.c_float), ("terminated", C.c_uint8), ("truncated", C.c_uint8),
     ("env_change", C.c_uint8), ("delta_change", C.c_float), ("violation", C.c_uint8), ("prob", C.c_float),
     ("ep_return", C.c_float), ("ep_length", C.c_int32), ("last_return", C.c_float),

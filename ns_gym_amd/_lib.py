@@ -12,8 +12,8 @@ LIB_PATH = os.environ.get("NSG_LIB", os.path.join(_PKG, "libnsgym_hip.so"))  # N
 _lib = None
 
 EXPORTS = [
-    "nsg_abi_version", "nsg_last_error", "nsg_sizeof_config", "nsg_sizeof_buffers", "nsg_sizeof_layout",
-    "nsg_layout_query", "nsg_create", "nsg_bind", "nsg_reset", "nsg_step", "nsg_rollout", "nsg_step_group",
+    "nsg_abi_version", "nsg_last_error", "nsg_sizeof_config", "nsg_sizeof_buffers", "nsg_sizeof_layout", "nsg_pcg64_jump_table",
+    "nsg_layout_query", "nsg_create", "nsg_bind", "nsg_reset", "nsg_reset_seeded", "nsg_step", "nsg_rollout", "nsg_step_group",
     "nsg_fork", "nsg_seed_streams",
     "nsg_compact_done", "nsg_theta_trace", "nsg_theta_trace_stateful", "nsg_rng_fill", "nsg_time_steps", "nsg_calib_copy_f64", "nsg_destroy",
     "nsg_specialize", "nsg_is_specialized", "nsg_spec_build", "nsg_spec_free",
@@ -61,6 +61,9 @@ def load():
     lib.nsg_create.argtypes = [C.POINTER(A.Config), vp, C.c_size_t, i64, C.POINTER(vp)]
     lib.nsg_bind.argtypes = [vp, C.POINTER(A.Buffers)]
     lib.nsg_reset.argtypes = [vp, vp, vp, vp]
+    lib.nsg_reset_seeded.argtypes = [vp, C.c_uint64, vp]
+    lib.nsg_pcg64_jump_table.argtypes = [vp]
+    lib.nsg_pcg64_jump_table.restype = None
     lib.nsg_step.argtypes = [vp, vp, vp]
     lib.nsg_rollout.argtypes = [vp, vp, i32, C.POINTER(A.RolloutOut), vp]
     lib.nsg_step_group.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), vp]
@@ -73,7 +76,7 @@ def load():
     lib.nsg_time_steps.argtypes = [vp, vp, i32, vp, C.POINTER(C.c_float)]
     lib.nsg_calib_copy_f64.argtypes = [vp, vp, i64, vp]
     lib.nsg_destroy.argtypes = [vp]
-    for f in EXPORTS[5:]:
+    for f in EXPORTS[6:]:
         getattr(lib, f).restype = C.c_int
     lib.nsg_spec_free.restype = None
     lib.nsg_spec_free.argtypes = [C.c_void_p]

@@ -25,30 +25,7 @@ namespace nsg {
 constexpr int kBlock = 256;
 constexpr int kMaxTableBytes = 16384;
 constexpr int kCntShards = NSG_CNT_SHARDS;
-// Where the helper lanes request the PCG64 records of the resetting envs: ahead of the θ-engine +
-// integrator work (the request's latency overlaps it, at the price of 8-10 live VGPRs) or after it.
-// Measured on MI355X (tools/ab.py): ahead wins for the generic plain-arithmetic kernels (C1 32.6 vs
-// 34.4 us); after wins for the full θ-engine (C2 50.4 vs 56.1 us: 122 instead of 133 VGPRs is one more
-// wavefront per SIMD) and for the config-specialised kernels (C1 28.4 vs 30.4 us: their compute
-// phase is too short to hide anything behind).
-#ifndef NSG_EARLY_DRAW
-#ifdef NSG_SPEC_BUILD
-#define NSG_EARLY_DRAW 0
-#else
-#define NSG_EARLY_DRAW 1
-#endif
-#endif
-template <bool FULL> constexpr bool kEarlyDraw = (NSG_EARLY_DRAW != 0) && !FULL;
-// Reset hand-over, where the resetting envs' PCG64 records come from (classic-control step):
-//   NSG_OWNER_LOAD 1: the OWNER lane requests its own record as soon as its status byte says "reset" - next to the
-//     workgroup's state loads, whose latency it shares - and parks it in LDS for the helper lanes; between the two
-//     barriers of the hand-over there is LDS traffic and arithmetic only.
-//   NSG_OWNER_LOAD 0: the helper lanes request the records after the first barrier (round 1): a dependent scattered
-//     global load on the workgroup's critical path, between its two barriers.
-#ifndef NSG_OWNER_LOAD
-#define NSG_OWNER_LOAD 1
-#endif
-// NSG_UNCOND_LOADS 1: the state / action loads do not wait for the status byte (a resetting lane's are discarded).
+// NSG_UNCOND_LOADS 1: the state / action loads do not wait for the episode word (a resetting lane's are discarded).
 #ifndef NSG_UNCOND_LOADS
 #define NSG_UNCOND_LOADS 1
 #endif
@@ -68,8 +45,7 @@ struct Segment {
   int32_t uses_normal;     // some update fn draws normals -> stage the normal ziggurat tables
   int32_t uses_exp;        // Memoryless (p < 1/3) / RandomCategorical -> stage the exponential ziggurat tables
   int32_t simple_theta;    // every update fn is plain arithmetic / table look-up (upd_kind_is_simple)
-  int32_t nt_records;      // the handle's rows outgrow the Infinity Cache: its config-specialised kernels are built with NSG_NT_RECORDS (nsg_rng.hip.h)
-  int32_t reserved0;
+  const uint64_t* jump;    // PCG64 jump-ahead table (nsg_rng.hip.h, pcg_at): kJumpWords words, global copy
 };
 
 struct ActionPtrs {
@@ -94,7 +70,6 @@ struct LdsTables {
   double* reset_state;  // [kBlock][4] initial states drawn by the helper lanes, read back by the owners
   uint64_t* blob;       // constant-table blob
   uint64_t* zig;        // 768 words (normal) + 768 words (exponential), each only when needed
-  uint64_t* streams;    // [kBlock][4] the chunk's env PCG64 records while a fused rollout runs (IoMode::lds_rng)
   uint64_t* ustreams;   // [kMaxLdsUpd][kBlock][4] the chunk's update-fn streams (first stochastic fns) during a fused rollout
 };
 constexpr int kLdsStreamBytes = kBlock * 32;
@@ -126,8 +101,7 @@ __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, 
   lds.reset_state = (double*)(base + 32 + kBlock * 2);
   lds.blob = (uint64_t*)(base + kLdsHeaderBytes);
   lds.zig = (uint64_t*)(base + kLdsHeaderBytes + ((sg.table_bytes + 7) & ~7));
-  lds.streams = (uint64_t*)(base + lds_bytes_for(sg.table_bytes, sg.uses_normal, sg.uses_exp));  // valid when the launch reserved it
-  lds.ustreams = lds.streams + kBlock * 4;
+  lds.ustreams = (uint64_t*)(base + lds_bytes_for(sg.table_bytes, sg.uses_normal, sg.uses_exp));  // valid when the launch reserved it (fused rollouts)
   const int tid = threadIdx.x;
   uint64_t* zexp = lds.zig + (sg.uses_normal ? 768 : 0);
   if (sg.uses_normal) {
@@ -148,6 +122,7 @@ __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, 
   zg.ke = zexp;
   zg.we = (const double*)(zexp + 256);
   zg.fe = (const double*)(zexp + 512);
+  zg.jump = sg.jump;
 }
 
 // Where one step's per-env outputs go: the handle's own buffers (nsg_step) or the k-th slice of
@@ -239,7 +214,7 @@ struct IoMode {  // wave-uniform
   bool load;   // fetch the persistent rows from memory (else: they are in the LaneState)
   bool store;  // write them back
   bool dirty;  // the LaneState's θ rows 0/1 may differ from memory (earlier fused steps did not store)
-  bool lds_rng;  // the chunk's env PCG64 records are in LDS (fused rollouts): the reset hand-over has no global round trip
+  bool lds_rng;  // fused rollouts: the chunk's first stochastic update fns' PCG64 records are in LDS (upd_stream_load)
   bool wt = false;  // single-step launches (nsg_step): persistent rows of the grid envs / Pendulum state leave through
                     // agent-scope stores (stg_wt); fused rollouts keep plain stores (C3 rollout: 12.3 vs 14.6 us per step)
 };
@@ -329,7 +304,8 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
 
   const uint32_t o1 = (uint32_t)i, o4 = o1 * 4u, o8 = o1 * 8u;  // per-lane byte offsets (N <= 2^27)
   const bool track = (cfg.flags & NSG_F_TRACK_RETURNS) != 0;
-  const unsigned st = !active ? 0u : io.load ? ldg(b.status, o1) : ls.st;
+  // episode word: bit 0 = needs reset, bits 1-31 = resets this env has drawn from its np_random so far (nsgym_hip.h)
+  const unsigned st = !active ? 0u : io.load ? (unsigned)ldg(b.episode, o4) : ls.st;
   const int t = !active ? 0 : io.load ? ldg(b.t, o4) : ls.t;
 #ifdef NSG_X_INLINE_RESET  // TIMING ABLATION ONLY (wrong results): a finished env re-initialises in its own lane, no hand-over
   const bool x_was_done = active && (st & NSG_ST_NEEDS_RESET);
@@ -339,10 +315,6 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
 #endif
   const bool do_step = active && !do_reset;
   if (sim && io.load && active) ls.tf = ldg(b.t_fork, o4);
-  // the resetting env's own stream record, requested by its owner lane (NSG_OWNER_LOAD)
-  const bool own_load = (NSG_OWNER_LOAD != 0) && !io.lds_rng;
-  Pcg g = {0, 0, 0, 0};
-  if (own_load && do_reset) pcg_load_record(b.rng_env, i, g);
   const bool ld_state = NSG_UNCOND_LOADS ? active : do_step;
   double s[T::PHYS];
 #pragma unroll
@@ -359,41 +331,6 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   double pre0 = 0.0, pre1 = 0.0;
   if (active && P > 0) pre0 = io.load ? ldg(b.theta, o8) : ls.th0;
   if (active && P > 1) pre1 = io.load ? ldg(b.theta + N, o8) : ls.th1;
-
-  // ---- compacted resets, part 1: queue the resetting envs; the helper lanes request their PCG64
-  // records.  Placed ahead of the θ-engine + integrator work (kEarlyDraw: the request's latency
-  // overlaps that work instead of sitting behind it on the workgroup's critical path) or after it.
-  int n_reset = 0, owner = 0;
-  bool helper = false;
-  auto queue_resets = [&]() {
-    int* rn = lds.reset_n + (parity & 1);
-    if (do_reset) {
-      const int q = atomicAdd(rn, 1);
-      lds.reset_list[q] = (short)tid;
-      if (own_load) {  // the record travels through the owner's reset_state slot (the helper replaces it with the drawn state)
-        uint64_t* rec = reinterpret_cast<uint64_t*>(lds.reset_state) + tid * 4;
-        rec[0] = g.sh; rec[1] = g.sl; rec[2] = g.ih; rec[3] = g.il;
-      }
-    }
-    __syncthreads();
-    n_reset = *rn;
-    if (tid == 0) lds.reset_n[(parity + 1) & 1] = 0;  // the other buffer is idle until the next chunk
-    helper = tid < n_reset;
-    if (helper) {
-      owner = lds.reset_list[tid];
-      if (io.lds_rng) {
-        const uint64_t* rec = lds.streams + owner * 4;
-        g.sh = rec[0]; g.sl = rec[1]; g.ih = rec[2]; g.il = rec[3];
-      } else if (own_load) {
-        const uint64_t* rec = reinterpret_cast<const uint64_t*>(lds.reset_state) + owner * 4;
-        g.sh = rec[0]; g.sl = rec[1]; g.ih = rec[2]; g.il = rec[3];
-      } else {
-        pcg_load_record(b.rng_env, base + owner, g);
-      }
-    }
-  };
-  const bool early_draw = kEarlyDraw<FULL> && !io.lds_rng && !own_load;  // LDS-resident / owner-loaded records: no latency to hide
-  if (early_draw) queue_resets();
 
   double th[T::NTHETA + T::NDERIVED];
 #pragma unroll
@@ -557,42 +494,44 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   }
   const bool done = term || trunc;
 
-  // ---- resets ---------------------------------------------------------------------------------
-#if defined(NSG_X_RESET_INLANE)  // EXPERIMENT: every resetting lane draws its own initial state (no queue, no barriers)
-  if (!io.lds_rng) {
-    if (do_reset) {
-      env_reset_draw<ENV>(g, s);
-      pcg_store_record_state(b.rng_env, i, g);
-    }
-  } else {
-#else
+  // ---- resets: queue -> helper lanes re-derive the streams and draw -> owners read back -----------------------------
+  // ~5 % of the envs reset per step but they sit in ~96 % of the wavefronts; compacting them per workgroup lets ONE wavefront
+  // execute the seeding + jump-ahead + draw path.  No stream state is read from or written to memory (nsg_rng.hip.h, pcg_at):
+  // the owner hands its episode count over through LDS, the helper rebuilds PCG64(SeedSequence(seed_i)) at draw D * count.
   {
-#endif
-  // compacted resets: queue -> helper lanes draw -> owners read back
-  if (!early_draw) queue_resets();
-  if (helper) {  // gymnasium reset(): np_random draws of the initial state [UPSTREAM]
-    double r0[T::PHYS];
-    env_reset_draw<ENV>(g, r0);
-    if (io.lds_rng) {
-      uint64_t* rec = lds.streams + owner * 4;
-      rec[0] = g.sh; rec[1] = g.sl;
-    } else {
-      pcg_store_record_state(b.rng_env, base + owner, g);
+    int* rn = lds.reset_n + (parity & 1);
+    uint64_t* slot = reinterpret_cast<uint64_t*>(lds.reset_state);
+    if (do_reset) {
+      const int q = atomicAdd(rn, 1);
+      lds.reset_list[q] = (short)tid;
+      slot[tid * 4] = (uint64_t)(st >> NSG_EP_COUNT_SHIFT);
     }
+    __syncthreads();
+    const int n_reset = *rn;
+    if (tid == 0) lds.reset_n[(parity + 1) & 1] = 0;  // the other buffer is idle until the next chunk
+    if (tid < n_reset) {  // helper lane: gymnasium reset() -> np_random draws of the initial state [UPSTREAM]
+      const int owner = lds.reset_list[tid];
+      const uint64_t count = slot[owner * 4];
+      Pcg g;
+      env_stream_at(b.rng_env, base + owner, count * (uint64_t)T::RESET_DRAWS, zg.jump, g);
+      double r0[T::PHYS];
+      env_reset_draw<ENV>(g, r0);
 #pragma unroll
-    for (int k = 0; k < T::PHYS; k++) lds.reset_state[owner * 4 + k] = r0[k];
-  }
-  __syncthreads();
-  if (do_reset) {
+      for (int k = 0; k < T::PHYS; k++) lds.reset_state[owner * 4 + k] = r0[k];
+    }
+    __syncthreads();
+    if (do_reset) {
 #pragma unroll
-    for (int k = 0; k < T::PHYS; k++) s[k] = lds.reset_state[tid * 4 + k];
-  }
+      for (int k = 0; k < T::PHYS; k++) s[k] = lds.reset_state[tid * 4 + k];
+    }
   }
 
 #pragma unroll
   for (int k = 0; k < T::PHYS; k++) ls.s[k] = s[k];
   ls.t = tnew;
-  ls.st = done ? NSG_ST_NEEDS_RESET : 0u;
+  // a reset consumed one more episode of the env's stream
+  const unsigned stw = (done ? NSG_ST_NEEDS_RESET : 0u) | (((st >> NSG_EP_COUNT_SHIFT) + (do_reset ? 1u : 0u)) << NSG_EP_COUNT_SHIFT);
+  ls.st = stw;
   if (active) {  // every row is written by its owner lane: fully coalesced stores
     if (io.store) {
 #pragma unroll
@@ -610,7 +549,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     stg_out(out.reward, o4, (float)reward);
     stg_out(out.terminated, o1, (uint8_t)(term ? 1 : 0));
     stg_out(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
-    if (io.store) stg(b.status, o1, (uint8_t)(done ? NSG_ST_NEEDS_RESET : 0));
+    if (io.store) stg(b.episode, o4, (int32_t)stw);
     if (track) {  // the episode length is the wrapper time t: only the return needs a running row
       if constexpr (kReturnFromT) {
         if (done) {
@@ -978,9 +917,11 @@ __global__ __launch_bounds__(kBlock) void step_group_kernel(GroupArgs ga, int ns
 // reset(seed) / reset(): NSWrapper.reset + subclass tails (base.py:365-431,
 // classic_control.py:102-109, toy_text.py:382-399).
 // ============================================================================================
+// `restart`: every (unmasked) env starts its stream over (nsg_reset_seeded: the host has installed a new affine descriptor).
+// With `seeds` the host has put the classic-control streams into their per-env form first (materialize_streams_kernel).
 template <int ENV>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict__ seg, const uint64_t* __restrict__ seeds,
-                                                       const uint8_t* __restrict__ mask) {
+                                                       const uint8_t* __restrict__ mask, int restart) {
   const Segment& sg = *seg;
   const nsg_config& cfg = sg.cfg;
   const nsg_buffers& b = sg.buf;
@@ -989,13 +930,25 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
   const bool persistent = (cfg.flags & NSG_F_PERSISTENT_PARAMS) != 0;
   // not a hot path: the ziggurat tables are read from their global copy
   const ZigLds zg = {sg.zig, (const double*)(sg.zig + 256), (const double*)(sg.zig + 512),
-                     sg.zig + 768, (const double*)(sg.zig + 1024), (const double*)(sg.zig + 1280)};
+                     sg.zig + 768, (const double*)(sg.zig + 1024), (const double*)(sg.zig + 1280), sg.jump};
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
     if (mask && !mask[i]) continue;
     Pcg g;
     constexpr bool GRID = ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE;
-    if (seeds) pcg_seed(g, seeds[i], -1);  // gymnasium Env.reset(seed) -> np_random(seed) [UPSTREAM]
-    else pcg_load<GRID>(b.rng_env, N, i, g);
+    [[maybe_unused]] uint32_t count = 0;   // classic envs: resets drawn from the env's stream so far
+    if constexpr (GRID) {
+      if (seeds) pcg_seed(g, seeds[i], -1);  // gymnasium Env.reset(seed) -> np_random(seed) [UPSTREAM]
+      else pcg_load<true>(b.rng_env, N, i, g);
+    } else {
+      if (seeds) {   // this env's own (seed, no spawn key) record; its stream starts over
+        b.rng_env[2 * (i + 1)] = seeds[i];
+        b.rng_env[2 * (i + 1) + 1] = (uint64_t)(uint32_t)-1;
+      } else if (!restart) {
+        count = (uint32_t)b.episode[i] >> NSG_EP_COUNT_SHIFT;   // reset(seed=None): the stream continues
+      }
+      if (seeds) pcg_seed(g, seeds[i], -1);
+      else env_stream_at(b.rng_env, i, (uint64_t)count * EnvTraits<GRID ? NSG_ENV_CARTPOLE : ENV>::RESET_DRAWS, sg.jump, g);
+    }
     if constexpr (ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE) {
       // FrozenLakeEnv / CliffWalkingEnv.reset consume one random() (categorical_sample over the one-hot
       // start distribution); Bridge.reset draws nothing
@@ -1012,7 +965,8 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
       env_obs<ENV>(s, o);
       store_obs<ENV>(b.obs, i, o);
     }
-    pcg_store_all<GRID>(b.rng_env, N, i, g);
+    if constexpr (GRID) pcg_store_all<true>(b.rng_env, N, i, g);
+    else b.episode[i] = (int32_t)((count + 1u) << NSG_EP_COUNT_SHIFT);   // one more episode drawn; needs-reset cleared
     b.t[i] = 0;
     if (b.t_fork) b.t_fork[i] = 0;
     for (int p = 0; p < P; p++) {
@@ -1053,7 +1007,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
     b.reward[i] = 0.f;
     b.terminated[i] = 0;
     b.truncated[i] = 0;
-    b.status[i] = 0;
+    if constexpr (GRID) b.status[i] = 0;
     if (cfg.flags & NSG_F_TRACK_RETURNS) {
       b.ep_return[i] = 0.f;
       b.ep_length[i] = 0;
@@ -1076,9 +1030,12 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const Segment* __restrict_
   const bool fl = is_grid_env(cfg.env_type);
   const int nd = cfg.env_type == NSG_ENV_CLIFFWALKING ? 4 : 3;
   const ZigLds zg = {sg.zig, (const double*)(sg.zig + 256), (const double*)(sg.zig + 512),
-                     sg.zig + 768, (const double*)(sg.zig + 1024), (const double*)(sg.zig + 1280)};
+                     sg.zig + 768, (const double*)(sg.zig + 1024), (const double*)(sg.zig + 1280), sg.jump};
   if (blockIdx.x == 0 && b.counters)
     for (int k = threadIdx.x; k < NSG_CNT_COUNT * kCntShards; k += kBlock) b.counters[k] = 0;
+  // a never-seeded classic-control batch: env i's np_random is PCG64(SeedSequence(i, spawn_key=(999,))) - a fixed stream where
+  // the reference has OS entropy - in the affine form (nothing per env)
+  if (!fl && blockIdx.x == 0 && threadIdx.x == 0) env_stream_set_affine(b.rng_env, 0, 999);
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
     if (fl) {
       for (int p = 0; p < cfg.n_params; p++)
@@ -1108,11 +1065,15 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const Segment* __restrict_
       b.env_change[(int64_t)p * N + i] = 0;
       b.delta_change[(int64_t)p * N + i] = 0.f;
     }
-    Pcg g;
-    pcg_seed(g, (uint64_t)i, 999);
-    pcg_store_env(b.rng_env, N, i, g, fl);
+    if (fl) {
+      Pcg g;
+      pcg_seed(g, (uint64_t)i, 999);
+      pcg_store_all<true>(b.rng_env, N, i, g);
+      b.status[i] = 0;
+    } else {
+      b.episode[i] = 0;
+    }
     b.t[i] = 0;
-    b.status[i] = 0;
     b.reward[i] = 0.f;
     b.terminated[i] = 0;
     b.truncated[i] = 0;
@@ -1256,7 +1217,8 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
     const int t = sb.t[is];
     db.t[i] = t;
     db.t_fork[i] = t;
-    db.status[i] = sb.status[is];
+    if (fl) db.status[i] = sb.status[is];
+    else db.episode[i] = sb.episode[is] & (int32_t)NSG_ST_NEEDS_RESET;   // the copy's own stream starts at its first episode
     for (int r = 0; r < (fl ? nd * P : P); r++) {
       const double cur = sb.theta[(int64_t)r * Ns + is];
       const double init = fl ? grid_initial(cfg, r / nd)[r % nd] : cfg.base_theta[cfg.params[r].theta_slot];
@@ -1301,9 +1263,14 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
         pcg_store_all(db.rng_upd + (int64_t)p * 4 * N, N, i, r);
       }
     }
-    Pcg g;  // the copy's base env is a new gym.make(): its np_random is unseeded
-    pcg_seed(g, entropy + (uint64_t)i, 7001);
-    pcg_store_env(db.rng_env, N, i, g, fl);
+    // the copy's base env is a new gym.make(): its np_random is unseeded -> stream (entropy + i, spawn key 7001)
+    if (fl) {
+      Pcg g;
+      pcg_seed(g, entropy + (uint64_t)i, 7001);
+      pcg_store_all<true>(db.rng_env, N, i, g);
+    } else if (i == 0) {
+      env_stream_set_affine(db.rng_env, entropy, 7001);
+    }
     for (int k = 0; k < obs; k++) db.obs[i * obs + k] = sb.obs[is * obs + k];
     db.reward[i] = sb.reward[is];
     db.terminated[i] = sb.terminated[is];
@@ -1313,8 +1280,29 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
       db.last_return[i] = 0.f;
       db.last_length[i] = 0;
     }
-    const unsigned long long done_mask = __ballot((sb.status[is] & NSG_ST_NEEDS_RESET) != 0);  // == the source's ballot word when N == Ns
+    const unsigned long long done_mask = __ballot(((fl ? (int)sb.status[is] : sb.episode[is]) & (int)NSG_ST_NEEDS_RESET) != 0);  // == the source's ballot word when N == Ns
     if (db.done_bits && (i & 63) == 0) db.done_bits[i >> 6] = done_mask;
+  }
+}
+
+// Classic-control env streams, affine -> per-env form (before a reset / re-seed with an ARBITRARY seed array): every env gets
+// its own (seed, spawn key) record; the descriptor is cleared by a second, one-thread launch (stream_set_kernel) so that no
+// block of this one can see it change.
+__global__ __launch_bounds__(kBlock) void materialize_streams_kernel(const Segment* __restrict__ seg) {
+  const Segment& sg = *seg;
+  const int64_t N = sg.N;
+  uint64_t* r = sg.buf.rng_env;
+  const uint64_t d0 = r[0], d1 = r[1];
+  if (!(d0 & NSG_STREAM_AFFINE)) return;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
+    r[2 * (i + 1)] = d1 + (uint64_t)i;
+    r[2 * (i + 1) + 1] = d0 & 0xffffffffULL;
+  }
+}
+__global__ void stream_set_kernel(const Segment* __restrict__ seg, uint64_t word0, uint64_t word1) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    seg->buf.rng_env[0] = word0;
+    seg->buf.rng_env[1] = word1;
   }
 }
 
@@ -1325,9 +1313,15 @@ __global__ __launch_bounds__(kBlock) void seed_streams_kernel(const Segment* __r
   const int64_t N = sg.N;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
     if (which == 0) {
-      Pcg g;
-      pcg_seed(g, seeds[i], -1);
-      pcg_store_env(sg.buf.rng_env, N, i, g, is_grid_env(sg.cfg.env_type));
+      if (is_grid_env(sg.cfg.env_type)) {
+        Pcg g;
+        pcg_seed(g, seeds[i], -1);
+        pcg_store_all<true>(sg.buf.rng_env, N, i, g);
+      } else {   // per-env record (the host has put the streams into their per-env form); the stream starts over
+        sg.buf.rng_env[2 * (i + 1)] = seeds[i];
+        sg.buf.rng_env[2 * (i + 1) + 1] = (uint64_t)(uint32_t)-1;
+        sg.buf.episode[i] &= (int32_t)NSG_ST_NEEDS_RESET;
+      }
     } else {
       for (int p = 0; p < sg.cfg.n_params; p++)
         if (sg.cfg.params[p].uses_rng) {

@@ -18,6 +18,7 @@
 #endif
 
 #include "nsg_math.hip.h"
+#include "nsgym_hip.h"
 
 namespace nsg {
 
@@ -169,6 +170,62 @@ __device__ inline void pcg_seed(Pcg& r, uint64_t seed, int child) {
 
 typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 
+// ---- PCG64 jump-ahead: the stream of env i at draw n, without ever storing the stream ---------------------------------
+// A PCG64 step is S <- S * M + inc (mod 2^128), so after n steps S_n = A_n * S_0 + inc * G_n with A_n = M^n and
+// G_n = 1 + M + ... + M^(n-1) - both independent of the stream.  A_n, G_n for an arbitrary n < 2^40 come from a table of
+// 5 x 256 entries (8-bit digits of n: entry (d, v) holds the pair for the exponent v * 256^d; built on the host in 128-bit
+// integer arithmetic, nsgym_hip.hip) by composing one entry per non-zero digit:
+//     exponents a then b:   A_(a+b) = A_a * A_b,   G_(a+b) = G_a * A_b + G_b.
+// The classic-control envs draw from env.np_random only in reset() (D doubles per reset: CartPole / Acrobot 4, Pendulum 2,
+// MountainCar 1), so the initial state of episode e of env i is draws [D*e, D*e + D) of PCG64(SeedSequence(seed_i)): a pure
+// function of (seed_i, e).  The step kernels therefore keep NO stream record per env - only the episode count e, in the env's
+// dense episode word - and the helper lanes of the reset hand-over rebuild the stream where they need it.  Measured on MI355X
+// (C1, specialised kernels; record loads / stores compiled out, everything else in place): 2^20 envs 25.2 -> 22.1 us,
+// 2^22 envs 105.9 -> 80.7 us, 2^24 envs 515 -> 423 us: the 32-byte records, touched by the ~5 % of lanes whose env resets,
+// cost more than any other part of the step (tools/stream_probe.hip reproduces it on a bare skeleton).
+constexpr int kJumpDigits = 5;                       // n < 2^40 draws per stream
+constexpr int kJumpWords = kJumpDigits * 256 * 4;    // u64 words: (A_hi, A_lo, G_hi, G_lo) per entry
+
+struct U128 {
+  uint64_t hi, lo;
+};
+__host__ __device__ __forceinline__ U128 mul128(U128 a, U128 b) {  // low 128 bits of a * b
+#ifdef __HIP_DEVICE_COMPILE__
+  const uint64_t hi = __umul64hi(a.lo, b.lo) + a.hi * b.lo + a.lo * b.hi;
+#else
+  const uint64_t hi = (uint64_t)(((unsigned __int128)a.lo * b.lo) >> 64) + a.hi * b.lo + a.lo * b.hi;
+#endif
+  return U128{hi, a.lo * b.lo};
+}
+__host__ __device__ __forceinline__ U128 add128(U128 a, U128 b) {
+  const uint64_t lo = a.lo + b.lo;
+  return U128{a.hi + b.hi + (lo < a.lo ? 1ULL : 0ULL), lo};
+}
+
+// The stream seeded like PCG64(SeedSequence(seed[, spawn_key = (child,)])), advanced by n draws.  `jump`: the table above
+// (global memory; 40 KB, shared by every env, cache-resident).  The digit loop is wave-uniform (it runs while ANY lane has a
+// non-zero digit left); a typical n (a few thousand episodes) takes two digits.
+__device__ inline void pcg_at(Pcg& r, uint64_t seed, int child, uint64_t n, const uint64_t* __restrict__ jump) {
+  pcg_seed(r, seed, child);
+  U128 A = {0, 1}, G = {0, 0};
+  uint64_t rest = n;
+  for (int d = 0; d < kJumpDigits; d++) {
+    if (__ballot(rest != 0) == 0) break;
+    const unsigned v = (unsigned)(rest & 255u);
+    rest >>= 8;
+    if (v != 0) {
+      const u64x2* e = reinterpret_cast<const u64x2*>(jump + ((size_t)d * 256 + v) * 4);
+      const u64x2 a = e[0], g = e[1];
+      const U128 Ad = {a.x, a.y}, Gd = {g.x, g.y};
+      G = add128(mul128(G, Ad), Gd);
+      A = mul128(A, Ad);
+    }
+  }
+  const U128 s = add128(mul128(A, U128{r.sh, r.sl}), mul128(G, U128{r.ih, r.il}));
+  r.sh = s.hi;
+  r.sl = s.lo;
+}
+
 // A stream is one 32-byte record per env, array-of-records [N][4]: state_hi, state_lo, inc_hi,
 // inc_lo.  Streams are touched by few, scattered lanes (the ~5 % of envs that reset, the lanes
 // whose scheduler fired), so one 32-byte record = one memory sector per touch; four SoA rows
@@ -196,33 +253,26 @@ __device__ __forceinline__ void pcg_load(const uint64_t* base, int64_t N, int64_
     r.sh = a.x; r.sl = a.y; r.ih = c.x; r.il = c.y;
   }
 }
-// The env stream RECORDS of the classic-control envs are touched only by the few lanes whose env resets: 32 bytes of a
-// 128-byte line per touch, yet over a few steps every line of the record array (128 MB at 2^22 envs) passes through the
-// caches and displaces the densely re-read state rows.  `nt` requests and writes them with the non-temporal policy instead.
-// It is a COMPILE-TIME choice (NSG_NT_RECORDS; a run-time select between the two load flavours - even one whose condition
-// folds to a constant after inlining - is merged into one plain load by the compiler): the config-specialised kernels of a handle whose rows outgrow the 256-MiB Infinity Cache are built with
-// it (nsg_specialize, Segment::nt_records), the precompiled generic kernels never.  Measured, C1, specialised kernels:
-// 2^22 envs 124 -> 113.5 us, 2^24 envs 499 -> 465 us; at 2^20 envs (everything cache-resident) the same policy COSTS
-// 25.7 -> 30.3 us, hence the switch by size.
-#ifndef NSG_NT_RECORDS
-#define NSG_NT_RECORDS 0
-#endif
-constexpr bool kNtRecords = NSG_NT_RECORDS != 0;
-__device__ __forceinline__ void pcg_load_record(const uint64_t* base, int64_t i, Pcg& r) {
-  const uint32_t o = (uint32_t)i * 32u;
-  u64x2 a, c;
-  if constexpr (kNtRecords) {
-    a = ldg_nt(reinterpret_cast<const u64x2*>(base), o);
-    c = ldg_nt(reinterpret_cast<const u64x2*>(base), o + 16u);
+// Stream of env i of a classic-control batch, positioned at draw n (buffers.rng_env, include/nsgym_hip.h): record 0 is the
+// batch's descriptor - affine (env i seeded base + i; nothing else is read) or not (record 1 + i holds the env's own seed and
+// spawn key: one 16-byte read by the few lanes that reset).
+__device__ __forceinline__ void env_stream_at(const uint64_t* rng_env, int64_t i, uint64_t n, const uint64_t* jump, Pcg& r) {
+  const u64x2 d = *reinterpret_cast<const u64x2*>(rng_env);
+  uint64_t seed;
+  int key;
+  if (d.x & NSG_STREAM_AFFINE) {
+    seed = d.y + (uint64_t)i;
+    key = (int)(uint32_t)d.x;
   } else {
-    a = ldg(reinterpret_cast<const u64x2*>(base), o);
-    c = ldg(reinterpret_cast<const u64x2*>(base), o + 16u);
+    const u64x2 rec = ldg(reinterpret_cast<const u64x2*>(rng_env), (uint32_t)(i + 1) * 16u);
+    seed = rec.x;
+    key = (int)(uint32_t)rec.y;
   }
-  r.sh = a.x; r.sl = a.y; r.ih = c.x; r.il = c.y;
+  pcg_at(r, seed, key, n, jump);
 }
-__device__ __forceinline__ void pcg_store_record_state(uint64_t* base, int64_t i, const Pcg& r) {
-  if constexpr (kNtRecords) stg_out(reinterpret_cast<u64x2*>(base), (uint32_t)i * 32u, u64x2{r.sh, r.sl});
-  else stg(reinterpret_cast<u64x2*>(base), (uint32_t)i * 32u, u64x2{r.sh, r.sl});
+__device__ __forceinline__ void env_stream_set_affine(uint64_t* rng_env, uint64_t base, int key) {
+  rng_env[0] = NSG_STREAM_AFFINE | (uint64_t)(uint32_t)key;
+  rng_env[1] = base;
 }
 template <bool ROWS = false, bool WT = false>
 __device__ __forceinline__ void pcg_store_state(uint64_t* base, int64_t N, int64_t i, const Pcg& r) {
@@ -259,6 +309,7 @@ struct ZigLds {
   const uint64_t* ke;   // exponential ziggurat (geometric inversion, Dirichlet)
   const double* we;
   const double* fe;
+  const uint64_t* jump = nullptr;  // PCG64 jump-ahead table (global memory), pcg_at
 };
 
 __device__ inline double pcg_std_normal(Pcg& g, const ZigLds& z) {

@@ -32,25 +32,18 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
   for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
     [[maybe_unused]] LaneState<GRID ? NSG_ENV_CARTPOLE : ENV> ls;
     [[maybe_unused]] GridLane<ENV == NSG_ENV_CLIFFWALKING ? 4 : 3> gl;
-    // classic envs: the chunk's env streams live in LDS for the K steps, so the per-step reset hand-over
-    // (helper lanes draw the queued envs' initial states) has no global-memory round trip on the
-    // workgroup's critical path; HBM sees the records once per launch
+    // classic envs: the first stochastic update fns' streams live in LDS for the K steps (each lane touches only its own
+    // record); the env's own np_random needs no state at all (episode word + jump-ahead, nsg_rng.hip.h)
     [[maybe_unused]] const int64_t ir = c * kBlock + threadIdx.x;
-    if constexpr (!GRID) {
+    if constexpr (!GRID && FULL) {
       if (ir < N) {
-        Pcg g;
-        pcg_load(b.rng_env, N, ir, g);
-        uint64_t* rec = lds.streams + threadIdx.x * 4;
-        rec[0] = g.sh; rec[1] = g.sl; rec[2] = g.ih; rec[3] = g.il;
-        if constexpr (FULL) {  // and the first stochastic update fns' streams (each lane touches only its own record)
-          for (int p = 0; p < cfg.n_params; p++) {
-            const nsg_param_cfg& pc = cfg.params[p];
-            if (!pc.uses_rng || pc.fn_slot != p || upd_lds_index(cfg, p) >= kMaxLdsUpd) continue;
-            Pcg u;
-            pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, ir, u);
-            uint64_t* ur = lds.ustreams + ((int64_t)upd_lds_index(cfg, p) * kBlock + threadIdx.x) * 4;
-            ur[0] = u.sh; ur[1] = u.sl; ur[2] = u.ih; ur[3] = u.il;
-          }
+        for (int p = 0; p < cfg.n_params; p++) {
+          const nsg_param_cfg& pc = cfg.params[p];
+          if (!pc.uses_rng || pc.fn_slot != p || upd_lds_index(cfg, p) >= kMaxLdsUpd) continue;
+          Pcg u;
+          pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, ir, u);
+          uint64_t* ur = lds.ustreams + ((int64_t)upd_lds_index(cfg, p) * kBlock + threadIdx.x) * 4;
+          ur[0] = u.sh; ur[1] = u.sl; ur[2] = u.ih; ur[3] = u.il;
         }
       }
       __syncthreads();
@@ -80,20 +73,15 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
       }
       parity ^= 1;
     }
-    if constexpr (!GRID) {
+    if constexpr (!GRID && FULL) {
       __syncthreads();
       if (ir < N) {
-        const uint64_t* rec = lds.streams + threadIdx.x * 4;
-        Pcg g = {rec[0], rec[1], 0, 0};
-        pcg_store_state(b.rng_env, N, ir, g);
-        if constexpr (FULL) {
-          for (int p = 0; p < cfg.n_params; p++) {
-            const nsg_param_cfg& pc = cfg.params[p];
-            if (!pc.uses_rng || pc.fn_slot != p || upd_lds_index(cfg, p) >= kMaxLdsUpd) continue;
-            const uint64_t* ur = lds.ustreams + ((int64_t)upd_lds_index(cfg, p) * kBlock + threadIdx.x) * 4;
-            Pcg u = {ur[0], ur[1], 0, 0};
-            pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, ir, u);
-          }
+        for (int p = 0; p < cfg.n_params; p++) {
+          const nsg_param_cfg& pc = cfg.params[p];
+          if (!pc.uses_rng || pc.fn_slot != p || upd_lds_index(cfg, p) >= kMaxLdsUpd) continue;
+          const uint64_t* ur = lds.ustreams + ((int64_t)upd_lds_index(cfg, p) * kBlock + threadIdx.x) * 4;
+          Pcg u = {ur[0], ur[1], 0, 0};
+          pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, ir, u);
         }
       }
       __syncthreads();  // the next chunk refills the records

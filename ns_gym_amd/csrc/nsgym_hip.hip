@@ -283,6 +283,24 @@ int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, cons
 
 extern "C" {
 
+// PCG64 jump-ahead table (nsg_rng.hip.h): entry (d, v) = (M^e, 1 + M + ... + M^(e-1)) mod 2^128 for e = v * 256^d.
+void nsg_pcg64_jump_table(uint64_t* out) {
+  typedef unsigned __int128 u128;
+  const u128 M = ((u128)2549297995355413924ULL << 64) | 4865540595714422341ULL;   // PCG_DEFAULT_MULTIPLIER_128
+  u128 base_a = M, base_g = 1;   // exponent 256^d, starting with d = 0 (exponent 1)
+  for (int d = 0; d < kJumpDigits; d++) {
+    u128 a = 1, g = 0;           // exponent 0
+    for (int v = 0; v < 256; v++) {
+      uint64_t* e = out + ((size_t)d * 256 + v) * 4;
+      e[0] = (uint64_t)(a >> 64); e[1] = (uint64_t)a; e[2] = (uint64_t)(g >> 64); e[3] = (uint64_t)g;
+      g = g * base_a + base_g;   // exponents x then 256^d:  G_(x+y) = G_x * A_y + G_y
+      a = a * base_a;
+    }
+    base_a = a;                  // after 256 compositions: exponent 256^(d+1)
+    base_g = g;
+  }
+}
+
 int nsg_abi_version(void) { return NSG_ABI_VERSION; }
 const char* nsg_last_error(void) { return g_err; }
 size_t nsg_sizeof_config(void) { return sizeof(nsg_config); }
@@ -318,8 +336,10 @@ int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
   const bool simenv = (cfg->flags & NSG_F_SIM_ENV) != 0;
   out->t_fork = simenv ? n : 0;
   out->derived = (simenv && e == NSG_ENV_CARTPOLE) ? 2 * n : 0;
-  out->status = n;
-  out->rng_env = fl ? 4 * ((n + kBlock - 1) / kBlock) * kBlock : 4 * n;  // grid envs: chunk-blocked rows; classic: [n][4] records
+  out->status = fl ? n : 0;     // grid envs: a byte; classic-control envs: the episode word
+  out->episode = fl ? 0 : n;
+  // grid envs: chunk-blocked PCG64 state rows; classic-control envs: descriptor + one (seed, spawn key) record per env
+  out->rng_env = fl ? 4 * ((n + kBlock - 1) / kBlock) * kBlock : 2 * (n + 1);
   out->rng_upd = any_rng ? (int64_t)P * 4 * n : 0;
   out->cursor = any_cursor ? (int64_t)P * n : 0;
   out->rng_sched = any_sched ? (int64_t)P * 4 * n : 0;
@@ -368,7 +388,9 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
   HIP_TRY_H(hipMalloc((void**)&h->d_tables, tb));
   HIP_TRY_H(hipMemset(h->d_tables, 0, tb));
   if (table_bytes) HIP_TRY_H(hipMemcpy(h->d_tables, tables, table_bytes, hipMemcpyHostToDevice));
-  uint64_t zig[1536];
+  static uint64_t zig[1536 + kJumpWords];   // ziggurat tables | PCG64 jump-ahead table (one device block)
+  static std::once_flag jump_once;
+  std::call_once(jump_once, [] { nsg_pcg64_jump_table(zig + 1536); });
   memcpy(zig, NSG_ZIG_KI, 2048);
   memcpy(zig + 256, NSG_ZIG_WI_BITS, 2048);
   memcpy(zig + 512, NSG_ZIG_FI_BITS, 2048);
@@ -383,6 +405,7 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
   h->host.N = n;
   h->host.tables = h->d_tables;
   h->host.zig = h->d_zig;
+  h->host.jump = h->d_zig + 1536;
   h->host.table_bytes = (int32_t)table_bytes;
   h->host.uses_normal = 0;
   h->host.simple_theta = 1;
@@ -400,19 +423,10 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
 // Bytes of all rows of a handle (what one step streams through the caches, give or take the rows a config never touches).
 static int64_t layout_bytes(const nsg_layout& l) {
   return 8 * (l.phys + l.theta + l.table_prob + l.derived + l.rng_env + l.rng_upd + l.rng_sched + l.done_bits) +
-         4 * (l.cell + l.t + l.t_fork + l.sched_next + l.cursor + l.obs + l.reward + l.delta_change + l.prob + l.ep_return + l.ep_length +
+         4 * (l.cell + l.t + l.t_fork + l.episode + l.sched_next + l.cursor + l.obs + l.reward + l.delta_change + l.prob + l.ep_return + l.ep_length +
               l.last_return + l.last_length) +
          (l.status + l.terminated + l.truncated + l.env_change + l.violation);
 }
-// Rows well beyond the 256-MiB Infinity Cache: the sparsely touched env stream records take the non-temporal path in the handle's
-// config-specialised kernels (nsg_rng.hip.h).  Measured on C1 (rows: 157 MB per 2^20 envs), nt against plain: 2^20 envs 29.4 vs
-// 25.2 us, 2^21 (252 MB of rows) 55.0 vs 47.0, 2^22 (503 MB) 106.1 vs 112.4, 2^24 520 vs 530 - the switch sits at 1.5 x the cache.
-// NSG_NT_RECORDS=0/1 forces it.
-static int nt_records_for(const nsg_layout& l) {
-  if (const char* e = getenv("NSG_NT_RECORDS")) return e[0] == '1';
-  return layout_bytes(l) > (384LL << 20);
-}
-
 static int grid_cap() {  // tuning knob (tools/kbench.py sweeps it); default from measurements
   static int cap = 0;
   if (!cap) {
@@ -434,12 +448,11 @@ int nsg_bind(nsg_handle* h, const nsg_buffers* bufs) {
   if (rc) return rc;
 #define NEED(field) \
   if (lay.field > 0 && !bufs->field) return fail(NSG_EINVAL, "buffer '%s' is required (%lld elements)", #field, (long long)lay.field)
-  NEED(phys); NEED(cell); NEED(theta); NEED(table_prob); NEED(derived); NEED(t); NEED(t_fork); NEED(status); NEED(rng_env); NEED(rng_upd); NEED(rng_sched); NEED(sched_next); NEED(cursor);
+  NEED(phys); NEED(cell); NEED(theta); NEED(table_prob); NEED(derived); NEED(t); NEED(t_fork); NEED(status); NEED(episode); NEED(rng_env); NEED(rng_upd); NEED(rng_sched); NEED(sched_next); NEED(cursor);
   NEED(obs); NEED(reward); NEED(terminated); NEED(truncated); NEED(env_change); NEED(delta_change); NEED(violation);
   NEED(ep_return); NEED(ep_length); NEED(last_return); NEED(last_length);
 #undef NEED
   h->host.buf = *bufs;
-  h->host.nt_records = nt_records_for(lay);
   g_generation++;
   HIP_TRY(hipMemcpy(h->dev, &h->host, sizeof(Segment), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(init_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, 0, h->dev);
@@ -465,8 +478,41 @@ int nsg_reset(nsg_handle* h, const uint64_t* seeds_dev, const uint8_t* mask_dev,
   if (!h) return fail(NSG_EINVAL, "handle is NULL");
   if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
   hipStream_t s = (hipStream_t)stream;
+  if (seeds_dev && !is_grid_env(h->host.cfg.env_type)) {
+    // arbitrary per-env seeds: the classic-control streams leave their affine form first (stream-ordered: records, then the
+    // descriptor, then the reset that writes the seeded envs' records)
+    hipLaunchKernelGGL(materialize_streams_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev);
+    hipLaunchKernelGGL(stream_set_kernel, dim3(1), dim3(1), 0, s, h->dev, 0ULL, 0ULL);
+  }
   DISPATCH_ENV(h->host.cfg.env_type,
-               hipLaunchKernelGGL(reset_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, seeds_dev, mask_dev));
+               hipLaunchKernelGGL(reset_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, seeds_dev, mask_dev, 0));
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
+// Fills seeds[i] = base + i (grid envs take their seeds as an array)
+__global__ void iota_seeds_kernel(uint64_t* out, uint64_t base, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = base + (uint64_t)i;
+}
+
+int nsg_reset_seeded(nsg_handle* h, uint64_t base_seed, void* stream) {
+  if (!h) return fail(NSG_EINVAL, "handle is NULL");
+  if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
+  hipStream_t s = (hipStream_t)stream;
+  if (is_grid_env(h->host.cfg.env_type)) {   // grid envs keep per-env PCG64 rows: seed them from base + i
+    uint64_t* seeds = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&seeds, sizeof(uint64_t) * (size_t)h->n, s));
+    hipLaunchKernelGGL(iota_seeds_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, s, seeds, base_seed, h->n);
+    DISPATCH_ENV(h->host.cfg.env_type,
+                 hipLaunchKernelGGL(reset_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, (const uint64_t*)seeds, (const uint8_t*)nullptr, 0));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipFreeAsync(seeds, s));
+    return NSG_OK;
+  }
+  // classic-control envs: env i <- PCG64(SeedSequence(base + i)), kept in the affine form (one descriptor, nothing per env)
+  hipLaunchKernelGGL(stream_set_kernel, dim3(1), dim3(1), 0, s, h->dev, NSG_STREAM_AFFINE | 0xffffffffULL, base_seed);
+  DISPATCH_ENV(h->host.cfg.env_type,
+               hipLaunchKernelGGL(reset_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, (const uint64_t*)nullptr, (const uint8_t*)nullptr, 1));
   HIP_TRY(hipGetLastError());
   return NSG_OK;
 }
@@ -510,7 +556,7 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
   hipStream_t s = (hipStream_t)stream;
   // fused rollouts of the classic envs keep the chunk's env PCG64 records in LDS
   const size_t rollout_lds = (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp) +
-                             (is_grid_env(h->host.cfg.env_type) ? 0 : kLdsStreamBytes * (1 + upd_lds_count(h->host.cfg)));
+                             (is_grid_env(h->host.cfg.env_type) ? 0 : kLdsStreamBytes * upd_lds_count(h->host.cfg));
   if (h->spec) {
     void* args[] = {(void*)&h->dev, (void*)&actions_dev, (void*)&k_steps, (void*)&o};
     HIP_TRY(hipModuleLaunchKernel(h->spec->rollout, grid_for(h->n), 1, 1, kBlock, 1, 1, (unsigned)rollout_lds, s, args, nullptr));
@@ -602,18 +648,15 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
       uint64_t h0 = 0x67726f7570ull;  // "group"
       const nsg_config* cfgs[NSG_MAX_SEGMENTS];
       bool full[NSG_MAX_SEGMENTS];
-      bool nt = false;
       for (int k = 0; k < n_handles; k++) {
         h0 = nsg_spec::fnv1a(&hs[k]->spec->h0, sizeof(uint64_t), h0);
         cfgs[k] = &hs[k]->host.cfg;
         full[k] = !hs[k]->host.simple_theta;
-        nt = nt || hs[k]->host.nt_records != 0;
       }
-      h0 = nsg_spec::fnv1a(&nt, sizeof(nt), h0);
       hipDeviceProp_t prop;
       HIP_TRY(hipGetDeviceProperties(&prop, hs[0]->device));
       const int rc = get_spec_module(hs[0]->device, h0, true,
-                                     [&](std::string& err) { return nsg_spec::group_compile(cfgs, full, n_handles, prop.gcnArchName, err, nt); },
+                                     [&](std::string& err) { return nsg_spec::group_compile(cfgs, full, n_handles, prop.gcnArchName, err); },
                                      &plan.group_spec);
       if (rc) plan.group_spec = nullptr;  // the generic group kernel stays in force
     }
@@ -656,6 +699,10 @@ int nsg_seed_streams(nsg_handle* h, const uint64_t* seeds_dev, int32_t which, vo
   if (!h || !seeds_dev) return fail(NSG_EINVAL, "NULL argument");
   if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
   if (which != 0 && which != 1) return fail(NSG_EINVAL, "which must be 0 (env) or 1 (update fns)");
+  if (which == 0 && !is_grid_env(h->host.cfg.env_type)) {   // per-env seeds: the streams leave their affine form (see nsg_reset)
+    hipLaunchKernelGGL(materialize_streams_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, (hipStream_t)stream, h->dev);
+    hipLaunchKernelGGL(stream_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, h->dev, 0ULL, 0ULL);
+  }
   hipLaunchKernelGGL(seed_streams_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, (hipStream_t)stream, h->dev, seeds_dev, which);
   HIP_TRY(hipGetLastError());
   return NSG_OK;
@@ -759,8 +806,7 @@ int nsg_spec_build(const nsg_config* cfg, const char* arch, void** code_out, siz
   for (int p = 0; p < cfg->n_params; p++)
     if (!upd_kind_is_simple(cfg->params[p].upd_kind) || sched_is_stochastic(cfg->params[p].sched_kind)) full = true;
   std::string err;
-  const char* ntenv = getenv("NSG_NT_RECORDS");  // the record policy of the unit (nsg_specialize derives it from the handle's size)
-  std::vector<char> code = nsg_spec::spec_compile(*cfg, full, arch && *arch ? arch : "gfx950", err, ntenv && ntenv[0] == '1');
+  std::vector<char> code = nsg_spec::spec_compile(*cfg, full, arch && *arch ? arch : "gfx950", err);
   if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
   void* p = malloc(code.size());
   if (!p) return fail(NSG_ENOMEM, "out of host memory");
@@ -781,12 +827,10 @@ int nsg_specialize(nsg_handle* h) {
   // key: config bytes + engine variant + target (+ the kernel sources this library was built from)
   uint64_t h0 = nsg_spec::fnv1a(&h->host.cfg, sizeof(nsg_config));
   h0 = nsg_spec::fnv1a(&full, sizeof(full), h0);
-  const bool nt = h->host.nt_records != 0;  // rows beyond the Infinity Cache: stream records take the non-temporal path
-  h0 = nsg_spec::fnv1a(&nt, sizeof(nt), h0);
   h0 = nsg_spec::fnv1a(prop.gcnArchName, strlen(prop.gcnArchName), h0);
   if (const char* e = getenv("NSG_SPEC_FLAGS")) h0 = nsg_spec::fnv1a(e, strlen(e), h0);
   const int rc = get_spec_module(h->device, h0, false,
-                                 [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err, nt); }, &h->spec);
+                                 [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err); }, &h->spec);
   g_generation++;   // a group that contains this handle re-plans (its specialised unit depends on every member's)
   return rc;
 }

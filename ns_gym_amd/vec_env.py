@@ -187,20 +187,30 @@ class VecNSEnv:
     def reset(self, *, seed=None, options=None, mask=None):
         """`reset(seed=s)`: env i is seeded exactly like the reference's `reset(seed=s+i)` (or
         `seed[i]` for a sequence); `reset()` continues every stream (ns_gym/base.py:365-410)."""
-        seeds = None
+        seeds, base = None, None
         if seed is not None:
             if np.isscalar(seed):
-                s = np.arange(self.N, dtype=np.uint64) + np.uint64(int(seed))
+                base = int(seed)
             else:
                 s = np.asarray(seed, dtype=np.uint64)
                 assert s.shape == (self.N,), "seed sequence must have one entry per env"
-            seeds = torch.from_numpy(s.view(np.int64)).to(self.device)
+                if self.N == 1 or bool((np.diff(s.astype(np.int64, copy=False)) == 1).all()):
+                    base = int(s[0])     # seed[i] = seed[0] + i: gymnasium's vector-env convention, given explicitly
+                else:
+                    seeds = torch.from_numpy(s.view(np.int64)).to(self.device)
+            if base is not None and mask is not None:   # a masked re-seed cannot stay in the affine form
+                seeds = torch.from_numpy(((np.arange(self.N, dtype=np.uint64) + np.uint64(base & (2**64 - 1)))).view(np.int64)).to(self.device)
+                base = None
         m = None
         if mask is not None:
             m = torch.as_tensor(mask, device=self.device).to(torch.uint8).contiguous()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.nsg_reset(self._h, seeds.data_ptr() if seeds is not None else None,
-                                          m.data_ptr() if m is not None else None, self._stream), "nsg_reset")
+            if base is not None:
+                # env i <- base + i with nothing stored per env (classic-control envs re-derive their streams: nsgym_hip.h)
+                _lib.check(self.lib.nsg_reset_seeded(self._h, C.c_uint64(base & (2**64 - 1)), self._stream), "nsg_reset_seeded")
+            else:
+                _lib.check(self.lib.nsg_reset(self._h, seeds.data_ptr() if seeds is not None else None,
+                                              m.data_ptr() if m is not None else None, self._stream), "nsg_reset")
         self.has_reset = True
         return self._obs(), self._info()
 

@@ -71,7 +71,7 @@ class OracleVecEnv:
         z = lambda shape, dt: np.zeros(shape, dtype=dt)  # noqa: E731
         self.a = {
             "phys": z((max(PHYS_DIM[et], 1), N), np.float64), "cell": z(N, np.int32),
-            "theta": z((max(rows, 1), N), np.float64), "table_prob": z((4, N), np.float64), "derived": z((2, N), np.float64), "t": z(N, np.int32), "t_fork": z(N, np.int32), "status": z(N, np.uint8),
+            "theta": z((max(rows, 1), N), np.float64), "table_prob": z((4, N), np.float64), "derived": z((2, N), np.float64), "t": z(N, np.int32), "t_fork": z(N, np.int32), "status": z(N, np.uint8), "episode": z(N, np.int32),
             "rng_env": z((N, 4), np.uint64), "rng_upd": z((max(P, 1), N, 4), np.uint64), "rng_sched": z((max(P, 1), N, 4), np.uint64),
             "sched_next": z((max(P, 1), N), np.int32),
             "cursor": z((max(P, 1), N), np.int32), "obs": z((N, OBS_DIM[et]), np.float32),

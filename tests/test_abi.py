@@ -51,12 +51,15 @@ def test_layout_query_is_pure_host_arithmetic(lib):
                                                         "gravity": RandomWalk(PeriodicScheduler(3))}, track_returns=True)
     lay = A.Layout()
     assert lib.nsg_layout_query(C.byref(cfg), 1000, C.byref(lay)) == 0
-    assert (lay.phys, lay.theta, lay.obs, lay.rng_env, lay.rng_upd, lay.cursor) == (4096, 2000, 4000, 4000, 8000, 0)   # phys is chunk-blocked: 4 rows x 4 chunks x 256
+    assert (lay.phys, lay.theta, lay.obs, lay.rng_env, lay.rng_upd, lay.cursor) == (4096, 2000, 4000, 2002, 8000, 0)   # phys is chunk-blocked: 4 rows x 4 chunks x 256
+    # classic-control envs: an episode word per env and NO per-env stream state (rng_env = descriptor + (seed, spawn key) records)
+    assert (lay.episode, lay.status) == (1000, 0)
     assert (lay.phys_dim, lay.obs_dim, lay.n_actions, lay.action_is_float) == (4, 4, 2, 0)
     assert lay.ep_return == 1000 and lay.counters == A.CNT_COUNT * A.CNT_SHARDS and lay.done_bits == 16
     cfg, _, _, _ = compile_config(make("FrozenLake-v1", map_name="8x8"), {"P": DistributionDecrementUpdate(ContinuousScheduler(), 0.1)})
     assert lib.nsg_layout_query(C.byref(cfg), 64, C.byref(lay)) == 0
     assert (lay.cell, lay.theta, lay.table_prob, lay.obs, lay.prob, lay.phys, lay.rng_env) == (64, 192, 768, 0, 64, 0, 1024)   # chunk-blocked rows pad to 256 envs
+    assert (lay.episode, lay.status) == (0, 64)   # grid envs: a status byte, PCG64 state rows (one draw per env per step)
     assert lib.nsg_layout_query(C.byref(cfg), 0, C.byref(lay)) != 0
     assert b"2^27" in lib.nsg_last_error()
     # maximum batch per handle: rows are addressed with 32-bit byte offsets (32-byte stream records)

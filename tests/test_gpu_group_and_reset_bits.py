@@ -33,7 +33,7 @@ def _acts(env, T, seed):
 def _same(a, b):
     import torch
 
-    for row in ("theta", "t", "reward", "terminated", "truncated", "status", "obs", "cell"):
+    for row in ("theta", "t", "reward", "terminated", "truncated", "status", "episode", "obs", "cell"):
         if a.buf[row] is not None:
             assert torch.equal(a.buf[row], b.buf[row]), row
 

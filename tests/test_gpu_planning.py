@@ -151,8 +151,9 @@ def test_fork_into_an_earlier_copy_reuses_it():
     for k in range(15, 30):
         fresh.step(acts[k])
         reused.step(acts[k])
-    for row in ("phys", "theta", "t", "t_fork", "status", "rng_env", "rng_upd", "obs", "reward", "terminated", "truncated"):
-        assert torch.equal(fresh.buf[row], reused.buf[row]), row
+    for row in ("phys", "theta", "t", "t_fork", "status", "episode", "rng_env", "rng_upd", "obs", "reward", "terminated", "truncated"):
+        if fresh.buf[row] is not None:
+            assert torch.equal(fresh.buf[row], reused.buf[row]), row
     other = VecNSEnv(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.01)}, n)
     other.reset(seed=1)
     with pytest.raises(AssertionError):
@@ -190,7 +191,7 @@ def test_fork_repeat_equals_separate_forks():
             big.step(acts[k].repeat(S))
             for p in parts:
                 p.step(acts[k])
-        rows = ("cell", "theta", "t", "status", "reward", "terminated", "truncated", "ep_return", "last_return")
+        rows = ("cell", "theta", "t", "status", "episode", "reward", "terminated", "truncated", "ep_return", "last_return")
         for s, p in enumerate(parts):
             if not big.is_grid:
                 assert torch.equal(big.phys[:, s * n:(s + 1) * n], p.phys), ("phys", s)

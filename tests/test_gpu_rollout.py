@@ -48,7 +48,9 @@ def test_rollout_equals_single_steps(name, n, K):
         assert torch.equal(getattr(a, field), getattr(b, field)), field
     if not a.is_grid:
         assert torch.equal(a.phys, b.phys)
-    assert torch.equal(a.buf["status"], b.buf["status"]) and torch.equal(a.buf["rng_env"], b.buf["rng_env"])
+    for row in ("status", "episode", "rng_env"):
+        if a.buf[row] is not None:
+            assert torch.equal(a.buf[row], b.buf[row]), row
     assert torch.equal(a.buf["ep_return"], b.buf["ep_return"]) and torch.equal(a.buf["last_return"], b.buf["last_return"])
     assert a.counters() == b.counters()
     a.close(); b.close()
@@ -79,7 +81,7 @@ def test_grid_rollout_equals_single_steps(name, n, K):
         assert torch.equal(traj["obs"][k], a.state) and torch.equal(traj["reward"][k], r), f"step {k}"
         assert torch.equal(traj["terminated"][k], te) and torch.equal(traj["truncated"][k], tr)
         assert torch.equal(traj["env_change"][k], a.gt_env_change[:P]) and torch.equal(traj["delta_change"][k], a.gt_delta_change[:P])
-    for row in ("cell", "t", "status", "theta", "table_prob", "rng_env", "prob", "ep_return", "last_return", "last_length", "cursor"):
+    for row in ("cell", "t", "status", "episode", "theta", "table_prob", "rng_env", "prob", "ep_return", "last_return", "last_length", "cursor"):
         if a.buf[row] is not None:
             assert torch.equal(a.buf[row], b.buf[row]), row
     assert a.counters() == b.counters()

@@ -9,7 +9,7 @@ from tests.util import TRAJ_SPECS, GpuView, check_trajectory, load, make_env_fro
 
 pytestmark = pytest.mark.gpu
 
-ROWS = ("phys", "cell", "theta", "table_prob", "t", "status", "rng_env", "rng_upd", "rng_sched", "sched_next", "cursor", "obs",
+ROWS = ("phys", "cell", "theta", "table_prob", "t", "status", "episode", "rng_env", "rng_upd", "rng_sched", "sched_next", "cursor", "obs",
         "reward", "terminated", "truncated", "env_change", "delta_change", "prob", "ep_return", "last_return", "last_length",
         "done_bits")
 

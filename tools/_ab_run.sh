@@ -1,5 +1,7 @@
-rm -f gpurun_out/r02k_ab.log
-for cap in 1024 1536 2048 3072 4096; do echo "cap $cap" >> gpurun_out/r02k_ab.log; NSG_GRID_CAP=$cap python tools/ab.py "lib:spec,lib:spec:-DNSG_X_INLINE_RESET" c1 2 1048576 300 >> gpurun_out/r02k_ab.log 2>&1; done
-for cap in 2048 4096 16384; do echo "cap $cap" >> gpurun_out/r02k_ab.log; NSG_GRID_CAP=$cap python tools/ab.py "lib:spec" c1 2 4194304 100 >> gpurun_out/r02k_ab.log 2>&1; done
-for cap in 2048 4096; do echo "cap $cap" >> gpurun_out/r02k_ab.log; NSG_GRID_CAP=$cap python tools/ab.py "lib:spec" c3 2 1048576 300 >> gpurun_out/r02k_ab.log 2>&1; done
-cat gpurun_out/r02k_ab.log
+rm -f gpurun_out/r02n_ab.log
+for n in 1048576 4194304 16777216; do
+  it=300; [ $n -gt 5000000 ] && it=60
+  python tools/ab.py "lib:spec,lib:spec:-DNSG_X_NO_RECORD_IO,lib:spec:-DNSG_X_NO_RECORD_IO -DNSG_X_RESET_INLANE,lib:spec:-DNSG_X_INLINE_RESET" c1 2 $n $it >> gpurun_out/r02n_ab.log 2>&1
+done
+python tools/ab.py "lib:spec,lib:spec:-DNSG_X_NO_RECORD_IO" c1 2 1048576 300 >> gpurun_out/r02n_ab.log 2>&1
+cat gpurun_out/r02n_ab.log
