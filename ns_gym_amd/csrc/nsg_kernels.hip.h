@@ -22,7 +22,14 @@
 
 namespace nsg {
 
-constexpr int kBlock = 256;
+// Workgroup size: NSG_BLOCK lanes = NSG_BLOCK / 256 consecutive 256-env layout chunks (the chunk-blocked rows are laid out in
+// 256-env chunks whatever the workgroup size, nsg_rng.hip.h blk_off8).  Measured with the counter-based env streams (C1,
+// specialised, 2^20 / 2^22 / 2^24 envs): 256 lanes 26.0 / 87.3 / 460 us, 512 lanes 25.8 / 87.2 / 447, 1024 lanes 26.4 / 87.4 / 447;
+// Acrobot and the full theta-engine lose with the larger ones (63 -> 65 -> 81 us, 34.4 -> 35.3 -> 40.4): 256 stays.
+#ifndef NSG_BLOCK
+#define NSG_BLOCK 256
+#endif
+constexpr int kBlock = NSG_BLOCK;
 constexpr int kMaxTableBytes = 16384;
 constexpr int kCntShards = NSG_CNT_SHARDS;
 // NSG_UNCOND_LOADS 1: the state / action loads do not wait for the episode word (a resetting lane's are discarded).
@@ -123,6 +130,10 @@ __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, 
   zg.we = (const double*)(zexp + 256);
   zg.fe = (const double*)(zexp + 512);
   zg.jump = sg.jump;
+  if (sg.cfg.env_type <= NSG_ENV_MOUNTAINCAR_CONT && sg.buf.rng_env) {  // classic-control env types; unbound handles (nsg_theta_trace) have no rows
+    zg.sd0 = sg.buf.rng_env[0];
+    zg.sd1 = sg.buf.rng_env[1];
+  }
 }
 
 // Where one step's per-env outputs go: the handle's own buffers (nsg_step) or the k-th slice of
@@ -513,7 +524,8 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
       const int owner = lds.reset_list[tid];
       const uint64_t count = slot[owner * 4];
       Pcg g;
-      env_stream_at(b.rng_env, base + owner, count * (uint64_t)T::RESET_DRAWS, zg.jump, g);
+      const u64x2 desc = {zg.sd0, zg.sd1};
+      env_stream_at(b.rng_env, base + owner, count * (uint64_t)T::RESET_DRAWS, zg.jump, g, &desc);
       double r0[T::PHYS];
       env_reset_draw<ENV>(g, r0);
 #pragma unroll
@@ -917,11 +929,12 @@ __global__ __launch_bounds__(kBlock) void step_group_kernel(GroupArgs ga, int ns
 // reset(seed) / reset(): NSWrapper.reset + subclass tails (base.py:365-431,
 // classic_control.py:102-109, toy_text.py:382-399).
 // ============================================================================================
-// `restart`: every (unmasked) env starts its stream over (nsg_reset_seeded: the host has installed a new affine descriptor).
+// `restart`: reset(seed = base_seed + i) for every env (nsg_reset_seeded: the host has installed the affine descriptor), the
+// update fns' streams included (SeedSequence(seed).spawn, base.py:412-421).
 // With `seeds` the host has put the classic-control streams into their per-env form first (materialize_streams_kernel).
 template <int ENV>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict__ seg, const uint64_t* __restrict__ seeds,
-                                                       const uint8_t* __restrict__ mask, int restart) {
+                                                       const uint8_t* __restrict__ mask, int restart, uint64_t base_seed) {
   const Segment& sg = *seg;
   const nsg_config& cfg = sg.cfg;
   const nsg_buffers& b = sg.buf;
@@ -996,9 +1009,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
           else pcg_seed(r, (uint64_t)i, 1000 + p);
           pcg_store_all(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
         }
-      } else if (pc.uses_rng && seeds) {  // SeedSequence(seed).spawn(P)[rng_child], base.py:412-421
+      } else if (pc.uses_rng && (seeds || restart)) {  // SeedSequence(seed).spawn(P)[rng_child], base.py:412-421
         Pcg r;
-        pcg_seed(r, seeds[i], pc.rng_child);
+        pcg_seed(r, seeds ? seeds[i] : base_seed + (uint64_t)i, pc.rng_child);
         pcg_store_all(b.rng_upd + (int64_t)p * 4 * N, N, i, r);
       }
       b.env_change[(int64_t)p * N + i] = 0;

@@ -207,9 +207,16 @@ __host__ __device__ __forceinline__ U128 add128(U128 a, U128 b) {
 // non-zero digit left); a typical n (a few thousand episodes) takes two digits.
 __device__ inline void pcg_at(Pcg& r, uint64_t seed, int child, uint64_t n, const uint64_t* __restrict__ jump) {
   pcg_seed(r, seed, child);
-  U128 A = {0, 1}, G = {0, 0};
-  uint64_t rest = n;
-  for (int d = 0; d < kJumpDigits; d++) {
+  // digit 0 as it stands in the table (entry (0, 0) is the identity), then one composition per further non-zero digit
+  U128 A, G;
+  {
+    const u64x2* e = reinterpret_cast<const u64x2*>(jump + (size_t)(n & 255u) * 4);
+    const u64x2 a = e[0], g = e[1];
+    A = U128{a.x, a.y};
+    G = U128{g.x, g.y};
+  }
+  uint64_t rest = n >> 8;
+  for (int d = 1; d < kJumpDigits; d++) {
     if (__ballot(rest != 0) == 0) break;
     const unsigned v = (unsigned)(rest & 255u);
     rest >>= 8;
@@ -256,8 +263,9 @@ __device__ __forceinline__ void pcg_load(const uint64_t* base, int64_t N, int64_
 // Stream of env i of a classic-control batch, positioned at draw n (buffers.rng_env, include/nsgym_hip.h): record 0 is the
 // batch's descriptor - affine (env i seeded base + i; nothing else is read) or not (record 1 + i holds the env's own seed and
 // spawn key: one 16-byte read by the few lanes that reset).
-__device__ __forceinline__ void env_stream_at(const uint64_t* rng_env, int64_t i, uint64_t n, const uint64_t* jump, Pcg& r) {
-  const u64x2 d = *reinterpret_cast<const u64x2*>(rng_env);
+__device__ __forceinline__ void env_stream_at(const uint64_t* rng_env, int64_t i, uint64_t n, const uint64_t* jump, Pcg& r,
+                                              const u64x2* desc = nullptr) {
+  const u64x2 d = desc ? *desc : *reinterpret_cast<const u64x2*>(rng_env);
   uint64_t seed;
   int key;
   if (d.x & NSG_STREAM_AFFINE) {
@@ -310,6 +318,8 @@ struct ZigLds {
   const double* we;
   const double* fe;
   const uint64_t* jump = nullptr;  // PCG64 jump-ahead table (global memory), pcg_at
+  uint64_t sd0 = 0, sd1 = 0;       // classic-control envs: the batch's stream descriptor (buffers.rng_env[0..1]), fetched once per
+                                   // workgroup next to the table staging so that the reset hand-over does not wait for it
 };
 
 __device__ inline double pcg_std_normal(Pcg& g, const ZigLds& z) {

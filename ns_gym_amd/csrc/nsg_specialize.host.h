@@ -103,11 +103,11 @@ inline std::string spec_source(const nsg_config& cfg, bool full) {
   snprintf(buf, sizeof(buf), "%d, %s", (int)cfg.env_type, full ? "true" : "false");
   const std::string targs = buf;
   s += "#define NSG_SPEC_CFG (*reinterpret_cast<const nsg_config*>(nsg::kCfgWords))\n"
-       "extern \"C\" __global__ __launch_bounds__(256) void nsg_spec_step(const nsg::Segment* __restrict__ seg,\n"
+       "extern \"C\" __global__ __launch_bounds__(NSG_BLOCK, NSG_MIN_WAVES) void nsg_spec_step(const nsg::Segment* __restrict__ seg,\n"
        "                                                                const void* __restrict__ actions, int reverse) {\n"
        "  nsg::step_body<" + targs + ">(NSG_SPEC_CFG, *seg, actions, (int)blockIdx.x, (int)gridDim.x, reverse);\n"
        "}\n"
-       "extern \"C\" __global__ __launch_bounds__(256) void nsg_spec_rollout(const nsg::Segment* __restrict__ seg,\n"
+       "extern \"C\" __global__ __launch_bounds__(NSG_BLOCK) void nsg_spec_rollout(const nsg::Segment* __restrict__ seg,\n"
        "                                                                   const void* __restrict__ actions, int k_steps,\n"
        "                                                                   nsg_rollout_out ro) {\n"
        "  nsg::rollout_body<" + targs + ">(NSG_SPEC_CFG, *seg, actions, k_steps, ro);\n"
@@ -141,7 +141,7 @@ inline std::string group_source(const nsg_config* const* cfgs, const bool* full,
       "namespace nsg {\n";
   for (int k = 0; k < n; k++) emit_cfg_words(s, *cfgs[k], k);
   s += "}  // namespace nsg\n"
-       "extern \"C\" __global__ __launch_bounds__(256) void nsg_spec_group(nsg::GroupArgs ga, int nseg,\n"
+       "extern \"C\" __global__ __launch_bounds__(NSG_BLOCK, NSG_MIN_WAVES) void nsg_spec_group(nsg::GroupArgs ga, int nseg,\n"
        "                                                                 nsg::ActionPtrs acts, int reverse) {\n"
        "  const int sidx = nsg::group_segment_of_block(ga, nseg);\n"
        "  const nsg::Segment& sg = *ga.seg[sidx];\n"
@@ -192,7 +192,9 @@ inline std::vector<char> compile_source(const std::string& src, const char* arch
   }
   const std::string archopt = std::string("--offload-arch=") + arch;
   // the same flags as the library build (csrc/Makefile): contraction off keeps the float64 rounding sequence
-  std::vector<const char*> opts = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function"};
+  // the unit's workgroup size is the library's (the host launches both with kBlock threads)
+  static const std::string blockopt = "-DNSG_BLOCK=" + std::to_string(NSG_BLOCK);
+  std::vector<const char*> opts = {archopt.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function", blockopt.c_str()};
   // tuning knob (tools/ab.py): extra -D / -m options for the specialised unit, space-separated
   std::vector<std::string> extra;
   if (const char* e = getenv("NSG_SPEC_FLAGS")) {

@@ -150,7 +150,7 @@ uint64_t spec_source_hash() {
   if (const char* e = getenv("NSG_SPEC_FLAGS")) h1 = nsg_spec::fnv1a(e, strlen(e), h1);  // extra compile options are part of the key
   // so are the fixed options of nsg_spec::compile_source (keep this literal in step with them) and the toolchain the
   // library was built with: code objects persist on disk between processes (spec_cache_dir)
-  static const char kFixed[] = "-O3 -std=c++17 -ffp-contract=off -Wno-unused-function hip " HIP_VERSION_STR;
+  static const char kFixed[] = "-O3 -std=c++17 -ffp-contract=off -Wno-unused-function block " NSG_STR(NSG_BLOCK) " hip " HIP_VERSION_STR;
   h1 = nsg_spec::fnv1a(kFixed, sizeof(kFixed), h1);
   return h1;
 }
@@ -431,7 +431,7 @@ static int grid_cap() {  // tuning knob (tools/kbench.py sweeps it); default fro
   static int cap = 0;
   if (!cap) {
     const char* e = getenv("NSG_GRID_CAP");
-    cap = e ? atoi(e) : 4096;
+    cap = e ? atoi(e) : 4096 * 256 / kBlock;   // 2^20 envs per launch round, whatever the workgroup size
     if (cap < 1 || cap > NSG_CNT_SHARDS / (kBlock / 64)) cap = NSG_CNT_SHARDS / (kBlock / 64);  // one counter shard per wavefront slot
   }
   return cap;
@@ -485,7 +485,7 @@ int nsg_reset(nsg_handle* h, const uint64_t* seeds_dev, const uint8_t* mask_dev,
     hipLaunchKernelGGL(stream_set_kernel, dim3(1), dim3(1), 0, s, h->dev, 0ULL, 0ULL);
   }
   DISPATCH_ENV(h->host.cfg.env_type,
-               hipLaunchKernelGGL(reset_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, seeds_dev, mask_dev, 0));
+               hipLaunchKernelGGL(reset_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, seeds_dev, mask_dev, 0, (uint64_t)0));
   HIP_TRY(hipGetLastError());
   return NSG_OK;
 }
@@ -504,7 +504,7 @@ int nsg_reset_seeded(nsg_handle* h, uint64_t base_seed, void* stream) {
     HIP_TRY(hipMallocAsync((void**)&seeds, sizeof(uint64_t) * (size_t)h->n, s));
     hipLaunchKernelGGL(iota_seeds_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, s, seeds, base_seed, h->n);
     DISPATCH_ENV(h->host.cfg.env_type,
-                 hipLaunchKernelGGL(reset_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, (const uint64_t*)seeds, (const uint8_t*)nullptr, 0));
+                 hipLaunchKernelGGL(reset_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, (const uint64_t*)seeds, (const uint8_t*)nullptr, 0, (uint64_t)0));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipFreeAsync(seeds, s));
     return NSG_OK;
@@ -512,7 +512,7 @@ int nsg_reset_seeded(nsg_handle* h, uint64_t base_seed, void* stream) {
   // classic-control envs: env i <- PCG64(SeedSequence(base + i)), kept in the affine form (one descriptor, nothing per env)
   hipLaunchKernelGGL(stream_set_kernel, dim3(1), dim3(1), 0, s, h->dev, NSG_STREAM_AFFINE | 0xffffffffULL, base_seed);
   DISPATCH_ENV(h->host.cfg.env_type,
-               hipLaunchKernelGGL(reset_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, (const uint64_t*)nullptr, (const uint8_t*)nullptr, 1));
+               hipLaunchKernelGGL(reset_kernel<E>, dim3(grid_for(h->n)), dim3(kBlock), 0, s, h->dev, (const uint64_t*)nullptr, (const uint8_t*)nullptr, 1, base_seed));
   HIP_TRY(hipGetLastError());
   return NSG_OK;
 }

@@ -89,7 +89,7 @@ def test_many_episodes_per_env_stay_on_the_stream():
         if k % 500 == 499:
             compare_views(g._out(), o._out(), False, f"step {k}")
     ep = (g.env.buf["episode"] >> 1).cpu().numpy()
-    assert ep.min() > 100 and ep.max() > 256          # beyond one table digit
+    assert ep.min() > 40 and ep.max() > 100           # (counts beyond one table digit: the large-count test below)
     g.env.close()
 
 
