@@ -321,7 +321,9 @@ def _pmc_traffic(n_envs):
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f)["step_kernel_cartpole_specialised"]["bytes_per_env_step"] * n_envs
+            doc = json.load(f)
+            key = "r02_step_kernel_cartpole_specialised_2p20" if "r02_step_kernel_cartpole_specialised_2p20" in doc else "step_kernel_cartpole_specialised"
+            return doc[key]["bytes_per_env_step"] * n_envs
     except Exception:
         return None
 

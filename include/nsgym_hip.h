@@ -256,7 +256,8 @@ typedef struct nsg_buffers {
                             IS +-t) or paid only by the step that ends the episode (FrozenLake with default rewards,
                             Bridge: the return IS that reward); last_return is derived when an episode ends        */
   int32_t* ep_length;    /* [N]    running episode length                                 */
-  float* last_return;    /* [N]    return of the last finished episode                    */
+  float* last_return;    /* [N]    return of the last finished episode.  NULL for CartPole (+1 per step) and MountainCar (-1 per
+                            step): their return is +-last_length                                              */
   int32_t* last_length;  /* [N]                                                           */
   uint64_t* counters;    /* [NSG_CNT_COUNT][NSG_CNT_SHARDS] running totals                */
   uint64_t* done_bits;   /* [ceil(N/64)] wavefront ballot of "episode ended this step":
@@ -413,6 +414,9 @@ int nsg_calib_copy_f64(const double* src_dev, double* dst_dev, int64_t n, void* 
 int nsg_specialize(nsg_handle* h);
 int nsg_is_specialized(const nsg_handle* h);
 int nsg_spec_build(const nsg_config* cfg, const char* arch, void** code_out, size_t* size_out);
+/* the same for the unit nsg_step_group uses when every member is specialised: one kernel (nsg_spec_group) for the ordered tuple
+ * of the members' configs */
+int nsg_spec_build_group(const nsg_config* const* cfgs, int32_t n, const char* arch, void** code_out, size_t* size_out);
 void nsg_spec_free(void* code);
 
 int nsg_destroy(nsg_handle* h);

@@ -77,6 +77,7 @@ struct LdsTables {
   double* reset_state;  // [kBlock][4] initial states drawn by the helper lanes, read back by the owners
   uint64_t* blob;       // constant-table blob
   uint64_t* zig;        // 768 words (normal) + 768 words (exponential), each only when needed
+  uint64_t* streams;    // [kBlock][4] fused rollouts of the classic envs: every lane's env stream, derived ONCE per launch (rollout_body)
   uint64_t* ustreams;   // [kMaxLdsUpd][kBlock][4] the chunk's update-fn streams (first stochastic fns) during a fused rollout
 };
 constexpr int kLdsStreamBytes = kBlock * 32;
@@ -108,7 +109,8 @@ __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, 
   lds.reset_state = (double*)(base + 32 + kBlock * 2);
   lds.blob = (uint64_t*)(base + kLdsHeaderBytes);
   lds.zig = (uint64_t*)(base + kLdsHeaderBytes + ((sg.table_bytes + 7) & ~7));
-  lds.ustreams = (uint64_t*)(base + lds_bytes_for(sg.table_bytes, sg.uses_normal, sg.uses_exp));  // valid when the launch reserved it (fused rollouts)
+  lds.streams = (uint64_t*)(base + lds_bytes_for(sg.table_bytes, sg.uses_normal, sg.uses_exp));  // valid when the launch reserved it (fused rollouts)
+  lds.ustreams = lds.streams + kBlock * 4;
   const int tid = threadIdx.x;
   uint64_t* zexp = lds.zig + (sg.uses_normal ? 768 : 0);
   if (sg.uses_normal) {
@@ -225,7 +227,8 @@ struct IoMode {  // wave-uniform
   bool load;   // fetch the persistent rows from memory (else: they are in the LaneState)
   bool store;  // write them back
   bool dirty;  // the LaneState's θ rows 0/1 may differ from memory (earlier fused steps did not store)
-  bool lds_rng;  // fused rollouts: the chunk's first stochastic update fns' PCG64 records are in LDS (upd_stream_load)
+  bool lds_rng;  // fused rollouts: the chunk's env streams (derived once per launch) and its first stochastic update fns' PCG64
+                 // records are in LDS: a reset inside the launch is four sequential draws, not a re-derivation
   bool wt = false;  // single-step launches (nsg_step): persistent rows of the grid envs / Pendulum state leave through
                     // agent-scope stores (stg_wt); fused rollouts keep plain stores (C3 rollout: 12.3 vs 14.6 us per step)
 };
@@ -524,10 +527,19 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
       const int owner = lds.reset_list[tid];
       const uint64_t count = slot[owner * 4];
       Pcg g;
-      const u64x2 desc = {zg.sd0, zg.sd1};
-      env_stream_at(b.rng_env, base + owner, count * (uint64_t)T::RESET_DRAWS, zg.jump, g, &desc);
+      if (io.lds_rng) {   // fused rollout: the lane's stream sits in LDS, positioned at its next episode
+        const uint64_t* rec = lds.streams + owner * 4;
+        g.sh = rec[0]; g.sl = rec[1]; g.ih = rec[2]; g.il = rec[3];
+      } else {
+        const u64x2 desc = {zg.sd0, zg.sd1};
+        env_stream_at(b.rng_env, base + owner, count * (uint64_t)T::RESET_DRAWS, zg.jump, g, &desc);
+      }
       double r0[T::PHYS];
       env_reset_draw<ENV>(g, r0);
+      if (io.lds_rng) {
+        uint64_t* rec = lds.streams + owner * 4;
+        rec[0] = g.sh; rec[1] = g.sl;
+      }
 #pragma unroll
       for (int k = 0; k < T::PHYS; k++) lds.reset_state[owner * 4 + k] = r0[k];
     }
@@ -564,10 +576,9 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     if (io.store) stg(b.episode, o4, (int32_t)stw);
     if (track) {  // the episode length is the wrapper time t: only the return needs a running row
       if constexpr (kReturnFromT) {
-        if (done) {
-          stg(b.last_return, o4, T::RETURN_PER_STEP * (float)tnew);
-          stg(b.last_length, o4, tnew);
-        }
+        // one scattered store per finished episode, not two: the return of these env types IS +-length (buffers.last_return is
+        // not allocated for them; VecNSEnv.episode_returns derives it)
+        if (done) stg(b.last_length, o4, tnew);
       } else {
         er += (float)reward;
         if (done) {
@@ -1022,8 +1033,8 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
     b.truncated[i] = 0;
     if constexpr (GRID) b.status[i] = 0;
     if (cfg.flags & NSG_F_TRACK_RETURNS) {
-      b.ep_return[i] = 0.f;
-      b.ep_length[i] = 0;
+      if (b.ep_return) b.ep_return[i] = 0.f;
+      if (b.ep_length) b.ep_length[i] = 0;
     }
     // clear THIS env's bit of the ballot word only: a masked reset must neither wipe the bits of envs that are done but were
     // not reset nor leave the bit of a reset env standing (nsg_compact_done reads these words)
@@ -1091,7 +1102,10 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const Segment* __restrict_
     b.terminated[i] = 0;
     b.truncated[i] = 0;
     if (cfg.flags & NSG_F_TRACK_RETURNS) {
-      b.ep_return[i] = 0.f; b.ep_length[i] = 0; b.last_return[i] = 0.f; b.last_length[i] = 0;
+      if (b.ep_return) b.ep_return[i] = 0.f;
+      if (b.ep_length) b.ep_length[i] = 0;
+      if (b.last_return) b.last_return[i] = 0.f;
+      b.last_length[i] = 0;
     }
     if (b.done_bits && (i & 63) == 0) b.done_bits[i >> 6] = 0;
   }
@@ -1289,8 +1303,8 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
     db.terminated[i] = sb.terminated[is];
     db.truncated[i] = sb.truncated[is];
     if (ds.cfg.flags & NSG_F_TRACK_RETURNS) {
-      db.ep_return[i] = (cfg.flags & NSG_F_TRACK_RETURNS) ? sb.ep_return[is] : 0.f;
-      db.last_return[i] = 0.f;
+      if (db.ep_return) db.ep_return[i] = ((cfg.flags & NSG_F_TRACK_RETURNS) && sb.ep_return) ? sb.ep_return[is] : 0.f;
+      if (db.last_return) db.last_return[i] = 0.f;
       db.last_length[i] = 0;
     }
     const unsigned long long done_mask = __ballot(((fl ? (int)sb.status[is] : sb.episode[is]) & (int)NSG_ST_NEEDS_RESET) != 0);  // == the source's ballot word when N == Ns

@@ -35,6 +35,20 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
     // classic envs: the first stochastic update fns' streams live in LDS for the K steps (each lane touches only its own
     // record); the env's own np_random needs no state at all (episode word + jump-ahead, nsg_rng.hip.h)
     [[maybe_unused]] const int64_t ir = c * kBlock + threadIdx.x;
+    if constexpr (!GRID) {
+      // every lane derives its env stream ONCE per launch (seed -> jump to draw D * episodes so far: ~500 instructions, all lanes
+      // busy) and parks it in LDS: the resets of the K fused steps then draw sequentially from there (4 PCG64 steps each)
+      // instead of re-deriving the stream at every reset like nsg_step's hand-over has to
+      if (ir < N) {
+        Pcg g;
+        const uint64_t count = (uint64_t)((uint32_t)ldg(b.episode, (uint32_t)ir * 4u) >> NSG_EP_COUNT_SHIFT);
+        const u64x2 desc = {zg.sd0, zg.sd1};
+        env_stream_at(b.rng_env, ir, count * (uint64_t)EnvTraits<GRID ? NSG_ENV_CARTPOLE : ENV>::RESET_DRAWS, zg.jump, g, &desc);
+        uint64_t* rec = lds.streams + threadIdx.x * 4;
+        rec[0] = g.sh; rec[1] = g.sl; rec[2] = g.ih; rec[3] = g.il;
+      }
+      if constexpr (!FULL) __syncthreads();
+    }
     if constexpr (!GRID && FULL) {
       if (ir < N) {
         for (int p = 0; p < cfg.n_params; p++) {
@@ -73,6 +87,7 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
       }
       parity ^= 1;
     }
+    if constexpr (!GRID && !FULL) __syncthreads();  // the next chunk refills the env streams
     if constexpr (!GRID && FULL) {
       __syncthreads();
       if (ir < N) {

@@ -352,10 +352,13 @@ int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
   out->delta_change = (int64_t)(P > 0 ? P : 1) * n;
   out->prob = fl ? n : 0;
   out->violation = ((cfg->flags & NSG_F_VIOLATION_MASK) && !fl) ? (int64_t)(P > 0 ? P : 1) * n : 0;
+  // episode accounting (NSG_F_TRACK_RETURNS): CartPole pays +1 and MountainCar -1 on EVERY step, so their episode return is
+  // +-length: no running-return row and no last_return row (one scattered store per finished episode instead of two)
   const bool tr = (cfg->flags & NSG_F_TRACK_RETURNS) != 0;
-  out->ep_return = tr ? n : 0;
-  out->ep_length = tr ? n : 0;
-  out->last_return = tr ? n : 0;
+  const bool ret_from_len = e == NSG_ENV_CARTPOLE || e == NSG_ENV_MOUNTAINCAR;
+  out->ep_return = (tr && !ret_from_len) ? n : 0;
+  out->ep_length = 0;          // the running length is the wrapper time t
+  out->last_return = (tr && !ret_from_len) ? n : 0;
   out->last_length = tr ? n : 0;
   out->counters = NSG_CNT_COUNT * NSG_CNT_SHARDS;
   out->done_bits = (n + 63) / 64;
@@ -439,6 +442,16 @@ static int grid_cap() {  // tuning knob (tools/kbench.py sweeps it); default fro
 static int grid_for(int64_t n) {
   int64_t chunks = (n + kBlock - 1) / kBlock;
   return (int)(chunks < grid_cap() ? chunks : grid_cap());
+}
+// Workgroups of an nsg_step launch.  Batches of up to 2^20 envs (<= 4096 chunks) of the plain-arithmetic theta-engine run best
+// with 6 workgroups per CU (1536), every one resident from the start and walking 2-3 chunks - not with one workgroup per chunk
+// dispatched in two rounds: C1 2^19 envs 16.0 -> 14.1 us, 2^20 25.8 -> 25.0, Pendulum 20.9 -> 19.8, C3 19.5 -> 19.1 (5 and 7
+// per CU and the full engine, which runs at lower occupancy, do not gain: 2^20 C1 25.7 / 27.4, C2 35.5 -> 37.9); from 2^21 envs
+// on the cap of 4096 is best (45.4 vs 47.2 us).  NSG_GRID_CAP overrides.
+static int step_grid_for(const nsg_handle* h) {
+  const int64_t chunks = (h->n + kBlock - 1) / kBlock;
+  if (!getenv("NSG_GRID_CAP") && h->host.simple_theta && chunks > 1536 && chunks <= 4096) return 1536 * 256 / kBlock;
+  return grid_for(h->n);
 }
 
 int nsg_bind(nsg_handle* h, const nsg_buffers* bufs) {
@@ -529,7 +542,7 @@ int nsg_step(nsg_handle* h, const void* actions_dev, void* stream) {
   if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
   if (!actions_dev) return fail(NSG_EINVAL, "actions_dev is NULL");
   hipStream_t s = (hipStream_t)stream;
-  const int grid = grid_for(h->n);
+  const int grid = step_grid_for(h);
   const size_t lds = (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp);
   int reverse = next_traversal(h);
   if (h->spec) {
@@ -556,7 +569,7 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
   hipStream_t s = (hipStream_t)stream;
   // fused rollouts of the classic envs keep the chunk's env PCG64 records in LDS
   const size_t rollout_lds = (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp) +
-                             (is_grid_env(h->host.cfg.env_type) ? 0 : kLdsStreamBytes * upd_lds_count(h->host.cfg));
+                             (is_grid_env(h->host.cfg.env_type) ? 0 : kLdsStreamBytes * (1 + upd_lds_count(h->host.cfg)));
   if (h->spec) {
     void* args[] = {(void*)&h->dev, (void*)&actions_dev, (void*)&k_steps, (void*)&o};
     HIP_TRY(hipModuleLaunchKernel(h->spec->rollout, grid_for(h->n), 1, 1, kBlock, 1, 1, (unsigned)rollout_lds, s, args, nullptr));
@@ -807,6 +820,29 @@ int nsg_spec_build(const nsg_config* cfg, const char* arch, void** code_out, siz
     if (!upd_kind_is_simple(cfg->params[p].upd_kind) || sched_is_stochastic(cfg->params[p].sched_kind)) full = true;
   std::string err;
   std::vector<char> code = nsg_spec::spec_compile(*cfg, full, arch && *arch ? arch : "gfx950", err);
+  if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
+  void* p = malloc(code.size());
+  if (!p) return fail(NSG_ENOMEM, "out of host memory");
+  memcpy(p, code.data(), code.size());
+  *code_out = p;
+  *size_out = code.size();
+  return NSG_OK;
+}
+
+int nsg_spec_build_group(const nsg_config* const* cfgs, int32_t n, const char* arch, void** code_out, size_t* size_out) {
+  if (!code_out || !size_out || !cfgs || n <= 0 || n > NSG_MAX_SEGMENTS) return fail(NSG_EINVAL, "bad arguments");
+  *code_out = nullptr;
+  *size_out = 0;
+  bool full[NSG_MAX_SEGMENTS];
+  for (int k = 0; k < n; k++) {
+    int rc = validate(cfgs[k], (size_t)kMaxTableBytes);
+    if (rc) return rc;
+    full[k] = false;
+    for (int p = 0; p < cfgs[k]->n_params; p++)
+      if (!upd_kind_is_simple(cfgs[k]->params[p].upd_kind) || sched_is_stochastic(cfgs[k]->params[p].sched_kind)) full[k] = true;
+  }
+  std::string err;
+  std::vector<char> code = nsg_spec::group_compile(cfgs, full, n, arch && *arch ? arch : "gfx950", err);
   if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
   void* p = malloc(code.size());
   if (!p) return fail(NSG_ENOMEM, "out of host memory");

@@ -376,9 +376,14 @@ class VecNSEnv:
         return idx[: int(cnt.item())]
 
     def episode_returns(self):
-        if self.buf["last_return"] is None:
+        """(return, length) of every env's last finished episode (length 0 = none yet).  CartPole pays +1 and MountainCar -1 on
+        every step, so their return is +-length and no return row is kept for them (a derived tensor is returned)."""
+        if self.buf["last_length"] is None:
             raise ValueError("construct with track_returns=True")
-        return self.buf["last_return"], self.buf["last_length"]
+        length = self.buf["last_length"]
+        if self.buf["last_return"] is not None:
+            return self.buf["last_return"], length
+        return length.to(torch.float32) * (1.0 if self.cfg.env_type == A.ENV_CARTPOLE else -1.0), length
 
     def time_steps(self, actions, iters: int) -> float:
         """Average device milliseconds per `nsg_step` launch over `iters` back-to-back launches,

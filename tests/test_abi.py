@@ -55,7 +55,12 @@ def test_layout_query_is_pure_host_arithmetic(lib):
     # classic-control envs: an episode word per env and NO per-env stream state (rng_env = descriptor + (seed, spawn key) records)
     assert (lay.episode, lay.status) == (1000, 0)
     assert (lay.phys_dim, lay.obs_dim, lay.n_actions, lay.action_is_float) == (4, 4, 2, 0)
-    assert lay.ep_return == 1000 and lay.counters == A.CNT_COUNT * A.CNT_SHARDS and lay.done_bits == 16
+    # CartPole pays +1 on every step: its episode return is its length - no running-return row, no last_return row
+    assert (lay.ep_return, lay.last_return, lay.last_length) == (0, 0, 1000)
+    assert lay.counters == A.CNT_COUNT * A.CNT_SHARDS and lay.done_bits == 16
+    cfg, _, _, _ = compile_config(make("Pendulum-v1"), {"m": IncrementUpdate(ContinuousScheduler(), k=0.1)}, track_returns=True)
+    assert lib.nsg_layout_query(C.byref(cfg), 1000, C.byref(lay)) == 0
+    assert (lay.ep_return, lay.last_return, lay.last_length) == (1000, 1000, 1000)
     cfg, _, _, _ = compile_config(make("FrozenLake-v1", map_name="8x8"), {"P": DistributionDecrementUpdate(ContinuousScheduler(), 0.1)})
     assert lib.nsg_layout_query(C.byref(cfg), 64, C.byref(lay)) == 0
     assert (lay.cell, lay.theta, lay.table_prob, lay.obs, lay.prob, lay.phys, lay.rng_env) == (64, 192, 768, 0, 64, 0, 1024)   # chunk-blocked rows pad to 256 envs

@@ -54,3 +54,26 @@ def test_bad_config_is_rejected_not_compiled():
     code, size = C.c_void_p(), C.c_size_t()
     assert lib.nsg_spec_build(C.byref(cfg), b"gfx950", C.byref(code), C.byref(size)) == -22
     assert not code.value and size.value == 0
+
+
+def test_group_unit_compiles_for_gfx950():
+    """The heterogeneous launch's specialised unit (nsg_spec_group) for C4's pair of configs: compiles without a GPU."""
+    from ns_gym_amd import _lib
+    from ns_gym_amd.envs import make
+    from ns_gym_amd.spec import build_tunable_params, compile_config
+
+    lib = _lib.load()
+    cfgs = []
+    for name in ("c4_pendulum_m_inc", "c4_acrobot_mass2_inc", "c3_frozenlake_step50"):
+        spec = TRAJ_SPECS[name]
+        cfgs.append(compile_config(make(spec["env_id"], **spec.get("make_kwargs", {})), build_tunable_params(spec["params"]),
+                                   **{**spec["flags"], **spec.get("wrapper_kwargs", {})})[0])
+    arr = (C.c_void_p * len(cfgs))(*[C.cast(C.pointer(c), C.c_void_p) for c in cfgs])
+    code, size = C.c_void_p(), C.c_size_t()
+    rc = lib.nsg_spec_build_group(arr, len(cfgs), b"gfx950", C.byref(code), C.byref(size))
+    if rc == -95 and b"libhiprtc" in lib.nsg_last_error():
+        pytest.skip("libhiprtc.so not available in this environment")
+    assert rc == 0, lib.nsg_last_error().decode()
+    data = C.string_at(code, size.value)
+    lib.nsg_spec_free(code)
+    assert data[:4] == b"\x7fELF" and b"nsg_spec_group" in data

@@ -1,7 +1,3 @@
-python -m pytest tests/test_gpu_env_streams.py tests/test_gpu_parity.py tests/test_gpu_rollout.py tests/test_gpu_reference_update_fns.py -x -q > gpurun_out/r02s_tests.log 2>&1; tail -3 gpurun_out/r02s_tests.log
-rm -f gpurun_out/r02s_ab.log
-for n in 1048576 4194304 16777216; do
-  it=300; [ $n -gt 5000000 ] && it=60
-  python tools/ab.py "lib:spec,lib:spec:-DNSG_MIN_WAVES=8" c1 3 $n $it >> gpurun_out/r02s_ab.log 2>&1
-done
-cat gpurun_out/r02s_ab.log
+python -m pytest tests/test_gpu_rollout.py tests/test_gpu_harness.py tests/test_gpu_planning.py tests/test_gpu_random_configs.py tests/test_gpu_env_streams.py -x -q > gpurun_out/r02x_tests.log 2>&1; tail -2 gpurun_out/r02x_tests.log
+python tools/kbench.py --work c1,c2,pend,acro,c3 --spec --rollout 64 > gpurun_out/r02x_rollout.log 2>&1; cat gpurun_out/r02x_rollout.log | cut -c1-150
+python tools/kbench.py --work c1,c2,pend,acro,c3,mcar --spec > gpurun_out/r02x_step.log 2>&1; cat gpurun_out/r02x_step.log | cut -c1-150

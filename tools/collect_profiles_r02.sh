@@ -1,0 +1,32 @@
+#!/bin/bash
+# Round-2 profile collection (GPU box; run from the repo root through gpurun).  Every profiler invocation is bounded by `timeout`.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r02prof; mkdir -p $O
+python bench.py > $O/bench.json 2> $O/bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.log
+echo "stats rc=$?"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-hbm-resident > $O/pmc_$c.log 2>&1; echo "$c rc=$?"
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc24_$c -o p -- python3 tools/kbench.py --work c1 --n 16777216 --iters 20 --spec > $O/pmc24_$c.log 2>&1; echo "$c 2^24 rc=$?"
+done
+for w in c1 acro; do
+  timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --kernel-trace --output-format csv -d $O/sq1_$w -o p -- python3 tools/kbench.py --work $w --iters 60 --spec > $O/sq1_$w.log 2>&1; echo "sq1 $w rc=$?"
+  timeout -k 10 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq2_$w -o p -- python3 tools/kbench.py --work $w --iters 60 --spec > $O/sq2_$w.log 2>&1; echo "sq2 $w rc=$?"
+done
+python tools/measure_all.py > $O/kbench_all_configs.json 2> $O/kbench_all.err
+python - > $O/size_sweep.json <<'PY'
+import json, subprocess, sys
+rows = []
+for lg in (12, 14, 16, 18, 19, 20, 21, 22, 23, 24):
+    for extra, tag in (([], "nsg_step"), (["--rollout", "64"], "nsg_rollout_k64")):
+        if tag != "nsg_step" and lg in (19, 21, 23):
+            continue
+        out = subprocess.run([sys.executable, "tools/kbench.py", "--work", "c1", "--n", str(1 << lg), "--spec", "--iters", "300" if lg <= 22 else "60"] + extra,
+                             capture_output=True, text=True).stdout
+        for line in out.splitlines():
+            if line.startswith("c1 "):
+                rows.append({"envs_log2": lg, "api": tag, **json.loads(line.split(" ", 1)[1])})
+print(json.dumps({"workload": "C1 (CartPole masspole IncrementUpdate / ContinuousScheduler), config-specialised kernels, one GPU box, one call",
+                  "rows_bytes_per_env": 124, "infinity_cache_MiB": 256, "rows": rows}, indent=1))
+PY
+ls $O

@@ -79,8 +79,17 @@ def main():
             ms = best
         else:
             ms = min(e.time_steps(a, args.iters) for _ in range(3))
-        gbs = WORK[name][3] * n / (ms * 1e-3) / 1e9
-        res[name] = {"us": ms * 1e3, "GB/s": gbs, "frac": gbs / 8000, "Gsteps/s": n / (ms * 1e-3) / 1e9}
+        if args.rollout:
+            # a fused rollout keeps the persistent rows in registers: per env-step it moves the action (4 B) and the recorded
+            # outputs (obs + reward 4 + terminated 1 + truncated 1) only - NOT the step API's algorithmic bytes
+            per = 4 + (4 if e.is_grid else 4 * e.obs_dim) + 6
+            gbs = per * n / (ms * 1e-3) / 1e9
+            res[name] = {"us_per_step": ms * 1e3, "Gsteps/s": n / (ms * 1e-3) / 1e9, "hbm_bytes_per_env_step": per, "GB/s": gbs,
+                         "frac_of_8TBs": gbs / 8000, "bound": "instruction issue + the reset hand-over's barriers (DESIGN.md), not HBM"}
+        else:
+            gbs = WORK[name][3] * n / (ms * 1e-3) / 1e9
+            res[name] = {"us": ms * 1e3, "algorithmic_bytes_per_env_step": WORK[name][3], "GB/s": gbs, "frac": gbs / 8000,
+                         "Gsteps/s": n / (ms * 1e-3) / 1e9}
         print(name, json.dumps(res[name]), flush=True)
         e.close()
     if "pend" in args.work and "acro" in args.work:  # C4: heterogeneous launch, 2^18 each
