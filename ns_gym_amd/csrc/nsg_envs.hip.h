@@ -22,14 +22,19 @@ template <int ENV> struct EnvTraits;
 // RETURN_PER_STEP: env types whose reward is the same constant on EVERY step (CartPole-v1: 1.0 incl. the terminating
 // step; MountainCar-v0: -1.0) - their episode return is RETURN_PER_STEP * t exactly (float32 sums of +-1 are exact far
 // beyond any TimeLimit), so the kernels derive last_return from t instead of round-tripping a running-return row.
-template <> struct EnvTraits<NSG_ENV_CARTPOLE> { static constexpr int RESET_DRAWS = 4, PHYS = 4, OBS = 4, NTHETA = 6, NDERIVED = 2; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = 1.f; };
-template <> struct EnvTraits<NSG_ENV_PENDULUM> { static constexpr int RESET_DRAWS = 2, NDERIVED = 0, PHYS = 2, OBS = 3, NTHETA = 4; static constexpr bool FLOAT_ACT = true; static constexpr float RETURN_PER_STEP = 0.f; };
-template <> struct EnvTraits<NSG_ENV_ACROBOT> { static constexpr int RESET_DRAWS = 4, NDERIVED = 0, PHYS = 4, OBS = 6, NTHETA = 8; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = 0.f; };
-template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR> { static constexpr int RESET_DRAWS = 1, NDERIVED = 0, PHYS = 2, OBS = 2, NTHETA = 2; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = -1.f; };
-template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR_CONT> { static constexpr int RESET_DRAWS = 1, NDERIVED = 0, PHYS = 2, OBS = 2, NTHETA = 1; static constexpr bool FLOAT_ACT = true; static constexpr float RETURN_PER_STEP = 0.f; };
+template <> struct EnvTraits<NSG_ENV_CARTPOLE> { static constexpr bool RESET_IN_LANE = false; static constexpr int RESET_DRAWS = 4, PHYS = 4, OBS = 4, NTHETA = 6, NDERIVED = 2; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = 1.f; };
+template <> struct EnvTraits<NSG_ENV_PENDULUM> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 2, NDERIVED = 0, PHYS = 2, OBS = 3, NTHETA = 4; static constexpr bool FLOAT_ACT = true; static constexpr float RETURN_PER_STEP = 0.f; };
+template <> struct EnvTraits<NSG_ENV_ACROBOT> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 4, NDERIVED = 0, PHYS = 4, OBS = 6, NTHETA = 8; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = 0.f; };
+template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 1, NDERIVED = 0, PHYS = 2, OBS = 2, NTHETA = 2; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = -1.f; };
+template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR_CONT> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 1, NDERIVED = 0, PHYS = 2, OBS = 2, NTHETA = 1; static constexpr bool FLOAT_ACT = true; static constexpr float RETURN_PER_STEP = 0.f; };
 
 // ---- reset draws: np_random.uniform(low, high) = low + (high - low) * next_double ----------
 // EnvTraits::RESET_DRAWS = how many doubles a reset takes from the env's stream (the kernels jump to draw RESET_DRAWS * episode)
+// EnvTraits::RESET_IN_LANE: how the step kernels run the reset path (seed -> jump-ahead -> draws, ~550 instructions).  CartPole
+// under random actions ends ~5 % of its episodes per step, i.e. 96 % of the wavefronts hold a resetting lane: the resets are
+// compacted per workgroup (two barriers, ONE wavefront runs the path).  The other env types end 0.5-1 % per step (TimeLimit
+// 200-999, rare terminations): half or more of the wavefronts hold no resetting lane at all, so each lane runs its own reset and
+// the step has no barrier - measured at 2^20 envs: Acrobot 58.5 -> see DESIGN.md, C4's mixed launch likewise.
 template <int ENV> __device__ __forceinline__ void env_reset_draw(Pcg& g, double* s) {
   if constexpr (ENV == NSG_ENV_CARTPOLE) {
 #pragma unroll

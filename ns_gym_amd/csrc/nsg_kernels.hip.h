@@ -512,6 +512,24 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   // ~5 % of the envs reset per step but they sit in ~96 % of the wavefronts; compacting them per workgroup lets ONE wavefront
   // execute the seeding + jump-ahead + draw path.  No stream state is read from or written to memory (nsg_rng.hip.h, pcg_at):
   // the owner hands its episode count over through LDS, the helper rebuilds PCG64(SeedSequence(seed_i)) at draw D * count.
+  if constexpr (T::RESET_IN_LANE) {
+    // rare resets (nsg_envs.hip.h): every resetting lane re-derives its own stream and draws; no queue, no barrier
+    if (do_reset) {
+      Pcg g;
+      if (io.lds_rng) {   // fused rollout: the lane's stream sits in LDS, positioned at its next episode
+        const uint64_t* rec = lds.streams + tid * 4;
+        g.sh = rec[0]; g.sl = rec[1]; g.ih = rec[2]; g.il = rec[3];
+      } else {
+        const u64x2 desc = {zg.sd0, zg.sd1};
+        env_stream_at(b.rng_env, i, (uint64_t)(st >> NSG_EP_COUNT_SHIFT) * (uint64_t)T::RESET_DRAWS, zg.jump, g, &desc);
+      }
+      env_reset_draw<ENV>(g, s);
+      if (io.lds_rng) {
+        uint64_t* rec = lds.streams + tid * 4;
+        rec[0] = g.sh; rec[1] = g.sl;
+      }
+    }
+  } else
   {
     int* rn = lds.reset_n + (parity & 1);
     uint64_t* slot = reinterpret_cast<uint64_t*>(lds.reset_state);
