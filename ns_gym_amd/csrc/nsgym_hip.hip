@@ -630,8 +630,9 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
       static const int kEnvCost[NSG_ENV_COUNT] = {3, 2, 8, 1, 1, 2, 2, 2};  // relative time per workgroup
       return kEnvCost[hs[k]->host.cfg.env_type] + (hs[k]->host.simple_theta ? 0 : 2);
     };
+    static const bool shortest_first = [] { const char* e = getenv("NSG_GROUP_ORDER"); return e && e[0] == 's'; }();
     for (int a = 1; a < n_handles; a++)
-      for (int b = a; b > 0 && cost(order[b]) > cost(order[b - 1]); b--) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+      for (int b = a; b > 0 && (shortest_first ? cost(order[b]) < cost(order[b - 1]) : cost(order[b]) > cost(order[b - 1])); b--) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
     memset(&plan.ga, 0, sizeof(plan.ga));
     int begin = 0;
     for (int j = 0; j < n_handles; j++) {

@@ -3,8 +3,10 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02prof; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline --no-hbm-resident > $O/bench_under_rocprof.json 2> $O/stats.log
 echo "stats rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats24 -o s -- python3 tools/kbench.py --work c1 --n 16777216 --iters 100 --spec > $O/kbench24_under_rocprof.log 2> $O/stats24.log
+echo "stats24 rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-hbm-resident > $O/pmc_$c.log 2>&1; echo "$c rc=$?"
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc24_$c -o p -- python3 tools/kbench.py --work c1 --n 16777216 --iters 20 --spec > $O/pmc24_$c.log 2>&1; echo "$c 2^24 rc=$?"
@@ -14,6 +16,8 @@ for w in c1 acro; do
   timeout -k 10 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq2_$w -o p -- python3 tools/kbench.py --work $w --iters 60 --spec > $O/sq2_$w.log 2>&1; echo "sq2 $w rc=$?"
 done
 python tools/measure_all.py > $O/kbench_all_configs.json 2> $O/kbench_all.err
+python tools/kbench.py --work c1,c2,c3,pend,acro,mcar --n 4194304 --iters 100 --spec > $O/kbench_2p22.log 2>&1
+python tools/group_probe.py > $O/group_probe.log 2>&1
 python - > $O/size_sweep.json <<'PY'
 import json, subprocess, sys
 rows = []
