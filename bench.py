@@ -158,6 +158,7 @@ def main():
         env.step(pool[k % 8])
     if dist is not None:
         all_gather_returns(env, sizes=[n] * world)  # warm the RCCL communicator
+    env.episode_returns()   # warm-up of the end-of-rollout read-out (its first use loads torch's elementwise kernels: ~50 ms once)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()

@@ -383,7 +383,10 @@ class VecNSEnv:
         length = self.buf["last_length"]
         if self.buf["last_return"] is not None:
             return self.buf["last_return"], length
-        return length.to(torch.float32) * (1.0 if self.cfg.env_type == A.ENV_CARTPOLE else -1.0), length
+        if getattr(self, "_ret_derived", None) is None:
+            self._ret_derived = torch.empty(self.N, dtype=torch.float32, device=self.device)
+        torch.mul(length, 1.0 if self.cfg.env_type == A.ENV_CARTPOLE else -1.0, out=self._ret_derived)   # one small kernel
+        return self._ret_derived, length
 
     def time_steps(self, actions, iters: int) -> float:
         """Average device milliseconds per `nsg_step` launch over `iters` back-to-back launches,
