@@ -53,20 +53,13 @@ struct Segment {
   int32_t uses_exp;        // Memoryless (p < 1/3) / RandomCategorical -> stage the exponential ziggurat tables
   int32_t simple_theta;    // every update fn is plain arithmetic / table look-up (upd_kind_is_simple)
   const uint64_t* jump;    // PCG64 jump-ahead table (nsg_rng.hip.h, pcg_at): kJumpWords words, global copy
+  int32_t block_begin;     // heterogeneous launch (nsg_step_group) only: first block and block count of this member in the
+  int32_t block_count;     // launch's segment table (a per-plan COPY of the members' segments, see nsgym_hip.hip)
 };
 
 struct ActionPtrs {
   const void* p[NSG_MAX_SEGMENTS];
 };
-// Heterogeneous launch (nsg_step_group): every member's OWN device-resident Segment (kept current by nsg_bind) plus the block
-// range it takes in this launch, all by value in the kernel arguments - nothing shared between launches that a later call
-// could overwrite under a launch still in flight.
-struct GroupArgs {
-  const Segment* seg[NSG_MAX_SEGMENTS];
-  int32_t block_begin[NSG_MAX_SEGMENTS];
-  int32_t block_count[NSG_MAX_SEGMENTS];
-};
-
 // Dynamic LDS layout (sized per handle at launch: a batch with tiny tables must not pay 22 KB of
 // LDS per workgroup, which would cap residency at 6-7 workgroups per CU):
 //   [ pad | reset_n[2] | pad | reset_list[kBlock] (short) | reset_state[kBlock][4] (f64) |
@@ -928,20 +921,24 @@ __global__ __launch_bounds__(kBlock, NSG_MIN_WAVES) void step_kernel(const Segme
 
 // Heterogeneous launch: block ranges are assigned to env-type segments, so the env-type switch
 // is uniform per workgroup (no intra-wave divergence between Pendulum and Acrobot lanes).
-__device__ __forceinline__ int group_segment_of_block(const GroupArgs& ga, int nseg) {
+// The segment table of a heterogeneous launch reaches the kernel as a `const … __restrict__` kernel argument: that is what
+// lets the compiler read the members' configs and row pointers through SCALAR loads.  (Round 2 first passed per-member
+// segment pointers inside a by-value struct: `*args.seg[sidx]` has unknown provenance, every config access became a vector
+// load, and C4's launch went from 24.0 to 28-29 us.)
+__device__ __forceinline__ int group_segment_of_block(const Segment* __restrict__ segs, int nseg) {
   int sidx = 0;  // block ranges are disjoint but not ordered by member index (the host places long-running env types first)
   for (int k = 1; k < nseg; k++)
-    if ((int)blockIdx.x >= ga.block_begin[k] && (int)blockIdx.x < ga.block_begin[k] + ga.block_count[k]) sidx = k;
+    if ((int)blockIdx.x >= segs[k].block_begin && (int)blockIdx.x < segs[k].block_begin + segs[k].block_count) sidx = k;
   return sidx;
 }
 
 template <bool FULL>
-__global__ __launch_bounds__(kBlock) void step_group_kernel(GroupArgs ga, int nseg, ActionPtrs acts, int reverse) {
-  const int sidx = group_segment_of_block(ga, nseg);
-  const Segment& sg = *ga.seg[sidx];
+__global__ __launch_bounds__(kBlock) void step_group_kernel(const Segment* __restrict__ segs, int nseg, ActionPtrs acts, int reverse) {
+  const int sidx = group_segment_of_block(segs, nseg);
+  const Segment& sg = segs[sidx];
   const void* actions = acts.p[sidx];
-  const int rel = (int)blockIdx.x - ga.block_begin[sidx];
-  const int cnt = ga.block_count[sidx];
+  const int rel = (int)blockIdx.x - sg.block_begin;
+  const int cnt = sg.block_count;
   switch (sg.cfg.env_type) {
     case NSG_ENV_CARTPOLE: step_body<NSG_ENV_CARTPOLE, FULL>(sg.cfg, sg, actions, rel, cnt, reverse); break;
     case NSG_ENV_PENDULUM: step_body<NSG_ENV_PENDULUM, FULL>(sg.cfg, sg, actions, rel, cnt, reverse); break;

@@ -141,17 +141,17 @@ inline std::string group_source(const nsg_config* const* cfgs, const bool* full,
       "namespace nsg {\n";
   for (int k = 0; k < n; k++) emit_cfg_words(s, *cfgs[k], k);
   s += "}  // namespace nsg\n"
-       "extern \"C\" __global__ __launch_bounds__(NSG_BLOCK, NSG_MIN_WAVES) void nsg_spec_group(nsg::GroupArgs ga, int nseg,\n"
+       "extern \"C\" __global__ __launch_bounds__(NSG_BLOCK, NSG_MIN_WAVES) void nsg_spec_group(const nsg::Segment* __restrict__ segs, int nseg,\n"
        "                                                                 nsg::ActionPtrs acts, int reverse) {\n"
-       "  const int sidx = nsg::group_segment_of_block(ga, nseg);\n"
-       "  const nsg::Segment& sg = *ga.seg[sidx];\n"
-       "  const int rel = (int)blockIdx.x - ga.block_begin[sidx];\n"
+       "  const int sidx = nsg::group_segment_of_block(segs, nseg);\n"
+       "  const nsg::Segment& sg = segs[sidx];\n"
+       "  const int rel = (int)blockIdx.x - sg.block_begin;\n"
        "  switch (sidx) {\n";
   char buf[256];
   for (int k = 0; k < n; k++) {
     snprintf(buf, sizeof(buf),
              "    case %d: nsg::step_body<%d, %s>(*reinterpret_cast<const nsg_config*>(nsg::kCfgWords%d), sg, acts.p[%d], rel, "
-             "ga.block_count[sidx], reverse); break;\n",
+             "sg.block_count, reverse); break;\n",
              k, (int)cfgs[k]->env_type, full[k] ? "true" : "false", k, k);
     s += buf;
   }

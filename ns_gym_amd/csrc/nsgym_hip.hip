@@ -600,21 +600,34 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
 
 int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* actions_dev, void* stream) {
   if (!hs || !actions_dev || n_handles <= 0 || n_handles > NSG_MAX_SEGMENTS) return fail(NSG_EINVAL, "bad group arguments");
-  // Every launch carries its members' device segments and block ranges in its kernel arguments (GroupArgs): there is no
-  // table shared between launches.  What the calling thread remembers between calls is host-side only - the block ranges
-  // and the group's specialised unit for the last member list - and valid for one generation of the library's handles.
+  // The launch reads a segment table: copies of its members' segments with their block ranges, passed as a `const
+  // __restrict__` kernel argument (scalar loads, see step_group_kernel).  A table is written ONCE, when the plan for a member
+  // list is made (each of the calling thread's few plans owns its table; a plan slot is re-planned only after a device
+  // synchronisation), so alternating member lists never overwrite a table that a launch in flight may still read; and a plan is valid for one generation of the library's handles (bumped by nsg_bind,
+  // nsg_specialize and nsg_destroy on any thread), so a table never outlives the segments it was copied from.
   struct Plan {
     nsg_handle* members[NSG_MAX_SEGMENTS];
     int n_members = 0;
     unsigned long long built_at = ~0ULL;
-    GroupArgs ga;
+    Segment* d_table = nullptr;
     int total_blocks = 0, all_simple = 0, group_lds = 0, device = -1;
     const nsg_spec::Module* group_spec = nullptr;
   };
-  static thread_local Plan plan;
+  // a few plans per calling thread (callers that alternate member lists keep theirs); a slot's table is overwritten only
+  // after a device synchronisation
+  constexpr int kPlans = 4;
+  static thread_local Plan plans[kPlans];
+  static thread_local unsigned next_victim = 0;
   const unsigned long long gen = g_generation.load();
-  bool same = plan.n_members == n_handles && plan.built_at == gen;
-  for (int k = 0; same && k < n_handles; k++) same = plan.members[k] == hs[k];
+  int which = -1;
+  for (int q = 0; q < kPlans && which < 0; q++) {
+    bool same = plans[q].n_members == n_handles && plans[q].built_at == gen;
+    for (int k = 0; same && k < n_handles; k++) same = plans[q].members[k] == hs[k];
+    if (same) which = q;
+  }
+  const bool same = which >= 0;
+  if (!same) which = (int)(next_victim++ % kPlans);
+  Plan& plan = plans[which];
   if (!same) {
     int order[NSG_MAX_SEGMENTS];
     for (int k = 0; k < n_handles; k++) {
@@ -633,15 +646,19 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
     static const bool shortest_first = [] { const char* e = getenv("NSG_GROUP_ORDER"); return e && e[0] == 's'; }();
     for (int a = 1; a < n_handles; a++)
       for (int b = a; b > 0 && (shortest_first ? cost(order[b]) < cost(order[b - 1]) : cost(order[b]) > cost(order[b - 1])); b--) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
-    memset(&plan.ga, 0, sizeof(plan.ga));
+    Segment tmp[NSG_MAX_SEGMENTS];
     int begin = 0;
+    for (int k = 0; k < n_handles; k++) tmp[k] = hs[k]->host;
     for (int j = 0; j < n_handles; j++) {
       const int k = order[j];
-      plan.ga.seg[k] = hs[k]->dev;
-      plan.ga.block_begin[k] = begin;
-      plan.ga.block_count[k] = grid_for(hs[k]->n);
-      begin += plan.ga.block_count[k];
+      tmp[k].block_begin = begin;
+      tmp[k].block_count = grid_for(hs[k]->n);
+      begin += tmp[k].block_count;
     }
+    if (plan.d_table) HIP_TRY(hipDeviceSynchronize());   // launches that read this slot's old table have drained
+    if (plan.d_table && plan.device != hs[0]->device) { (void)hipFree(plan.d_table); plan.d_table = nullptr; }
+    if (!plan.d_table) HIP_TRY(hipMalloc((void**)&plan.d_table, sizeof(Segment) * NSG_MAX_SEGMENTS));
+    HIP_TRY(hipMemcpy(plan.d_table, tmp, sizeof(Segment) * n_handles, hipMemcpyHostToDevice));
     for (int k = 0; k < n_handles; k++) plan.members[k] = hs[k];
     plan.n_members = n_handles;
     plan.built_at = gen;
@@ -682,7 +699,7 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
     ap.p[k] = actions_dev[k];
   }
   int reverse = next_traversal(hs[0]);   // the members of a group alternate together
-  GroupArgs ga = plan.ga;
+  const Segment* ga = plan.d_table;
   if (plan.group_spec) {
     void* args[] = {(void*)&ga, (void*)&n_handles, (void*)&ap, (void*)&reverse};
     HIP_TRY(hipModuleLaunchKernel(plan.group_spec->group, plan.total_blocks, 1, 1, kBlock, 1, 1, (unsigned)plan.group_lds, (hipStream_t)stream, args, nullptr));
