@@ -1,4 +1,9 @@
-python -m pytest tests/test_gpu_env_streams.py tests/test_gpu_parity.py tests/test_gpu_rollout.py tests/test_gpu_specialized.py tests/test_gpu_harness.py tests/test_gpu_planning.py tests/test_gpu_fullsize.py -x -q > gpurun_out/r02z_tests.log 2>&1; tail -2 gpurun_out/r02z_tests.log
-python tools/kbench.py --work c1,c2,pend,acro,c3,mcar --spec > gpurun_out/r02z_step.log 2>&1; cat gpurun_out/r02z_step.log | cut -c1-150
-python tools/kbench.py --work pend,acro,mcar --spec --rollout 64 2>&1 | cut -c1-120
-python tools/kbench.py --work pend,acro --n 262144 --spec 2>&1 | cut -c1-150
+python -m pytest tests/test_gpu_env_streams.py tests/test_gpu_parity.py tests/test_gpu_rollout.py tests/test_gpu_specialized.py -x -q 2>&1 | tail -1
+NSG_HELPER_WAVE=1 NSG_SPEC_FLAGS="-DNSG_HELPER_LANES=64 -DNSG_MIN_WAVES=8" python -m pytest tests/test_gpu_env_streams.py tests/test_gpu_specialized.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -1
+rm -f gpurun_out/r02ab_ab.log
+for n in 262144 524288 1048576 4194304 16777216; do
+  it=300; [ $n -gt 5000000 ] && it=60
+  python tools/ab.py "lib:spec,lib:spec:-DNSG_MIN_WAVES=8" c1 2 $n $it >> gpurun_out/r02ab_ab.log 2>&1
+  NSG_HELPER_WAVE=1 python tools/ab.py "lib:spec:-DNSG_HELPER_LANES=64 -DNSG_MIN_WAVES=8" c1 2 $n $it >> gpurun_out/r02ab_ab.log 2>&1
+done
+cat gpurun_out/r02ab_ab.log
