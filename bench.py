@@ -154,6 +154,15 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # Setup (untimed, before the W warm-up steps): one pass over the 8-entry action pool.  The timed loop cycles through the pool;
+    # an entry no launch of this process has read yet costs its first launch ~4 us of address-translation misses at the start
+    # of every workgroup (rocprofv3 kernel trace of `--steps 20 --warmup 5`: 28.4 / 27.5 / 27.8 us for the launches that read
+    # pool[5..7] for the first time, 24.0-24.4 us for the others; tools/trace_gaps.py).  A policy kernel that has just WRITTEN
+    # its actions leaves their pages translated, so the steady state the metric is about is the warm one.  Reported as
+    # config.setup_steps.
+    SETUP_STEPS = len(pool)
+    for k in range(SETUP_STEPS):
+        env.step(pool[k])
     for k in range(args.warmup):
         env.step(pool[k % 8])
     if dist is not None:
@@ -251,7 +260,7 @@ def main():
             "config": {
                 "workload": "CartPole-v1 + masspole IncrementUpdate(+0.1)/ContinuousScheduler (BASELINE C1/C5 config), "
                             f"{n} envs per GPU, random actions, next-step autoreset, episode returns tracked",
-                "envs_per_gpu": n, "total_envs": n * world,
+                "envs_per_gpu": n, "total_envs": n * world, "setup_steps": SETUP_STEPS,
                 "parallelism": f"env-sharded x{world}, no per-step collective; 1 all-gather of episode returns at rollout end"
                                if world > 1 else "single GPU",
                 "episodes_finished_rank0": episodes_rank0,

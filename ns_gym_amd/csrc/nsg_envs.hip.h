@@ -22,7 +22,10 @@ template <int ENV> struct EnvTraits;
 // RETURN_PER_STEP: env types whose reward is the same constant on EVERY step (CartPole-v1: 1.0 incl. the terminating
 // step; MountainCar-v0: -1.0) - their episode return is RETURN_PER_STEP * t exactly (float32 sums of +-1 are exact far
 // beyond any TimeLimit), so the kernels derive last_return from t instead of round-tripping a running-return row.
-template <> struct EnvTraits<NSG_ENV_CARTPOLE> { static constexpr bool RESET_IN_LANE = false; static constexpr int RESET_DRAWS = 4, PHYS = 4, OBS = 4, NTHETA = 6, NDERIVED = 2; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = 1.f; };
+#ifndef NSG_CARTPOLE_INLANE   // measurement knob: 1 = CartPole resets in-lane too (no hand-over, no barriers)
+#define NSG_CARTPOLE_INLANE 0
+#endif
+template <> struct EnvTraits<NSG_ENV_CARTPOLE> { static constexpr bool RESET_IN_LANE = NSG_CARTPOLE_INLANE != 0; static constexpr int RESET_DRAWS = 4, PHYS = 4, OBS = 4, NTHETA = 6, NDERIVED = 2; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = 1.f; };
 template <> struct EnvTraits<NSG_ENV_PENDULUM> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 2, NDERIVED = 0, PHYS = 2, OBS = 3, NTHETA = 4; static constexpr bool FLOAT_ACT = true; static constexpr float RETURN_PER_STEP = 0.f; };
 template <> struct EnvTraits<NSG_ENV_ACROBOT> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 4, NDERIVED = 0, PHYS = 4, OBS = 6, NTHETA = 8; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = 0.f; };
 template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 1, NDERIVED = 0, PHYS = 2, OBS = 2, NTHETA = 2; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = -1.f; };

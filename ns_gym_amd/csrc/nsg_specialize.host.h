@@ -81,7 +81,7 @@ inline const Rtc* rtc() {
 // ---- the specialised translation unit ----------------------------------------------------------
 // The config is emitted as its raw 64-bit words (independent of the struct's field list) and viewed
 // as nsg_config; after inlining every access is a load from a constant at a constant offset.
-inline std::string spec_source(const nsg_config& cfg, bool full) {
+inline std::string spec_source(const nsg_config& cfg, bool full, bool resets_in_lane = false) {
   static_assert(sizeof(nsg_config) % 8 == 0, "nsg_config is emitted as 64-bit words");
   std::string s;
   s.reserve(16384);
@@ -89,7 +89,9 @@ inline std::string spec_source(const nsg_config& cfg, bool full) {
       "typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
       "typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t;\n"
       "typedef unsigned long size_t;\n"
-      "#define NSG_SPEC_BUILD 1\n"
+      "#define NSG_SPEC_BUILD 1\n";
+  if (resets_in_lane) s += "#define NSG_CARTPOLE_INLANE 1\n";   // batch-size policy of nsg_specialize (nsg_envs.hip.h)
+  s +=
       "#include \"nsg_rollout.hip.h\"\n"
       "namespace nsg {\n"
       "__device__ const uint64_t kCfgWords[] = {\n";
@@ -162,8 +164,8 @@ inline std::string group_source(const nsg_config* const* cfgs, const bool* full,
 inline std::vector<char> compile_source(const std::string& src, const char* arch, std::string& err);
 
 // Compile the specialised unit for `arch` (e.g. "gfx950"); no GPU needed.  Returns "" and fills `err` on failure.
-inline std::vector<char> spec_compile(const nsg_config& cfg, bool full, const char* arch, std::string& err) {
-  return compile_source(spec_source(cfg, full), arch, err);
+inline std::vector<char> spec_compile(const nsg_config& cfg, bool full, const char* arch, std::string& err, bool resets_in_lane = false) {
+  return compile_source(spec_source(cfg, full, resets_in_lane), arch, err);
 }
 inline std::vector<char> group_compile(const nsg_config* const* cfgs, const bool* full, int n, const char* arch, std::string& err) {
   return compile_source(group_source(cfgs, full, n), arch, err);

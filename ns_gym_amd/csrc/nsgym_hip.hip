@@ -881,10 +881,15 @@ int nsg_specialize(nsg_handle* h) {
   // key: config bytes + engine variant + target (+ the kernel sources this library was built from)
   uint64_t h0 = nsg_spec::fnv1a(&h->host.cfg, sizeof(nsg_config));
   h0 = nsg_spec::fnv1a(&full, sizeof(full), h0);
+  // CartPole batches of 2^16-2^17 envs (one wavefront per SIMD: the launch is bound by its serial chain) reset in-lane like the
+  // rare-reset env types - no hand-over, no barriers: C1 5.84 -> 5.60 us and C2 (BASELINE's own 65 536 envs) 7.80 -> 7.29 us at
+  // 2^16, +-0 at 2^17; smaller and larger batches lose (2^14: 5.3 -> 6.0, 2^18: 9.4 -> 10.1, 2^20: 23.7 -> 26.1)
+  const bool inlane = h->host.cfg.env_type == NSG_ENV_CARTPOLE && h->n >= 49152 && h->n <= 163840;
+  h0 = nsg_spec::fnv1a(&inlane, sizeof(inlane), h0);
   h0 = nsg_spec::fnv1a(prop.gcnArchName, strlen(prop.gcnArchName), h0);
   if (const char* e = getenv("NSG_SPEC_FLAGS")) h0 = nsg_spec::fnv1a(e, strlen(e), h0);
   const int rc = get_spec_module(h->device, h0, false,
-                                 [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err); }, &h->spec);
+                                 [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err, inlane); }, &h->spec);
   g_generation++;   // a group that contains this handle re-plans (its specialised unit depends on every member's)
   return rc;
 }
