@@ -306,9 +306,12 @@ int nsg_reset(nsg_handle* h, const uint64_t* seeds_dev, const uint8_t* mask_dev,
  * (buffers.rng_env): no per-env seed record is read when an env resets. */
 int nsg_reset_seeded(nsg_handle* h, uint64_t base_seed, void* stream);
 
-/* Host-side construction of the PCG64 jump-ahead table the kernels use (nsg_rng.hip.h): 5 x 256 x 4 uint64 words
- * (A_hi, A_lo, G_hi, G_lo for the exponent v * 256^d).  No GPU needed; exported so that the table can be checked against
- * plain big-integer arithmetic (tests/test_jump_table_cpu.py). */
+/* Host-side construction of the PCG64 jump-ahead table the kernels use (nsg_rng.hip.h): NSG_JUMP_TABLE_WORDS uint64 words,
+ * 4 per entry (A_hi, A_lo, G_hi, G_lo): NSG_JUMP_LOW entries for the exponents 0 .. NSG_JUMP_LOW-1, then 4 x 256 entries for
+ * the exponents v * 256^d (d = 1 .. 4).  No GPU needed; exported so that the table can be checked against plain big-integer
+ * arithmetic (tests/test_jump_table_cpu.py). */
+#define NSG_JUMP_LOW 264
+#define NSG_JUMP_TABLE_WORDS ((NSG_JUMP_LOW + 4 * 256) * 4)
 void nsg_pcg64_jump_table(uint64_t* out_words);
 
 /* Replaces NSClassicControlWrapper.step / NSFrozenLakeWrapper.step -> NSWrapper.step ->

@@ -38,19 +38,25 @@ template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR_CONT> { static constexpr bool R
 // compacted per workgroup (two barriers, ONE wavefront runs the path).  The other env types end 0.5-1 % per step (TimeLimit
 // 200-999, rare terminations): half or more of the wavefronts hold no resetting lane at all, so each lane runs its own reset and
 // the step has no barrier - measured at 2^20 envs: Acrobot 58.5 -> see DESIGN.md, C4's mixed launch likewise.
-template <int ENV> __device__ __forceinline__ void env_reset_draw(Pcg& g, double* s) {
+// Component k of the initial state from the k-th uniform double of reset() [UPSTREAM]; k < RESET_DRAWS.
+template <int ENV> __device__ __forceinline__ double env_reset_map(int k, double u) {
   if constexpr (ENV == NSG_ENV_CARTPOLE) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) s[k] = -0.05 + (0.05 - -0.05) * pcg_double(g);
+    return -0.05 + (0.05 - -0.05) * u;
   } else if constexpr (ENV == NSG_ENV_PENDULUM) {
-    s[0] = -NSG_PI + (NSG_PI - -NSG_PI) * pcg_double(g);
-    s[1] = -1.0 + (1.0 - -1.0) * pcg_double(g);
+    return k == 0 ? -NSG_PI + (NSG_PI - -NSG_PI) * u : -1.0 + (1.0 - -1.0) * u;
   } else if constexpr (ENV == NSG_ENV_ACROBOT) {  // .astype(np.float32) upstream
-#pragma unroll
-    for (int k = 0; k < 4; k++) s[k] = (double)(float)(-0.1 + (0.1 - -0.1) * pcg_double(g));
+    return (double)(float)(-0.1 + (0.1 - -0.1) * u);
   } else {  // MountainCar / MountainCarContinuous: [uniform(-0.6, -0.4), 0]
-    s[0] = -0.6 + (-0.4 - -0.6) * pcg_double(g);
-    s[1] = 0.0;
+    return -0.6 + (-0.4 - -0.6) * u;
+  }
+}
+// READY: `g` already stands AFTER the step of its next draw (pcg_at<2>): the first uniform is the output of the state as it is.
+template <int ENV, bool READY = false> __device__ __forceinline__ void env_reset_draw(Pcg& g, double* s) {
+  using T = EnvTraits<ENV>;
+#pragma unroll
+  for (int k = 0; k < T::PHYS; k++) {
+    if (k < T::RESET_DRAWS) s[k] = env_reset_map<ENV>(k, (READY && k == 0) ? pcg_double_out(g) : pcg_double(g));
+    else s[k] = 0.0;
   }
 }
 

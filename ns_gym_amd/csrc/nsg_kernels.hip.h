@@ -33,6 +33,9 @@ constexpr int kBlock = NSG_BLOCK;
 constexpr int kMaxTableBytes = 16384;
 constexpr int kCntShards = NSG_CNT_SHARDS;
 // NSG_UNCOND_LOADS 1: the state / action loads do not wait for the episode word (a resetting lane's are discarded).
+#ifndef NSG_RESET_LANE_PER_DRAW
+#define NSG_RESET_LANE_PER_DRAW 1   // single-step reset hand-over: D helper lanes per reset (one draw each) instead of one
+#endif
 #ifndef NSG_UNCOND_LOADS
 #define NSG_UNCOND_LOADS 1
 #endif
@@ -62,11 +65,11 @@ struct ActionPtrs {
 };
 // Dynamic LDS layout (sized per handle at launch: a batch with tiny tables must not pay 22 KB of
 // LDS per workgroup, which would cap residency at 6-7 workgroups per CU):
-//   [ pad | reset_n[2] | pad | reset_list[kBlock] (short) | reset_state[kBlock][4] (f64) |
+//   [ pad | reset_n[2] | pad | reset_q[kBlock] (u64) | reset_state[kBlock][4] (f64) |
 //     table blob | ziggurat ki/wi/fi | streams[kBlock][4] (u64; fused rollouts of classic envs only) ]
 struct LdsTables {
   int* reset_n;         // [2] workgroup-level compaction of the autoreset lanes (double-buffered)
-  short* reset_list;    // [kBlock] lanes whose env resets in this chunk
+  uint64_t* reset_q;    // [kBlock] queue of the chunk's resetting envs: (episode count << 16) | owner lane
   double* reset_state;  // [kBlock][4] initial states drawn by the helper lanes, read back by the owners
   uint64_t* blob;       // constant-table blob
   uint64_t* zig;        // 768 words (normal) + 768 words (exponential), each only when needed
@@ -87,7 +90,7 @@ __host__ __device__ inline int upd_lds_count(const nsg_config& cfg) {
   const int n = upd_lds_index(cfg, cfg.n_params);
   return n < kMaxLdsUpd ? n : kMaxLdsUpd;
 }
-constexpr int kLdsHeaderBytes = 32 + kBlock * 2 + kBlock * 4 * 8;
+constexpr int kLdsHeaderBytes = 32 + kBlock * 8 + kBlock * 4 * 8;
 
 __host__ __device__ inline int lds_bytes_for(int table_bytes, int uses_normal, int uses_exp) {
   return kLdsHeaderBytes + ((table_bytes + 7) & ~7) + (uses_normal ? 768 * 8 : 0) + (uses_exp ? 768 * 8 : 0);
@@ -98,8 +101,8 @@ __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, 
   extern __shared__ __attribute__((aligned(16))) unsigned char nsg_dyn_lds[];
   unsigned char* base = nsg_dyn_lds;
   lds.reset_n = (int*)(base + 16);
-  lds.reset_list = (short*)(base + 32);
-  lds.reset_state = (double*)(base + 32 + kBlock * 2);
+  lds.reset_q = (uint64_t*)(base + 32);
+  lds.reset_state = (double*)(base + 32 + kBlock * 8);
   lds.blob = (uint64_t*)(base + kLdsHeaderBytes);
   lds.zig = (uint64_t*)(base + kLdsHeaderBytes + ((sg.table_bytes + 7) & ~7));
   lds.streams = (uint64_t*)(base + lds_bytes_for(sg.table_bytes, sg.uses_normal, sg.uses_exp));  // valid when the launch reserved it (fused rollouts)
@@ -510,62 +513,76 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     if (do_reset) {
       Pcg g;
       if (io.lds_rng) {   // fused rollout: the lane's stream sits in LDS, positioned at its next episode
-        const uint64_t* rec = lds.streams + tid * 4;
-        g.sh = rec[0]; g.sl = rec[1]; g.ih = rec[2]; g.il = rec[3];
-      } else {
-        const u64x2 desc = {zg.sd0, zg.sd1};
-        env_stream_at(b.rng_env, i, (uint64_t)(st >> NSG_EP_COUNT_SHIFT) * (uint64_t)T::RESET_DRAWS, zg.jump, g, &desc);
-      }
-      env_reset_draw<ENV>(g, s);
-      if (io.lds_rng) {
         uint64_t* rec = lds.streams + tid * 4;
+        g.sh = rec[0]; g.sl = rec[1]; g.ih = rec[2]; g.il = rec[3];
+        env_reset_draw<ENV>(g, s);
         rec[0] = g.sh; rec[1] = g.sl;
+      } else {            // jump straight to the state whose output is the episode's first draw
+        const u64x2 desc = {zg.sd0, zg.sd1};
+        env_stream_at<2>(b.rng_env, i, (uint64_t)(st >> NSG_EP_COUNT_SHIFT) * (uint64_t)T::RESET_DRAWS, zg.jump, g, &desc);
+        env_reset_draw<ENV, true>(g, s);
       }
     }
   } else
   {
+    constexpr int D = T::RESET_DRAWS;
+    static_assert(kBlock <= 65536 && (64 % D) == 0, "queue entry packing / helper-lane grouping");
     int* rn = lds.reset_n + (parity & 1);
-    uint64_t* slot = reinterpret_cast<uint64_t*>(lds.reset_state);
-    if (do_reset) {
-      const int q = atomicAdd(rn, 1);
-      lds.reset_list[q] = (short)tid;
-      slot[tid * 4] = (uint64_t)(st >> NSG_EP_COUNT_SHIFT);
-    }
+    if (do_reset) lds.reset_q[atomicAdd(rn, 1)] = ((uint64_t)(st >> NSG_EP_COUNT_SHIFT) << 16) | (uint64_t)tid;
     __syncthreads();
     const int n_reset = *rn;
     if (tid == 0) lds.reset_n[(parity + 1) & 1] = 0;  // the other buffer is idle until the next chunk
-    if (tid < n_reset) {  // helper lane: gymnasium reset() -> np_random draws of the initial state [UPSTREAM]
-      const int owner = lds.reset_list[tid];
-      const uint64_t count = slot[owner * 4];
-      Pcg g;
-      if (io.lds_rng) {   // fused rollout: the lane's stream sits in LDS, positioned at its next episode
-        const uint64_t* rec = lds.streams + owner * 4;
-        g.sh = rec[0]; g.sl = rec[1]; g.ih = rec[2]; g.il = rec[3];
-      } else {
-        const u64x2 desc = {zg.sd0, zg.sd1};
-        env_stream_at(b.rng_env, base + owner, count * (uint64_t)T::RESET_DRAWS, zg.jump, g, &desc);
-      }
-      double r0[T::PHYS];
-      env_reset_draw<ENV>(g, r0);
-      if (io.lds_rng) {
+    if (io.lds_rng) {
+      // fused rollout: the owner's stream sits in LDS, positioned at its next episode - D sequential draws by one helper lane
+      if (tid < n_reset) {
+        const int owner = (int)(lds.reset_q[tid] & 0xffffu);
         uint64_t* rec = lds.streams + owner * 4;
+        Pcg g = {rec[0], rec[1], rec[2], rec[3]};
+        double r0[T::PHYS];
+        env_reset_draw<ENV>(g, r0);
         rec[0] = g.sh; rec[1] = g.sl;
-      }
 #pragma unroll
-      for (int k = 0; k < T::PHYS; k++) lds.reset_state[owner * 4 + k] = r0[k];
+        for (int k = 0; k < T::PHYS; k++) lds.reset_state[owner * 4 + k] = r0[k];
+      }
+    } else {
+      // single step: D helper lanes per reset, lane (q, j) produces draw j of reset q on its own - gymnasium reset() ->
+      // np_random draws of the initial state [UPSTREAM]: seed -> T0, ONE jump to the state after draw D * count + j's step,
+      // output.  No sequential PCG64 steps at all; a typical chunk's ~13 resets fill one wavefront.
+#if NSG_RESET_LANE_PER_DRAW
+      for (int h = tid; h < n_reset * D; h += kBlock) {
+        const uint64_t qe = lds.reset_q[h / D];
+        const int owner = (int)(qe & 0xffffu), j = h % D;
+        Pcg g;
+        const u64x2 desc = {zg.sd0, zg.sd1};
+        env_stream_at<2>(b.rng_env, base + owner, (qe >> 16) * (uint64_t)D + (uint64_t)j, zg.jump, g, &desc);
+        lds.reset_state[owner * 4 + j] = env_reset_map<ENV>(j, pcg_double_out(g));
+      }
+#else   // one helper lane per reset: one jump, then D - 1 sequential PCG64 steps
+      if (tid < n_reset) {
+        const uint64_t qe = lds.reset_q[tid];
+        const int owner = (int)(qe & 0xffffu);
+        Pcg g;
+        const u64x2 desc = {zg.sd0, zg.sd1};
+        env_stream_at<2>(b.rng_env, base + owner, (qe >> 16) * (uint64_t)D, zg.jump, g, &desc);
+        double r0[T::PHYS];
+        env_reset_draw<ENV, true>(g, r0);
+#pragma unroll
+        for (int k = 0; k < D; k++) lds.reset_state[owner * 4 + k] = r0[k];
+      }
+#endif
     }
     __syncthreads();
     if (do_reset) {
 #pragma unroll
-      for (int k = 0; k < T::PHYS; k++) s[k] = lds.reset_state[tid * 4 + k];
+      for (int k = 0; k < T::PHYS; k++) s[k] = k < D || io.lds_rng ? lds.reset_state[tid * 4 + k] : 0.0;
     }
   }
 
+  // a reset consumed one more episode of the env's stream
+  const unsigned stw = (done ? NSG_ST_NEEDS_RESET : 0u) | (((st >> NSG_EP_COUNT_SHIFT) + (do_reset ? 1u : 0u)) << NSG_EP_COUNT_SHIFT);
 #pragma unroll
   for (int k = 0; k < T::PHYS; k++) ls.s[k] = s[k];
   ls.t = tnew;
-  // a reset consumed one more episode of the env's stream
-  const unsigned stw = (done ? NSG_ST_NEEDS_RESET : 0u) | (((st >> NSG_EP_COUNT_SHIFT) + (do_reset ? 1u : 0u)) << NSG_EP_COUNT_SHIFT);
   ls.st = stw;
   if (active) {  // every row is written by its owner lane: fully coalesced stores
     if (io.store) {
@@ -907,10 +924,9 @@ __device__ __forceinline__ void step_body(const nsg_config& cfg, const Segment& 
   // 22.4 - so the effect is local to the XCD, not the memory-side Infinity Cache (L2 hit / miss counters do not move: DESIGN.md section 4).  A ragged tail of fewer than 8 chunks keeps its
   // place.  Results do not depend on the order.
   const int64_t groups = chunks >> 3;
-  for (int64_t c = block_rel; c < chunks; c += block_count, parity ^= 1) {
-    const int64_t ce = (reverse && (c >> 3) < groups) ? ((groups - 1 - (c >> 3)) << 3) + (c & 7) : c;
-    step_block<ENV, FULL>(cfg, b, N, tb, zg, actions, out, ce * kBlock, parity, lds, wc);
-  }
+  auto chunk_of = [&](int64_t c) { return (reverse && (c >> 3) < groups) ? ((groups - 1 - (c >> 3)) << 3) + (c & 7) : c; };
+  for (int64_t c = block_rel; c < chunks; c += block_count, parity ^= 1)
+    step_block<ENV, FULL>(cfg, b, N, tb, zg, actions, out, chunk_of(c) * kBlock, parity, lds, wc);
   flush_counts(b.counters, block_rel, wc);
 }
 

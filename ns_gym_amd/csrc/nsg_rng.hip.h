@@ -104,6 +104,16 @@ __device__ __forceinline__ uint64_t pcg_next64(Pcg& r) {
   return (x >> rot) | (x << ((64u - rot) & 63u));
 }
 
+// output function alone: the draw whose step has already been taken (pcg_at<2>)
+__device__ __forceinline__ uint64_t pcg_out64(const Pcg& r) {
+  uint64_t x = r.sh ^ r.sl;
+  unsigned rot = (unsigned)(r.sh >> 58);
+  return (x >> rot) | (x << ((64u - rot) & 63u));
+}
+__device__ __forceinline__ double pcg_double_out(const Pcg& r) {
+  return (double)(pcg_out64(r) >> 11) * (1.0 / 9007199254740992.0);
+}
+
 __device__ __forceinline__ double pcg_double(Pcg& r) {
   return (double)(pcg_next64(r) >> 11) * (1.0 / 9007199254740992.0);
 }
@@ -122,8 +132,10 @@ __device__ __forceinline__ uint32_t ss_mix(uint32_t x, uint32_t y) {
   return r;
 }
 
-// Seeds PCG64 exactly like np.random.PCG64(SeedSequence(seed[, spawn_key=(child,)])).
-__device__ inline void pcg_seed(Pcg& r, uint64_t seed, int child) {
+// PCG64(SeedSequence(seed[, spawn_key=(child,)])) one step BEFORE its initial state: r.s = T0 = inc + initstate, r.i = inc.
+// pcg64_srandom_r is "state = 0; step; state += initstate; step", i.e. S_0 = step(T0), and the state after k draws is
+// step^(k+1)(T0): pcg_at folds that last seeding step into its jump.
+__device__ inline void pcg_seed_t0(Pcg& r, uint64_t seed, int child) {
   uint32_t e0 = (uint32_t)seed, e1 = (uint32_t)(seed >> 32);
   // entropy words; with a spawn key the entropy is zero-padded to the pool size (4) first
   uint32_t p0, p1, p2, p3, hc = 0x43b0d7e5u;
@@ -156,15 +168,17 @@ __device__ inline void pcg_seed(Pcg& r, uint64_t seed, int child) {
   }
   uint64_t s_hi = (uint64_t)w[0] | ((uint64_t)w[1] << 32), s_lo = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
   uint64_t q_hi = (uint64_t)w[4] | ((uint64_t)w[5] << 32), q_lo = (uint64_t)w[6] | ((uint64_t)w[7] << 32);
-  // pcg64_srandom_r: state = 0; inc = (initseq << 1) | 1; step; state += initstate; step
+  // pcg64_srandom_r: state = 0; inc = (initseq << 1) | 1; step (-> state = inc); state += initstate; [step: the caller's]
   r.ih = (q_hi << 1) | (q_lo >> 63);
   r.il = (q_lo << 1) | 1ULL;
-  r.sh = 0;
-  r.sl = 0;
-  pcg_step(r);
-  uint64_t lo = r.sl + s_lo;
-  r.sh = r.sh + s_hi + (lo < r.sl ? 1ULL : 0ULL);
+  const uint64_t lo = r.il + s_lo;
+  r.sh = r.ih + s_hi + (lo < r.il ? 1ULL : 0ULL);
   r.sl = lo;
+}
+
+// Seeds PCG64 exactly like np.random.PCG64(SeedSequence(seed[, spawn_key=(child,)])).
+__device__ inline void pcg_seed(Pcg& r, uint64_t seed, int child) {
+  pcg_seed_t0(r, seed, child);
   pcg_step(r);
 }
 
@@ -172,9 +186,10 @@ typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 
 // ---- PCG64 jump-ahead: the stream of env i at draw n, without ever storing the stream ---------------------------------
 // A PCG64 step is S <- S * M + inc (mod 2^128), so after n steps S_n = A_n * S_0 + inc * G_n with A_n = M^n and
-// G_n = 1 + M + ... + M^(n-1) - both independent of the stream.  A_n, G_n for an arbitrary n < 2^40 come from a table of
-// 5 x 256 entries (8-bit digits of n: entry (d, v) holds the pair for the exponent v * 256^d; built on the host in 128-bit
-// integer arithmetic, nsgym_hip.hip) by composing one entry per non-zero digit:
+// G_n = 1 + M + ... + M^(n-1) - both independent of the stream.  A_n, G_n for an arbitrary n < 2^40 come from a table over the
+// 8-bit digits of n - a digit-0 block of kJumpLow entries (entry e holds the pair for the exponent e itself, a little past
+// 255: see LEAD below) followed by 4 blocks of 256 (entry (d, v) holds the pair for the exponent v * 256^d); built on the host
+// in 128-bit integer arithmetic, nsgym_hip.hip - by composing one entry per non-zero digit:
 //     exponents a then b:   A_(a+b) = A_a * A_b,   G_(a+b) = G_a * A_b + G_b.
 // The classic-control envs draw from env.np_random only in reset() (D doubles per reset: CartPole / Acrobot 4, Pendulum 2,
 // MountainCar 1), so the initial state of episode e of env i is draws [D*e, D*e + D) of PCG64(SeedSequence(seed_i)): a pure
@@ -184,7 +199,9 @@ typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 // 2^22 envs 105.9 -> 80.7 us, 2^24 envs 515 -> 423 us: the 32-byte records, touched by the ~5 % of lanes whose env resets,
 // cost more than any other part of the step (tools/stream_probe.hip reproduces it on a bare skeleton).
 constexpr int kJumpDigits = 5;                       // n < 2^40 draws per stream
-constexpr int kJumpWords = kJumpDigits * 256 * 4;    // u64 words: (A_hi, A_lo, G_hi, G_lo) per entry
+constexpr int kJumpLow = 264;                        // digit 0 block: exponents 0 .. 263 (255 + the lead of 1 or 2 steps, padded)
+constexpr int kJumpWords = (kJumpLow + (kJumpDigits - 1) * 256) * 4;   // u64 words: (A_hi, A_lo, G_hi, G_lo) per entry
+static_assert(kJumpLow == NSG_JUMP_LOW && kJumpWords == NSG_JUMP_TABLE_WORDS, "nsgym_hip.h and the kernels disagree on the jump table");
 
 struct U128 {
   uint64_t hi, lo;
@@ -202,26 +219,31 @@ __host__ __device__ __forceinline__ U128 add128(U128 a, U128 b) {
   return U128{a.hi + b.hi + (lo < a.lo ? 1ULL : 0ULL), lo};
 }
 
-// The stream seeded like PCG64(SeedSequence(seed[, spawn_key = (child,)])), advanced by n draws.  `jump`: the table above
-// (global memory; 40 KB, shared by every env, cache-resident).  The digit loop is wave-uniform (it runs while ANY lane has a
-// non-zero digit left); a typical n (a few thousand episodes) takes two digits.
+// The stream seeded like PCG64(SeedSequence(seed[, spawn_key = (child,)])) at draw n.  LEAD = 1: the state BEFORE draw n (what the
+// generator object holds after n draws; pcg_next64 continues from it).  LEAD = 2: the state after draw n's own step - draw n is
+// pcg_out64 of it, no further multiply.  Both are step^(n + LEAD)(T0) = A_(n+LEAD) * T0 + inc * G_(n+LEAD) with T0 from
+// pcg_seed_t0: the table's digit-0 block is indexed by (n mod 256) + LEAD, so the seeding's last step costs nothing.
+// `jump`: the table above (global memory; 41 KB, shared by every env, cache-resident).  The digit loop is wave-uniform (it runs
+// while ANY lane has a non-zero digit left); a typical n (a few thousand episodes) takes two digits.
+template <int LEAD = 1>
 __device__ inline void pcg_at(Pcg& r, uint64_t seed, int child, uint64_t n, const uint64_t* __restrict__ jump) {
-  pcg_seed(r, seed, child);
-  // digit 0 as it stands in the table (entry (0, 0) is the identity), then one composition per further non-zero digit
+  static_assert(LEAD >= 0 && 255 + LEAD < kJumpLow, "digit-0 block too small");
+  pcg_seed_t0(r, seed, child);
   U128 A, G;
   {
-    const u64x2* e = reinterpret_cast<const u64x2*>(jump + (size_t)(n & 255u) * 4);
+    const u64x2* e = reinterpret_cast<const u64x2*>(jump + (size_t)((unsigned)(n & 255u) + (unsigned)LEAD) * 4);
     const u64x2 a = e[0], g = e[1];
     A = U128{a.x, a.y};
     G = U128{g.x, g.y};
   }
+  // one composition per further non-zero digit
   uint64_t rest = n >> 8;
   for (int d = 1; d < kJumpDigits; d++) {
     if (__ballot(rest != 0) == 0) break;
     const unsigned v = (unsigned)(rest & 255u);
     rest >>= 8;
     if (v != 0) {
-      const u64x2* e = reinterpret_cast<const u64x2*>(jump + ((size_t)d * 256 + v) * 4);
+      const u64x2* e = reinterpret_cast<const u64x2*>(jump + ((size_t)kJumpLow + (size_t)(d - 1) * 256 + v) * 4);
       const u64x2 a = e[0], g = e[1];
       const U128 Ad = {a.x, a.y}, Gd = {g.x, g.y};
       G = add128(mul128(G, Ad), Gd);
@@ -263,6 +285,7 @@ __device__ __forceinline__ void pcg_load(const uint64_t* base, int64_t N, int64_
 // Stream of env i of a classic-control batch, positioned at draw n (buffers.rng_env, include/nsgym_hip.h): record 0 is the
 // batch's descriptor - affine (env i seeded base + i; nothing else is read) or not (record 1 + i holds the env's own seed and
 // spawn key: one 16-byte read by the few lanes that reset).
+template <int LEAD = 1>
 __device__ __forceinline__ void env_stream_at(const uint64_t* rng_env, int64_t i, uint64_t n, const uint64_t* jump, Pcg& r,
                                               const u64x2* desc = nullptr) {
   const u64x2 d = desc ? *desc : *reinterpret_cast<const u64x2*>(rng_env);
@@ -276,7 +299,7 @@ __device__ __forceinline__ void env_stream_at(const uint64_t* rng_env, int64_t i
     seed = rec.x;
     key = (int)(uint32_t)rec.y;
   }
-  pcg_at(r, seed, key, n, jump);
+  pcg_at<LEAD>(r, seed, key, n, jump);
 }
 __device__ __forceinline__ void env_stream_set_affine(uint64_t* rng_env, uint64_t base, int key) {
   rng_env[0] = NSG_STREAM_AFFINE | (uint64_t)(uint32_t)key;

@@ -81,7 +81,8 @@ inline const Rtc* rtc() {
 // ---- the specialised translation unit ----------------------------------------------------------
 // The config is emitted as its raw 64-bit words (independent of the struct's field list) and viewed
 // as nsg_config; after inlining every access is a load from a constant at a constant offset.
-inline std::string spec_source(const nsg_config& cfg, bool full, bool resets_in_lane = false) {
+constexpr const char* kGeneratorRev = "spec_source r2.3";   // part of the cache key (nsgym_hip.hip: spec_source_hash)
+inline std::string spec_source(const nsg_config& cfg, bool full, bool resets_in_lane = false, bool six_waves = true) {
   static_assert(sizeof(nsg_config) % 8 == 0, "nsg_config is emitted as 64-bit words");
   std::string s;
   s.reserve(16384);
@@ -91,6 +92,11 @@ inline std::string spec_source(const nsg_config& cfg, bool full, bool resets_in_
       "typedef unsigned long size_t;\n"
       "#define NSG_SPEC_BUILD 1\n";
   if (resets_in_lane) s += "#define NSG_CARTPOLE_INLANE 1\n";   // batch-size policy of nsg_specialize (nsg_envs.hip.h)
+  // CartPole's step is asked to keep 6 wavefronts per SIMD (<= 80 VGPRs): the launch policy (step_grid_for: 6 workgroups per
+  // CU, all resident from the start) is built on it, and at 81 VGPRs the same kernel is 8 % slower (C1 2^20 envs: 23.9 ->
+  // 26.3 us).  The compiler meets the bound without spilling for the usual configs (C1 69, C2 75 VGPRs); a config for which
+  // it cannot is rebuilt without the bound (spec_compile).
+  if (six_waves && cfg.env_type == NSG_ENV_CARTPOLE) s += "#ifndef NSG_MIN_WAVES\n#define NSG_MIN_WAVES 6\n#endif\n";
   s +=
       "#include \"nsg_rollout.hip.h\"\n"
       "namespace nsg {\n"
@@ -163,9 +169,35 @@ inline std::string group_source(const nsg_config* const* cfgs, const bool* full,
 
 inline std::vector<char> compile_source(const std::string& src, const char* arch, std::string& err);
 
+// VGPR spill count of kernel `name` from the code object's metadata note (msgpack: the kernel's map holds its keys in
+// alphabetical order, so ".vgpr_spill_count" follows ".name" of the same kernel).  -1 = not found.
+inline int vgpr_spill_count(const std::vector<char>& code, const char* name) {
+  const std::string kn = std::string(".name") + (char)(0xa0 + strlen(name)) + name;   // fixstr key, fixstr value (< 32 chars)
+  const std::string ks = "\xb1.vgpr_spill_count";                                      // fixstr of 17 chars
+  const std::string blob(code.begin(), code.end());
+  const size_t a = blob.find(kn);
+  if (a == std::string::npos) return -1;
+  const size_t b = blob.find(ks, a);
+  if (b == std::string::npos || b + ks.size() >= blob.size()) return -1;
+  const unsigned char* v = (const unsigned char*)blob.data() + b + ks.size();
+  const size_t left = blob.size() - (b + ks.size());
+  if (v[0] < 0x80) return v[0];                                            // positive fixint
+  if (v[0] == 0xcc && left >= 2) return v[1];                              // uint8
+  if (v[0] == 0xcd && left >= 3) return (v[1] << 8) | v[2];                // uint16
+  if (v[0] == 0xce && left >= 5) return (int)(((unsigned)v[1] << 24) | (v[2] << 16) | (v[3] << 8) | v[4]);
+  return -1;
+}
+
 // Compile the specialised unit for `arch` (e.g. "gfx950"); no GPU needed.  Returns "" and fills `err` on failure.
+// A step kernel that spills vector registers is never shipped: spilling costs more than the occupancy the register bound was
+// asked for (a two-stochastic-param CartPole config: 65-100 spilled VGPRs, 228 B of scratch per lane) - and one such build
+// returned wrong results on MI355X (ROCm 7.2 hiprtc; spill stores placed under a partial exec mask, reloaded under the full
+// one).  Such a config is compiled again without the bound.
 inline std::vector<char> spec_compile(const nsg_config& cfg, bool full, const char* arch, std::string& err, bool resets_in_lane = false) {
-  return compile_source(spec_source(cfg, full, resets_in_lane), arch, err);
+  std::vector<char> code = compile_source(spec_source(cfg, full, resets_in_lane, true), arch, err);
+  if (!code.empty() && vgpr_spill_count(code, "nsg_spec_step") != 0)
+    code = compile_source(spec_source(cfg, full, resets_in_lane, false), arch, err);
+  return code;
 }
 inline std::vector<char> group_compile(const nsg_config* const* cfgs, const bool* full, int n, const char* arch, std::string& err) {
   return compile_source(group_source(cfgs, full, n), arch, err);
@@ -243,6 +275,7 @@ struct Module {
   hipFunction_t step = nullptr, rollout = nullptr;  // single-config unit
   hipFunction_t group = nullptr;                     // heterogeneous-launch unit
   uint64_t h0 = 0;                                    // config key (group keys are built from their members')
+  int step_waves = 0;                                 // wavefronts per SIMD the step kernel's registers allow (0 = unknown)
 };
 
 struct Key {

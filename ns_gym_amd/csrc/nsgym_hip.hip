@@ -152,6 +152,8 @@ uint64_t spec_source_hash() {
   // library was built with: code objects persist on disk between processes (spec_cache_dir)
   static const char kFixed[] = "-O3 -std=c++17 -ffp-contract=off -Wno-unused-function block " NSG_STR(NSG_BLOCK) " hip " HIP_VERSION_STR;
   h1 = nsg_spec::fnv1a(kFixed, sizeof(kFixed), h1);
+  // and the text spec_source() wraps around the headers (launch bounds, per-env-type defines): bump when it changes
+  h1 = nsg_spec::fnv1a(nsg_spec::kGeneratorRev, strlen(nsg_spec::kGeneratorRev), h1);
   return h1;
 }
 
@@ -272,6 +274,11 @@ int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, cons
     } else {
       HIP_TRY(hipModuleGetFunction(&m.step, m.mod, "nsg_spec_step"));
       HIP_TRY(hipModuleGetFunction(&m.rollout, m.mod, "nsg_spec_rollout"));
+      int regs = 0;   // the launch policy (step_grid_for) needs to know how many workgroups of this kernel a CU holds
+      if (hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, m.step) == hipSuccess && regs > 0) {
+        const int w = 512 / ((regs + 7) & ~7);
+        m.step_waves = w > 8 ? 8 : w;
+      }
     }
     it = cache.emplace(key, m).first;
   }
@@ -283,16 +290,29 @@ int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, cons
 
 extern "C" {
 
-// PCG64 jump-ahead table (nsg_rng.hip.h): entry (d, v) = (M^e, 1 + M + ... + M^(e-1)) mod 2^128 for e = v * 256^d.
+// PCG64 jump-ahead table (nsg_rng.hip.h): the pair (M^e, 1 + M + ... + M^(e-1)) mod 2^128 for the exponents e = 0 .. kJumpLow-1
+// (digit-0 block), then for e = v * 256^d, d = 1 .. 4, v = 0 .. 255.
 void nsg_pcg64_jump_table(uint64_t* out) {
   typedef unsigned __int128 u128;
   const u128 M = ((u128)2549297995355413924ULL << 64) | 4865540595714422341ULL;   // PCG_DEFAULT_MULTIPLIER_128
-  u128 base_a = M, base_g = 1;   // exponent 256^d, starting with d = 0 (exponent 1)
-  for (int d = 0; d < kJumpDigits; d++) {
+  auto put = [&](size_t idx, u128 a, u128 g) {
+    uint64_t* e = out + idx * 4;
+    e[0] = (uint64_t)(a >> 64); e[1] = (uint64_t)a; e[2] = (uint64_t)(g >> 64); e[3] = (uint64_t)g;
+  };
+  u128 base_a = 1, base_g = 0;   // exponent 256^d of the block being written
+  {
     u128 a = 1, g = 0;           // exponent 0
+    for (int v = 0; v < kJumpLow; v++) {
+      put((size_t)v, a, g);
+      if (v == 256) { base_a = a; base_g = g; }
+      g = g * M + 1;             // exponents x then 1:  G_(x+1) = G_x * M + 1
+      a = a * M;
+    }
+  }
+  for (int d = 1; d < kJumpDigits; d++) {
+    u128 a = 1, g = 0;
     for (int v = 0; v < 256; v++) {
-      uint64_t* e = out + ((size_t)d * 256 + v) * 4;
-      e[0] = (uint64_t)(a >> 64); e[1] = (uint64_t)a; e[2] = (uint64_t)(g >> 64); e[3] = (uint64_t)g;
+      put((size_t)kJumpLow + (size_t)(d - 1) * 256 + v, a, g);
       g = g * base_a + base_g;   // exponents x then 256^d:  G_(x+y) = G_x * A_y + G_y
       a = a * base_a;
     }
@@ -443,14 +463,18 @@ static int grid_for(int64_t n) {
   int64_t chunks = (n + kBlock - 1) / kBlock;
   return (int)(chunks < grid_cap() ? chunks : grid_cap());
 }
-// Workgroups of an nsg_step launch.  Batches of up to 2^20 envs (<= 4096 chunks) of the plain-arithmetic theta-engine run best
-// with 6 workgroups per CU (1536), every one resident from the start and walking 2-3 chunks - not with one workgroup per chunk
-// dispatched in two rounds: C1 2^19 envs 16.0 -> 14.1 us, 2^20 25.8 -> 25.0, Pendulum 20.9 -> 19.8, C3 19.5 -> 19.1 (5 and 7
-// per CU and the full engine, which runs at lower occupancy, do not gain: 2^20 C1 25.7 / 27.4, C2 35.5 -> 37.9); from 2^21 envs
-// on the cap of 4096 is best (45.4 vs 47.2 us).  NSG_GRID_CAP overrides.
+// Workgroups of an nsg_step launch.  Batches of up to 2^20 envs (<= 4096 chunks) run best with 6 workgroups per CU (1536),
+// every one resident from the start and walking 2-3 chunks - not with one workgroup per chunk dispatched in two rounds: C1 2^19
+// envs 16.0 -> 14.1 us, 2^20 25.8 -> 25.0, Pendulum 20.9 -> 19.8, C3 19.5 -> 19.1; C2's specialised kernel, once it fitted 6
+// wavefronts per SIMD, 34.8 -> 32.9.  That needs a kernel whose registers ALLOW 6 workgroups per CU: at 5 the sixth waits for
+// a second round and the launch is 8 % slower than with 4096 (C1 at 81 VGPRs: 26.3 us).  So: the plain-arithmetic generic
+// kernels (built at <= 80 VGPRs for the env types this matters for) and any specialised kernel whose register count says so.
+// 1024, 1366, 1792, 2048 are all worse (C1 2^20: 25.5 / 27.8 / 26.1 / 25.0 vs 24.0 us, profiles/r02_ab_runs.txt); from 2^21
+// envs on the cap of 4096 is best (45.4 vs 47.2 us).  NSG_GRID_CAP overrides.
 static int step_grid_for(const nsg_handle* h) {
   const int64_t chunks = (h->n + kBlock - 1) / kBlock;
-  if (!getenv("NSG_GRID_CAP") && h->host.simple_theta && chunks > 1536 && chunks <= 4096) return 1536 * 256 / kBlock;
+  const bool six_fit = h->spec ? (h->spec->step_waves >= 6 || (h->spec->step_waves == 0 && h->host.simple_theta)) : h->host.simple_theta;
+  if (!getenv("NSG_GRID_CAP") && six_fit && chunks > 1536 && chunks <= 4096) return 1536 * 256 / kBlock;
   return grid_for(h->n);
 }
 

@@ -77,3 +77,41 @@ def test_group_unit_compiles_for_gfx950():
     data = C.string_at(code, size.value)
     lib.nsg_spec_free(code)
     assert data[:4] == b"\x7fELF" and b"nsg_spec_group" in data
+
+
+def _notes(data):
+    """{kernel name: {metadata key: int}} from the code object's notes (llvm-readelf)."""
+    import os
+    import re
+    import subprocess
+    import tempfile
+
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not available")
+    with tempfile.NamedTemporaryFile(suffix=".hsaco") as f:
+        f.write(data)
+        f.flush()
+        out = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+    res = {}
+    for blk in out.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        res[name] = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|vgpr_spill_count|private_segment_fixed_size):\s+(\d+)", blk)}
+    return res
+
+
+def test_no_specialised_step_kernel_spills_vector_registers():
+    """CartPole's specialised step is built under a 6-wavefront register bound (80 VGPRs); a config that does not fit is
+    rebuilt without it (nsg_specialize.host.h: spec_compile).  A spilling build is slow and - case 61 of
+    tests/test_gpu_random_configs.py, two update fns with their own streams - was miscompiled by the runtime compiler."""
+    import numpy as np
+
+    from tests.test_gpu_random_configs import _decode, random_spec
+
+    light = _notes(_build(TRAJ_SPECS["c1_cartpole_masspole_inc"]))["nsg_spec_step"]
+    assert light["vgpr_spill_count"] == 0 and light["vgpr_count"] <= 80            # the bound holds where it can
+    for case in (61, 3, 17):
+        spec = random_spec(np.random.default_rng(10_000 + case))
+        spec = {**spec, "wrapper_kwargs": _decode(spec)}
+        for name, k in _notes(_build(spec, track_returns=True)).items():
+            assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (case, name, k)
