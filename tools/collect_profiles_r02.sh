@@ -11,6 +11,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-hbm-resident > $O/pmc_$c.log 2>&1; echo "$c rc=$?"
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc24_$c -o p -- python3 tools/kbench.py --work c1 --n 16777216 --iters 20 --spec > $O/pmc24_$c.log 2>&1; echo "$c 2^24 rc=$?"
 done
+for w in c2 c3 pend; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${w}_$c -o p -- python3 tools/kbench.py --work $w --iters 60 --spec > $O/pmc_${w}_$c.log 2>&1; echo "$w $c rc=$?"
+  done
+done
 for w in c1 acro; do
   timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --kernel-trace --output-format csv -d $O/sq1_$w -o p -- python3 tools/kbench.py --work $w --iters 60 --spec > $O/sq1_$w.log 2>&1; echo "sq1 $w rc=$?"
   timeout -k 10 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq2_$w -o p -- python3 tools/kbench.py --work $w --iters 60 --spec > $O/sq2_$w.log 2>&1; echo "sq2 $w rc=$?"

@@ -2,7 +2,7 @@
 """Fold two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same command) into
 profiles/pmc_traffic.json:  HBM-side bytes per launch of one kernel.
 
-    tools/pmc_summarize.py <fetch_dir> <write_dir> <kernel-name substring> <json key> [n_envs]
+    tools/pmc_summarize.py <fetch_dir> <write_dir> <kernel-name substring> <json key> [n_envs] [algorithmic bytes per env-step]
 
 Corrections per MI355X_MICROARCH.md §HBM and the calibration recorded in the same JSON: unit KiB,
 FETCH_SIZE x2 on gfx950, WRITE_SIZE x1."""
@@ -28,6 +28,7 @@ def avg(d, counter, kern):
 def main():
     fetch_dir, write_dir, kern, key = sys.argv[1:5]
     n = int(sys.argv[5]) if len(sys.argv) > 5 else 1 << 20
+    alg = int(sys.argv[6]) if len(sys.argv) > 6 else 120
     f_kb, nf = avg(fetch_dir, "FETCH_SIZE", kern)
     w_kb, nw = avg(write_dir, "WRITE_SIZE", kern)
     fetch = 2.0 * f_kb * 1024.0
@@ -38,9 +39,10 @@ def main():
     doc[key] = {
         "kernel_match": kern, "dispatches": min(nf, nw), "FETCH_SIZE_KB_avg_raw": f_kb, "WRITE_SIZE_KB_avg": w_kb,
         "fetch_bytes_corrected": fetch, "write_bytes": write, "bytes_per_launch": fetch + write,
-        "bytes_per_env_step": (fetch + write) / n, "algorithmic_bytes_per_env_step": 120, "n_envs": n,
+        "bytes_per_env_step": (fetch + write) / n, "algorithmic_bytes_per_env_step": alg, "ratio": (fetch + write) / n / alg, "n_envs": n,
     }
-    doc["step_kernel_cartpole_bytes_per_launch"] = fetch + write   # what bench.py reports as roofline.traffic
+    if "cartpole_specialised_2p20" in key:
+        doc["step_kernel_cartpole_bytes_per_launch"] = fetch + write   # what bench.py reports as roofline.traffic
     json.dump(doc, open(path, "w"), indent=1)
     print(json.dumps(doc[key], indent=1))
 
