@@ -161,29 +161,47 @@ def main():
     # its actions leaves their pages translated, so the steady state the metric is about is the warm one.  Reported as
     # config.setup_steps.
     SETUP_STEPS = len(pool)
+    if dist is not None:
+        all_gather_returns(env, sizes=[n] * world)  # warm the RCCL communicator
+    env.episode_returns()   # warm-up of the end-of-rollout read-out (its first use loads torch's elementwise kernels: ~50 ms once)
+    e0 = torch.cuda.Event(enable_timing=True)   # HIP events on the stream the kernels are enqueued on
+    e1 = torch.cuda.Event(enable_timing=True)
+    ew = torch.cuda.Event()
+
+    def drain(ev):
+        """torch.cuda.synchronize(), entered only once the stream has reached `ev`: polling the event costs a few us where a
+        blocking wait on an idle-going device costs tens - which a 20-step window (0.5 ms) would carry as 5-10 % of its time."""
+        while not ev.query():
+            pass
+        torch.cuda.synchronize()
+
     for k in range(SETUP_STEPS):
         env.step(pool[k])
     for k in range(args.warmup):
         env.step(pool[k % 8])
-    if dist is not None:
-        all_gather_returns(env, sizes=[n] * world)  # warm the RCCL communicator
-    env.episode_returns()   # warm-up of the end-of-rollout read-out (its first use loads torch's elementwise kernels: ~50 ms once)
-    torch.cuda.synchronize()
+    ew.record()
+    drain(ew)
     barrier()
     torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True)   # HIP events on the stream the kernels are enqueued on
-    e1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
     for k in range(args.steps):
         env.step(pool[k % 8])
     e1.record()
-    gathered = all_gather_returns(env, sizes=[n] * world) if dist is not None else env.episode_returns()[0]
-    torch.cuda.synchronize()
+    drain(e1)
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kern_ms = e0.elapsed_time(e1) / args.steps   # average launch duration incl. back-to-back gap
+
+    # The job's ONE exchange: every rank's episode returns gathered at the END of a rollout (per rollout, not per step - a
+    # rollout is thousands of steps; inside the driver's 20-step window it would be a third of the time at N = 8).  Timed on
+    # its own and reported as config.returns_gather_ms, with barriers on both sides like the steps.
+    tg = time.perf_counter()
+    gathered = all_gather_returns(env, sizes=[n] * world) if dist is not None else env.episode_returns()[0]
+    torch.cuda.synchronize()
+    barrier()
+    gather_ms = (time.perf_counter() - tg) * 1e3
 
     episodes_rank0 = env.counters()["episodes"]
     # secondary figure (not `value`): the same env-steps through nsg_rollout, K = 64 fused steps per launch
@@ -262,10 +280,10 @@ def main():
                 "workload": "CartPole-v1 + masspole IncrementUpdate(+0.1)/ContinuousScheduler (BASELINE C1/C5 config), "
                             f"{n} envs per GPU, random actions, next-step autoreset, episode returns tracked",
                 "envs_per_gpu": n, "total_envs": n * world, "setup_steps": SETUP_STEPS,
-                "parallelism": f"env-sharded x{world}, no per-step collective; 1 all-gather of episode returns at rollout end"
+                "parallelism": f"env-sharded x{world}, no per-step collective; 1 all-gather of episode returns at rollout end (returns_gather_ms, outside the K timed steps)"
                                if world > 1 else "single GPU",
                 "episodes_finished_rank0": episodes_rank0,
-                "gathered_returns": int(gathered.numel()),
+                "gathered_returns": int(gathered.numel()), "returns_gather_ms": gather_ms,
                 "rollout_k64_env_steps_per_sec_per_gpu": rollout_rate,
                 "kernels": "generic (precompiled)" if args.generic else "config-specialised (nsg_specialize, hiprtc)",
                 ("specialised_kernel_avg_launch_us" if args.generic else "generic_kernel_avg_launch_us"): other_us,

@@ -50,6 +50,7 @@ def test_two_ranks_aggregate_line():
     assert KEYS <= set(d) and "cpu_baseline" not in d            # the CPU leg runs on rank 0 of an N = 1 run only
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 2 * 65536 and d["config"]["gathered_returns"] == 2 * 65536
     assert abs(d["value"] - 2 * 65536 * 60 / (d["ms_per_step"] * 60 / 1e3)) / d["value"] < 1e-6   # whole-job aggregate
+    assert d["config"]["returns_gather_ms"] > 0.0       # the end-of-rollout exchange, timed on its own
 
 
 def test_gpus_flag_launches_its_own_ranks():
