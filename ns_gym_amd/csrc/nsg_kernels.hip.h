@@ -92,9 +92,13 @@ __host__ __device__ inline int upd_lds_count(const nsg_config& cfg) {
 }
 constexpr int kLdsHeaderBytes = 32 + kBlock * 8 + kBlock * 4 * 8;
 
-__host__ __device__ inline int lds_bytes_for(int table_bytes, int uses_normal, int uses_exp) {
+__host__ __device__ constexpr int lds_bytes_for(int table_bytes, int uses_normal, int uses_exp) {
   return kLdsHeaderBytes + ((table_bytes + 7) & ~7) + (uses_normal ? 768 * 8 : 0) + (uses_exp ? 768 * 8 : 0);
 }
+
+// the largest launch (full tables, both ziggurats, a fused rollout's env + update-fn streams) must fit the 64 KB of dynamic LDS
+// a kernel gets without opting in to more
+static_assert(kBlock != 256 || lds_bytes_for(kMaxTableBytes, 1, 1) + kLdsStreamBytes * (1 + kMaxLdsUpd) <= 65536, "dynamic LDS budget");
 
 // Cooperative staging of the constant tables into LDS (once per workgroup).
 __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, Tables& tb, ZigLds& zg) {
