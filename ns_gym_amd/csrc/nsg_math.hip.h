@@ -21,6 +21,9 @@
 #ifndef NSG_SINCOS_FMA
 #define NSG_SINCOS_FMA 0
 #endif
+#ifndef NSG_SINCOS_STAGES
+#define NSG_SINCOS_STAGES 3   // pieces of pi/2 the argument reduction subtracts (2 or 3)
+#endif
 
 namespace nsg {
 
@@ -53,6 +56,14 @@ NSG_HD void nsg_sincos(double x, double* sn, double* cs) {
     const double r2 = r1 + c2;
     const double b2 = r2 - r1;
     const double e2 = (r1 - (r2 - b2)) + (c2 - b2);
+#if NSG_SINCOS_STAGES == 2
+    // pi/2 = pio2_1 + pio2_2 + pio2_2t to 119 bits: the reduced argument is off by |x| * 2^-119, i.e. by 2^(c-119) of itself
+    // when c leading bits cancel; no double below 2^20 * pi/2 cancels more than ~62 bits against a multiple of pi/2, so the
+    // third piece (fdlibm's third iteration) could only ever move the result by < 2^-57 of itself - 1/16 ulp.
+    const double tail = e2 - fn * pio2_2t;
+    y0 = r2 + tail;
+    y1 = (r2 - y0) + tail;
+#else
     const double c3 = -(fn * pio2_3);
     const double r3 = r2 + c3;
     const double b3 = r3 - r2;
@@ -60,9 +71,10 @@ NSG_HD void nsg_sincos(double x, double* sn, double* cs) {
     const double tail = (e2 + e3) - fn * pio2_3t;
     y0 = r3 + tail;
     y1 = (r3 - y0) + tail;
+#endif
     n = (int)fn;
   }
-  (void)pio2_1t; (void)pio2_2t;
+  (void)pio2_1t; (void)pio2_2t; (void)pio2_3; (void)pio2_3t;
   // fdlibm __kernel_sin / __kernel_cos on (y0, y1)
   const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
