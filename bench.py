@@ -189,9 +189,9 @@ def main():
         env.step(pool[k % 8])
     e1.record()
     drain(e1)
-    barrier()
+    dt = time.perf_counter() - t0      # this rank's K steps, device drained; the MAX over ranks below is the job's time
+    barrier()                          # closing bracket (its own latency - an RCCL collective - is not part of the steps)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
     kern_ms = e0.elapsed_time(e1) / args.steps   # average launch duration incl. back-to-back gap
 
     # The job's ONE exchange: every rank's episode returns gathered at the END of a rollout (per rollout, not per step - a
