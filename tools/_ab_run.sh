@@ -1,8 +1,9 @@
-rm -f gpurun_out/r02al_ab.log
-for w in acro pend; do
-  python tools/ab.py "lib:spec,lib:spec:-DNSG_SINCOS_STAGES=2" $w 3 1048576 300 >> gpurun_out/r02al_ab.log 2>&1
+NSG_SPEC_FLAGS="-DNSG_BALANCED=1" python -m pytest tests/test_gpu_fullsize.py -x -q 2>&1 | tail -2
+rm -f gpurun_out/r02am_ab.log
+for n in 524288 786432 1048576; do
+  python tools/ab.py "lib:spec,lib:spec:-DNSG_BALANCED=1" c1 3 $n 400 >> gpurun_out/r02am_ab.log 2>&1
 done
-python tools/ab.py "lib:spec,lib:spec:-DNSG_SINCOS_STAGES=2" acro 3 262144 300 >> gpurun_out/r02al_ab.log 2>&1
-python tools/ab.py "lib:spec,lib:spec:-DNSG_SINCOS_STAGES=2" acro 2 1048576 640 64 >> gpurun_out/r02al_ab.log 2>&1
-python tools/ab.py "lib:spec,lib:spec:-DNSG_SINCOS_STAGES=2" pend 2 1048576 640 64 >> gpurun_out/r02al_ab.log 2>&1
-cat gpurun_out/r02al_ab.log
+for w in c2 c3 pend mcar; do
+  python tools/ab.py "lib:spec,lib:spec:-DNSG_BALANCED=1" $w 2 1048576 300 >> gpurun_out/r02am_ab.log 2>&1
+done
+cat gpurun_out/r02am_ab.log
