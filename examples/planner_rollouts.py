@@ -34,7 +34,9 @@ for decision in range(100):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 ret, length = env.episode_returns()
-print(f"{R} roots x 100 decisions: {steps / dt / 1e9:.1f} G simulated env-steps/s; episodes finished so far: "
-      f"{int((length > 0).sum())}, mean length of the last finished episode {length[length > 0].float().mean().item():.0f} "
-      f"(random policy: ~22)")
+done = int((length > 0).sum())
+tail = (f"mean length of the last finished episode {length[length > 0].float().mean().item():.0f}" if done
+        else "every root is still in its first episode after 100 decisions")
+print(f"{R} roots x 100 decisions: {steps / dt / 1e9:.1f} G simulated env-steps/s; episodes finished so far: {done}, {tail} "
+      f"(random policy: ~22 steps per episode)")
 env.close(); sims.close()
