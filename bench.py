@@ -183,6 +183,14 @@ def main():
     drain(ew)
     barrier()
     torch.cuda.synchronize()
+    # At N > 1 the barrier is an RCCL collective that ends in a BLOCKING stream wait: the device sits idle for tens of us before
+    # this process is back, and the next launches would pay for that gap (see drain()).  Two untimed steps and a polled drain
+    # put the device back where the W warm-up steps left it; the ranks leave this point within a few us of each other.
+    REWARM_STEPS = 2
+    for k in range(REWARM_STEPS):
+        env.step(pool[(args.warmup + k) % 8])
+    ew.record()
+    drain(ew)
     t0 = time.perf_counter()
     e0.record()
     for k in range(args.steps):
@@ -279,7 +287,7 @@ def main():
             "config": {
                 "workload": "CartPole-v1 + masspole IncrementUpdate(+0.1)/ContinuousScheduler (BASELINE C1/C5 config), "
                             f"{n} envs per GPU, random actions, next-step autoreset, episode returns tracked",
-                "envs_per_gpu": n, "total_envs": n * world, "setup_steps": SETUP_STEPS,
+                "envs_per_gpu": n, "total_envs": n * world, "setup_steps": SETUP_STEPS, "rewarm_steps": REWARM_STEPS,
                 "parallelism": f"env-sharded x{world}, no per-step collective; 1 all-gather of episode returns at rollout end (returns_gather_ms, outside the K timed steps)"
                                if world > 1 else "single GPU",
                 "episodes_finished_rank0": episodes_rank0,
