@@ -402,6 +402,12 @@ int nsg_time_steps(nsg_handle* h, const void* actions_dev, int32_t iters, void* 
  * with one 8-byte access per lane, the access shape of the step kernels' state rows. */
 int nsg_calib_copy_f64(const double* src_dev, double* dst_dev, int64_t n, void* stream);
 
+/* Latency-bound read-back (the N = 1 adaptors' step outputs): one small launch copies `bytes` (a multiple of 16, at most
+ * 1 MiB) from device memory into PINNED, device-mapped host memory (hipHostMalloc; same address on both sides) and then stores
+ * `seq` into the uint64 that follows the copied bytes (system-scope release).  The host polls that word: no DMA copy, no
+ * event.  `dst_host_mapped` must therefore have room for bytes + 8.  New: the reference reads Python attributes. */
+int nsg_read_back(const void* src_dev, void* dst_host_mapped, int64_t bytes, uint64_t seq, void* stream);
+
 /* Config-specialised kernels.  The generic kernels read nsg_config through scalar loads and branch
  * on it at run time — the device-side equivalent of the reference's per-step Python dispatch over
  * Scheduler / UpdateFn objects (ns_gym/base.py:124-149, classic_control.py:60-100).  nsg_specialize()

@@ -1399,6 +1399,18 @@ __global__ __launch_bounds__(kBlock) void calib_copy_f64_kernel(const double* __
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) dst[i] = src[i] + 1.0;
 }
 
+// Small read-back for latency-bound callers (the N = 1 adaptors): ONE workgroup copies `bytes` (a multiple of 16) from device
+// memory into pinned, device-mapped HOST memory with plain stores and then publishes `seq` in the word that follows them
+// (system-scope release after a workgroup barrier) - the host polls that word instead of paying for a DMA copy + event.
+__global__ __launch_bounds__(kBlock) void read_back_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16, uint64_t seq) {
+  for (int64_t k = threadIdx.x; k < n16; k += kBlock) dst[k] = src[k];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(dst + n16), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 #endif  // NSG_SPEC_BUILD
 
 }  // namespace nsg

@@ -850,6 +850,14 @@ int nsg_calib_copy_f64(const double* src_dev, double* dst_dev, int64_t n, void* 
   return NSG_OK;
 }
 
+int nsg_read_back(const void* src_dev, void* dst_host_mapped, int64_t bytes, uint64_t seq, void* stream) {
+  if (!src_dev || !dst_host_mapped || bytes <= 0 || (bytes & 15) || bytes > (1 << 20) || ((uintptr_t)src_dev & 15) || ((uintptr_t)dst_host_mapped & 15))
+    return fail(NSG_EINVAL, "nsg_read_back: 16-byte aligned pointers and a multiple of 16 bytes (at most 1 MiB) are required");
+  hipLaunchKernelGGL(read_back_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, (const uint4*)src_dev, (uint4*)dst_host_mapped, bytes / 16, seq);
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
 /* ---- config-specialised code objects (nsg_specialize.host.h) ---------------------------------- */
 int nsg_spec_build(const nsg_config* cfg, const char* arch, void** code_out, size_t* size_out) {
   if (!code_out || !size_out) return fail(NSG_EINVAL, "NULL output argument");

@@ -145,10 +145,12 @@ class _NSSingle:
     def _step(self, action):
         v = self._vec
         if self._act is None:
-            self._act = torch.zeros(1, dtype=torch.float32 if v.action_is_float else torch.int32, device=v.device)
-        # the action reaches the device as the scalar argument of a fill kernel (asynchronous), not as a host-to-device copy
-        self._act.fill_(float(np.asarray(action, dtype=np.float64).reshape(-1)[0]) if v.action_is_float else int(action))
-        v.step(self._act)
+            # one pinned host word: the kernel reads the action straight out of it (host memory pinned through HIP is mapped into
+            # the device's address space at the same address) - no fill kernel, no host-to-device copy, one launch per step
+            self._act = torch.zeros(1, dtype=torch.float32 if v.action_is_float else torch.int32).pin_memory()
+            self._act_np = self._act.numpy()
+        self._act_np[0] = float(np.asarray(action, dtype=np.float64).reshape(-1)[0]) if v.action_is_float else int(action)
+        v._step_raw(self._act.data_ptr())
         o, inf = self._scalars()
         if v.may_raise:      # what the reference raises inside step() (LCBounded exhaustion, see VecNSEnv.check_errors)
             v.check_errors()
