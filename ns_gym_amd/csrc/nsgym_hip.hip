@@ -474,7 +474,8 @@ static int grid_for(int64_t n) {
 static int step_grid_for(const nsg_handle* h) {
   const int64_t chunks = (h->n + kBlock - 1) / kBlock;
   const bool six_fit = h->spec ? (h->spec->step_waves >= 6 || (h->spec->step_waves == 0 && h->host.simple_theta)) : h->host.simple_theta;
-  if (!getenv("NSG_GRID_CAP") && six_fit && chunks > 1536 && chunks <= 4096) return 1536 * 256 / kBlock;
+  static const bool cap_overridden = getenv("NSG_GRID_CAP") != nullptr;   // read once: this runs on every launch
+  if (!cap_overridden && six_fit && chunks > 1536 && chunks <= 4096) return 1536 * 256 / kBlock;
   return grid_for(h->n);
 }
 
