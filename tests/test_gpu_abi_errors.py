@@ -62,3 +62,32 @@ def test_live_handle_misuse_is_refused_and_harmless():
     assert torch.equal(env.t, before + 1)
     for e in (env, other, copy, small, pend):
         e.close()
+
+
+def test_read_back_copies_into_pinned_memory_and_publishes_the_sequence_number():
+    """nsg_read_back: device rows -> pinned, device-mapped host memory by one small launch, completion told by the uint64 behind
+    the copied bytes (what VecNSEnv.host_rows polls); misaligned / oversized requests are refused without a launch."""
+    import numpy as np
+    import torch
+
+    from ns_gym_amd import _lib
+
+    lib = _lib.load()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    src = torch.arange(4096, dtype=torch.int32, device="cuda")           # 16 KiB
+    dst = torch.zeros(4096 * 4 + 16, dtype=torch.uint8).pin_memory()
+    flag = dst.numpy()[4096 * 4: 4096 * 4 + 8].view(np.uint64)
+    for seq in (7, 8):
+        src.add_(1)
+        assert lib.nsg_read_back(src.data_ptr(), dst.data_ptr(), 4096 * 4, seq, stream) == 0, lib.nsg_last_error()
+        for _ in range(10_000_000):
+            if int(flag[0]) == seq:
+                break
+        assert int(flag[0]) == seq
+        np.testing.assert_array_equal(dst.numpy()[: 4096 * 4].view(np.int32), src.cpu().numpy())
+    assert lib.nsg_read_back(src.data_ptr(), dst.data_ptr(), 24, 9, stream) == EINVAL            # not a multiple of 16
+    assert lib.nsg_read_back(src.data_ptr() + 4, dst.data_ptr(), 32, 9, stream) == EINVAL        # misaligned source
+    assert lib.nsg_read_back(src.data_ptr(), dst.data_ptr(), (1 << 20) + 16, 9, stream) == EINVAL  # beyond 1 MiB
+    assert lib.nsg_read_back(None, dst.data_ptr(), 32, 9, stream) == EINVAL
+    torch.cuda.synchronize()
+    assert int(flag[0]) == 8                                                                       # nothing was launched
