@@ -102,6 +102,38 @@ def test_every_env_of_the_full_batch_equals_oracle(name, n, T):
     env.close()
 
 
+@pytest.mark.parametrize("n", [49151, 49152, 163840, 163841, 393216, 393217, 393472, 1048575])
+@pytest.mark.parametrize("name", ["c1_cartpole_masspole_inc", "c2_cartpole_gravity_rw"])
+def test_batch_sizes_either_side_of_the_launch_policies(name, n):
+    """The specialised CartPole kernels change shape with the batch size: resets in-lane for 49 152 .. 163 840 envs
+    (nsg_specialize), one workgroup per chunk up to 1536 chunks (393 216 envs), 1536 workgroups walking 2-3 chunks up to 2^20
+    (step_grid_for).  Every env of batches one env either side of each threshold (and of a ragged last chunk) against the
+    oracle for 60 steps - long enough for every env to have finished at least one episode."""
+    import os
+
+    import torch
+
+    from oracle.oracle import OracleVecEnv
+    from tests.util import GpuView
+
+    spec = TRAJ_SPECS[name]
+    env = make_env_from_spec(_vec, spec, n=n, track_returns=True, specialize=True)
+    orc = make_env_from_spec(OracleVecEnv, spec, n=n, track_returns=True)
+    env.reset(seed=31)
+    orc.reset(seed=np.arange(n, dtype=np.uint64) + np.uint64(31))
+    view, oview = GpuView(env), OracleView(orc)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    threads = min(16, os.cpu_count() or 1)
+    for k in range(60):
+        a = torch.randint(0, env.n_actions, (n,), dtype=torch.int32, device="cuda", generator=g)
+        env.step(a)
+        orc.step_mt(a.cpu().numpy(), threads)
+        if k % 20 == 19:
+            compare_views(view._out(), oview._out(), False, f"{name}: all {n} envs, step {k}")
+    assert env.counters()["episodes"] >= n
+    env.close()
+
+
 ACROBOT_MAX_SPLITS = 16      # envs whose episodes END one step apart, of 262 144 envs over 200 steps (seen: 0-5)
 ACROBOT_MAX_DRIFTS = 64      # envs whose float32 observation drifts past the bar inside one long episode (measured: 16)
 ACROBOT_DRIFT_MIN_AGE = 100  # ... and only in an episode at least this many steps old (measured: first at 115)
