@@ -344,8 +344,13 @@ class VecNSEnv:
             st[3] = seq = seq + 1
             with torch.cuda.device(self.device):
                 _lib.check(self.lib.nsg_read_back(self._arena.data_ptr(), buf.data_ptr(), head, seq, self._stream), "nsg_read_back")
+            spins = 0
             while int(flag[0]) != seq:
-                pass
+                spins += 1
+                if spins == 2_000_000:        # ~1 s of polling: let the runtime report a fault instead of spinning for ever
+                    torch.cuda.synchronize(self.device)
+                    if int(flag[0]) != seq:
+                        raise _lib.NsgError("nsg_read_back: the device finished without publishing the rows")
         else:
             buf[:self._arena_head].copy_(self._arena[:self._arena_head], non_blocking=True)
             ev.record(torch.cuda.current_stream(self.device))
