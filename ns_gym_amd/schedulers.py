@@ -53,6 +53,23 @@ class BurstScheduler(Scheduler):
                 "sched_i1": int(self.off_duration), **self._range()}
 
 
+_TABLE_BITS = 8 * 12288     # what one scheduler may take of the kernels' 16-KiB constant tables
+
+
+def _fit_table(n: int, horizon, who: str):
+    """Length of a scheduler's bit table over t = 0 .. n-1 and what the kernels answer beyond it (0: never fires - exact when the
+    table covers every listed time; 2: unknown - counted and raised, like a sampled CustomScheduler).  A table that does not fit
+    the constant-table budget is cut at the largest t the batch can reach (`horizon`: 2 x max_episode_steps, see
+    CustomScheduler); times beyond it cannot be reached anyway, and a t that does get there (a copy of a copy) is reported, not
+    answered silently."""
+    if n <= _TABLE_BITS:
+        return n, 0
+    if horizon and int(horizon) + 1 <= _TABLE_BITS:
+        return int(horizon) + 1, 2
+    raise ValueError(f"{who}: times up to {n - 1} do not fit the kernels' constant tables ({_TABLE_BITS} steps) and this env has "
+                     f"no TimeLimit to bound t; list times below {_TABLE_BITS}")
+
+
 class DiscreteScheduler(Scheduler):
     """Fires at the listed time steps (ns_gym/schedulers.py:56-74)."""
 
@@ -63,13 +80,13 @@ class DiscreteScheduler(Scheduler):
         assert max(event_list) <= end, "Scheduler end time occurs before last event in event list"
 
     def _compile(self, tables, horizon):
-        n = int(max(self.event_list)) + 1
+        n, beyond = _fit_table(int(max(self.event_list)) + 1, horizon, "DiscreteScheduler")
         bits = np.zeros(max(n, 1), dtype=np.uint8)
         for e in self.event_list:
-            if e >= 0 and int(e) == e:
+            if 0 <= e < n and int(e) == e:
                 bits[int(e)] = 1
         off, ln = tables.add_bits(bits)
-        return {"sched_kind": A.SCHED_TABLE, "sched_tab_off": off, "sched_tab_len": ln, "sched_i0": 0,
+        return {"sched_kind": A.SCHED_TABLE, "sched_tab_off": off, "sched_tab_len": ln, "sched_i0": beyond,
                 **self._range()}
 
 
@@ -83,12 +100,13 @@ class WindowScheduler(Scheduler):
     def _compile(self, tables, horizon):
         finite = [w_end for _, w_end in self.windows if np.isfinite(w_end)]
         starts = [w_start for w_start, _ in self.windows]
-        n = int(max(finite + starts + [0])) + 2
+        n, cut = _fit_table(int(max(finite + starts + [0])) + 2, horizon, "WindowScheduler")
         t = np.arange(n)
         bits = np.zeros(n, dtype=np.uint8)
         for w_start, w_end in self.windows:
             bits |= ((w_start <= t) & (t <= w_end)).astype(np.uint8)
-        beyond = int(any(not np.isfinite(w_end) for _, w_end in self.windows))
+        # beyond an uncut table: inside an open-ended window (1) or nothing (0); beyond a cut one: unknown (2)
+        beyond = cut or int(any(not np.isfinite(w_end) for _, w_end in self.windows))
         off, ln = tables.add_bits(bits)
         return {"sched_kind": A.SCHED_TABLE, "sched_tab_off": off, "sched_tab_len": ln, "sched_i0": beyond,
                 **self._range()}

@@ -390,7 +390,7 @@ class VecNSEnv:
                              f"in {n} (env, step) case(s); those distributions were left unchanged")
         if c["scheduler_overruns"] > self._err_seen[1]:
             n, self._err_seen[1] = c["scheduler_overruns"] - self._err_seen[1], c["scheduler_overruns"]
-            raise ValueError(f"a CustomScheduler was asked {n} time(s) about a t beyond the horizon its event function was sampled "
+            raise ValueError(f"a CustomScheduler (or a Discrete / Window schedule cut at the reachable horizon) was asked {n} time(s) about a t beyond the horizon its event function was sampled "
                              f"over (it did not fire there); construct it with horizon=<largest t reached>")
 
     def check_constraints(self) -> int:

@@ -125,6 +125,19 @@ def test_table_schedulers_compile_to_reference_fire_patterns():
                    initial_prob_dist=[1, 0, 0, 0])
     cfg, _, _, _ = mk(BurstScheduler(3, 2, start=1))
     assert (cfg.params[0].sched_kind, cfg.params[0].sched_i0, cfg.params[0].sched_i1) == (A.SCHED_BURST, 3, 2)
+    # a listed time far beyond anything the batch can reach (the reference simply never gets there): the table is cut at the
+    # reachable horizon (2 x TimeLimit) and a t beyond it is "unknown" (2: counted and raised), not a 125-KB table
+    cfg, blob, _, _ = mk(DiscreteScheduler({7, 10 ** 6}))
+    bits, pc = _table_bits(cfg, blob)
+    assert pc.sched_tab_len == 1001 and [t for t, b in enumerate(bits) if b] == [7] and pc.sched_i0 == 2
+    cfg, blob, _, _ = mk(DiscreteScheduler({7, 90000}))            # fits: kept whole, nothing fires beyond it (0)
+    assert cfg.params[0].sched_tab_len == 90001 and cfg.params[0].sched_i0 == 0
+    cfg, blob, _, _ = mk(WindowScheduler([(5, 8), (10 ** 6, 10 ** 6 + 5)]))
+    bits, pc = _table_bits(cfg, blob)
+    assert pc.sched_tab_len == 1001 and [t for t, b in enumerate(bits) if b] == [5, 6, 7, 8] and pc.sched_i0 == 2
+    with pytest.raises(ValueError, match="no TimeLimit"):
+        compile_config(make("CliffWalking-v1", max_episode_steps=None), {"P": DistributionNoUpdate(DiscreteScheduler({3, 10 ** 6}))},
+                       initial_prob_dist=[1, 0, 0, 0])
 
 
 def test_value_list_update_fns_and_unsupported_kinds():
