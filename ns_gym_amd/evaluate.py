@@ -81,13 +81,16 @@ class _LaggedFlag:
 
 
 def run_episodes(env, policy: Optional[Callable] = None, seed: int = 0, max_steps: Optional[int] = None,
-                 record_sarns: bool = False, sample_id=None, actions: Optional[torch.Tensor] = None, chunk: int = 64) -> list:
+                 record_sarns: bool = False, sample_id=None, actions: Optional[torch.Tensor] = None, chunk: int = 64,
+                 as_arrays: bool = False):
     """One episode per env of `env` (a VecNSEnv).
 
     `actions`: open-loop action table `[T, N]` (device tensor; step k of every env takes `actions[k]`), or
     `policy`: `policy(state_tensor) -> action tensor [N]` (closed loop), or neither: uniform random actions.
     Returns rows `[total_reward, SARNS, num_steps, seed, sample_id, time]` (run_experiment.py:133-141); SARNS is a list of
-    (state, action, reward, next_state) tuples per env when `record_sarns`, else []."""
+    (state, action, reward, next_state) tuples per env when `record_sarns`, else [].
+    `as_arrays=True`: the same columns as NumPy arrays in a dict (`total_reward`, `num_steps`, `seed`, `sample_id`, `time`) -
+    building a million Python rows costs ~1 s of host time where the episodes themselves cost milliseconds of device time."""
     n, dev = env.num_envs, env.device
     limit = max_steps if max_steps is not None else (env.cfg.max_episode_steps or 10_000)
     total_steps = limit + 1                      # the reference breaks at num_steps == max_steps + 1 (run_experiment.py:127-129)
@@ -156,6 +159,10 @@ def run_episodes(env, policy: Optional[Callable] = None, seed: int = 0, max_step
         env.check_errors()
     seeds = (np.arange(n) + int(seed)) if np.isscalar(seed) else np.asarray(seed)
     ids = list(range(n)) if sample_id is None else list(sample_id)
+    if as_arrays:
+        assert not record_sarns, "SARNS tuples are per-step Python objects: use the row format for them"
+        return {"total_reward": total.astype(np.float64), "num_steps": steps.astype(np.int64), "seed": np.asarray(seeds),
+                "sample_id": np.asarray(ids), "time": wall}
     rows = []
     for i in range(n):
         sarns = []

@@ -85,6 +85,13 @@ def test_default_random_policy_is_fused_and_ends_early():
     assert steps.max() < 200 and steps.min() >= 5
     launched = env.counters()["env_steps"] + env.counters()["episodes"]
     assert launched <= 4096 * (steps.max() + 3 * 32)                  # at most ~2 chunks past the last episode's end
+    # the same columns as arrays (no Python row per env): an open-loop table makes the two runs identical
+    import torch
+    table = torch.randint(0, 2, (300, 4096), dtype=torch.int32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    rows = run_episodes(env, seed=7, actions=table, sample_id=range(100, 100 + 4096))
+    cols = run_episodes(env, seed=7, actions=table, sample_id=range(100, 100 + 4096), as_arrays=True)
+    assert cols["total_reward"].tolist() == [r[0] for r in rows] and cols["num_steps"].tolist() == [r[2] for r in rows]
+    assert cols["seed"].tolist() == [r[3] for r in rows] and cols["sample_id"].tolist() == [r[4] for r in rows]
     env.close()
 
 
