@@ -197,6 +197,11 @@ inline std::vector<char> spec_compile(const nsg_config& cfg, bool full, const ch
   std::vector<char> code = compile_source(spec_source(cfg, full, resets_in_lane, true), arch, err);
   if (!code.empty() && vgpr_spill_count(code, "nsg_spec_step") != 0)
     code = compile_source(spec_source(cfg, full, resets_in_lane, false), arch, err);
+  if (!code.empty() && vgpr_spill_count(code, "nsg_spec_step") > 0) {   // only reachable through NSG_SPEC_FLAGS (a forced register bound)
+    err = "the specialised step kernel spills vector registers under the given NSG_SPEC_FLAGS; such builds are not used "
+          "(see spec_compile)";
+    code.clear();
+  }
   return code;
 }
 inline std::vector<char> group_compile(const nsg_config* const* cfgs, const bool* full, int n, const char* arch, std::string& err) {
