@@ -328,6 +328,8 @@ def main():
                 # for context: the shape the reference's path has today - one Python wrapper object per env, one step()
                 # call per env per step, dict observations (oracle/python_loop.py), 1 core
                 "python_object_loop": _python_object_loop(),
+                # the same loop in one worker PROCESS per host core of this GPU's share, rates summed
+                "python_object_loop_all_cores": _python_object_loop_all_cores(threads),
             }
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -350,6 +352,24 @@ def _python_object_loop():
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "env-steps/s", "cores": 1,
             "sample": f"64 wrapper objects x 600 steps of the same config in {dt:.1f} s"}
+
+
+def _python_object_loop_all_cores(workers):
+    """`workers` child processes (plain children of this one, started after the GPU work is done), each running the object
+    loop on its own 64 wrapper objects; the sum of their rates."""
+    import subprocess
+
+    env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.python_loop", "600"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, text=True) for _ in range(workers)]
+    rates = []
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        if p.returncode == 0:
+            rates.append(float(out.strip().splitlines()[-1]))
+    return {"value": sum(rates), "unit": "env-steps/s", "cores": len(rates),
+            "sample": f"{len(rates)} processes x 64 wrapper objects x 600 steps, {time.perf_counter() - t0:.1f} s wall incl. interpreter start-up"}
 
 
 def _pmc_traffic(n_envs):

@@ -180,3 +180,21 @@ def run_loop(envs, actions, steps):
                 done[i] = term or trunc
             total += 1
     return total
+
+
+if __name__ == "__main__":   # one worker of bench.py's all-cores leg: prints its own env-steps per second
+    import sys
+    import time
+
+    import numpy as np
+
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+    envs = [make_c1() for _ in range(64)]
+    for i, e in enumerate(envs):
+        e.reset(seed=i)
+    acts = np.random.default_rng(123).integers(2, size=(8, 64))
+    run_loop(envs, acts, 20)
+    t0 = time.perf_counter()
+    n = run_loop(envs, acts, steps)
+    print(n / (time.perf_counter() - t0))
+
