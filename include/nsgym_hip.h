@@ -126,10 +126,10 @@ enum {
 
 /* device-side counters: uint64 running totals, one shard per wavefront slot of a launch.
  * buffers.counters is [NSG_CNT_COUNT][NSG_CNT_SHARDS]; a total is the sum over its shards.
- * Produced by wavefront ballots + popcounts; every wavefront adds its counts to ITS OWN shard
- * (workgroup index within the handle's launch range x 4 + wavefront index) with one
- * fire-and-forget add: no contention, no workgroup barrier, no wait.  Launch grids are capped at
- * NSG_CNT_SHARDS / 4 workgroups so that a shard has exactly one owner per launch. */
+ * Produced by wavefront ballots + popcounts; every wavefront adds its counts to the shard
+ * (workgroup index within the handle's launch range x 4 + wavefront index) mod NSG_CNT_SHARDS with one
+ * fire-and-forget atomic add: no workgroup barrier, no wait.  Up to NSG_CNT_SHARDS / 4 workgroups a shard
+ * has exactly one owner per launch; the wider launches of very large batches share a shard between four. */
 enum {
   NSG_CNT_DONE = 0,       /* episodes finished (terminated or truncated)                */
   NSG_CNT_FIRED = 1,      /* (env,param) updates applied (notification flags raised)    */

@@ -157,15 +157,15 @@ struct WaveCounts {
   unsigned done = 0, fired = 0, viol = 0, steps = 0, lc_exhausted = 0, sched_overrun = 0;
 };
 
-// `block_rel` = workgroup index within the handle's launch range (< NSG_CNT_SHARDS / 4).
+// `block_rel` = workgroup index within the handle's launch range (beyond NSG_CNT_SHARDS / 4 workgroups the shards are shared).
 __device__ __forceinline__ void flush_counts(uint64_t* counters, int block_rel, const WaveCounts& wc) {
   const int lane = threadIdx.x & 63;
   if (counters && lane < NSG_CNT_COUNT) {
     const unsigned v = lane == NSG_CNT_DONE ? wc.done : lane == NSG_CNT_FIRED ? wc.fired : lane == NSG_CNT_VIOLATION ? wc.viol
                      : lane == NSG_CNT_STEPS ? wc.steps : lane == NSG_CNT_LC_EXHAUSTED ? wc.lc_exhausted : wc.sched_overrun;
     // fire-and-forget add (no return value requested): the wavefront retires without waiting for a
-    // read-modify-write round trip; the shard has a single owner per launch, so there is no contention
-    if (v) atomicAdd((unsigned long long*)&counters[(int64_t)lane * kCntShards + block_rel * (kBlock / 64) + (threadIdx.x >> 6)],
+    // read-modify-write round trip; up to 4096 workgroups the shard has a single owner per launch, so there is no contention
+    if (v) atomicAdd((unsigned long long*)&counters[(int64_t)lane * kCntShards + ((block_rel * (kBlock / 64) + (threadIdx.x >> 6)) & (kCntShards - 1))],
                      (unsigned long long)v);
   }
 }

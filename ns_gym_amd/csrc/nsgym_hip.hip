@@ -455,7 +455,7 @@ static int grid_cap() {  // tuning knob (tools/kbench.py sweeps it); default fro
   if (!cap) {
     const char* e = getenv("NSG_GRID_CAP");
     cap = e ? atoi(e) : 4096 * 256 / kBlock;   // 2^20 envs per launch round, whatever the workgroup size
-    if (cap < 1 || cap > NSG_CNT_SHARDS / (kBlock / 64)) cap = NSG_CNT_SHARDS / (kBlock / 64);  // one counter shard per wavefront slot
+    if (cap < 1 || cap > 65536) cap = NSG_CNT_SHARDS / (kBlock / 64);  // beyond 4096 workgroups the counter shards are shared (atomic adds)
   }
   return cap;
 }
@@ -470,13 +470,32 @@ static int grid_for(int64_t n) {
 // a second round and the launch is 8 % slower than with 4096 (C1 at 81 VGPRs: 26.3 us).  So: the plain-arithmetic generic
 // kernels (built at <= 80 VGPRs for the env types this matters for) and any specialised kernel whose register count says so.
 // 1024, 1366, 1792, 2048 are all worse (C1 2^20: 25.5 / 27.8 / 26.1 / 25.0 vs 24.0 us, profiles/r02_ab_runs.txt); from 2^21
-// envs on the cap of 4096 is best (45.4 vs 47.2 us).  NSG_GRID_CAP overrides.
+// envs on 4096 and more (next paragraph).  NSG_GRID_CAP overrides everything.
+//
+// Beyond 2^20 envs (more than 4096 chunks) a launch of a kernel that stages nothing into LDS and is bound by memory runs best
+// with up to 16384 workgroups - one chunk each at 2^22 envs, 2 / 4 at 2^23 / 2^24 - rather than 4096 walking 4-16 chunks
+// (specialised C1: 2^22 84.9 -> 80.8 us, 2^23 183 -> 174.5, 2^24 414.9 -> 390.6; MountainCar 55.7 -> 54.5, C3 84.1 -> 83.3,
+// fused rollouts 46.0 -> 44.0 per step; 65536 is no better).  Not for the full theta-engine, whose every workgroup first stages
+// the ziggurat tables (C2 2^22: 138 -> 150 us), nor for Acrobot, bound by its arithmetic (206.8 -> 209.6).  The counter shards
+// (NSG_CNT_SHARDS = 16384, one per wavefront of a 4096-workgroup launch) are then shared by four wavefronts each: plain atomic adds.
+static bool wide_grid_ok(const nsg_handle* h) {
+  return h->host.simple_theta && !h->host.uses_normal && !h->host.uses_exp && h->host.cfg.env_type != NSG_ENV_ACROBOT;
+}
+static int launch_grid_for(const nsg_handle* h) {   // nsg_step beyond the 1536 policy, nsg_rollout
+  static const bool cap_overridden = getenv("NSG_GRID_CAP") != nullptr;   // read once: this runs on every launch
+  const int64_t chunks = (h->n + kBlock - 1) / kBlock;
+  if (!cap_overridden && chunks > 4096 * 256 / kBlock && wide_grid_ok(h)) {
+    const int64_t wide = 16384 * 256 / kBlock;
+    return (int)(chunks < wide ? chunks : wide);
+  }
+  return grid_for(h->n);
+}
 static int step_grid_for(const nsg_handle* h) {
   const int64_t chunks = (h->n + kBlock - 1) / kBlock;
   const bool six_fit = h->spec ? (h->spec->step_waves >= 6 || (h->spec->step_waves == 0 && h->host.simple_theta)) : h->host.simple_theta;
-  static const bool cap_overridden = getenv("NSG_GRID_CAP") != nullptr;   // read once: this runs on every launch
+  static const bool cap_overridden = getenv("NSG_GRID_CAP") != nullptr;
   if (!cap_overridden && six_fit && chunks > 1536 && chunks <= 4096) return 1536 * 256 / kBlock;
-  return grid_for(h->n);
+  return launch_grid_for(h);
 }
 
 int nsg_bind(nsg_handle* h, const nsg_buffers* bufs) {
@@ -597,13 +616,13 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
                              (is_grid_env(h->host.cfg.env_type) ? 0 : kLdsStreamBytes * (1 + upd_lds_count(h->host.cfg)));
   if (h->spec) {
     void* args[] = {(void*)&h->dev, (void*)&actions_dev, (void*)&k_steps, (void*)&o};
-    HIP_TRY(hipModuleLaunchKernel(h->spec->rollout, grid_for(h->n), 1, 1, kBlock, 1, 1, (unsigned)rollout_lds, s, args, nullptr));
+    HIP_TRY(hipModuleLaunchKernel(h->spec->rollout, launch_grid_for(h), 1, 1, kBlock, 1, 1, (unsigned)rollout_lds, s, args, nullptr));
   } else if (h->host.simple_theta) {
     DISPATCH_ENV(h->host.cfg.env_type,
-                 hipLaunchKernelGGL((rollout_kernel<E, false>), dim3(grid_for(h->n)), dim3(kBlock), rollout_lds, s, h->dev, actions_dev, k_steps, o));
+                 hipLaunchKernelGGL((rollout_kernel<E, false>), dim3(launch_grid_for(h)), dim3(kBlock), rollout_lds, s, h->dev, actions_dev, k_steps, o));
   } else {
     DISPATCH_ENV(h->host.cfg.env_type,
-                 hipLaunchKernelGGL((rollout_kernel<E, true>), dim3(grid_for(h->n)), dim3(kBlock), rollout_lds, s, h->dev, actions_dev, k_steps, o));
+                 hipLaunchKernelGGL((rollout_kernel<E, true>), dim3(launch_grid_for(h)), dim3(kBlock), rollout_lds, s, h->dev, actions_dev, k_steps, o));
   }
   HIP_TRY(hipGetLastError());
   // the last step landed in the handle's own output rows: mirror them into the last trajectory slice
