@@ -102,12 +102,12 @@ def test_every_env_of_the_full_batch_equals_oracle(name, n, T):
     env.close()
 
 
-@pytest.mark.parametrize("n", [49151, 49152, 163840, 163841, 393216, 393217, 393472, 1048575])
+@pytest.mark.parametrize("n", [49151, 49152, 163840, 163841, 393216, 393217, 393472, 1048575, 1048577, 1310720])
 @pytest.mark.parametrize("name", ["c1_cartpole_masspole_inc", "c2_cartpole_gravity_rw"])
 def test_batch_sizes_either_side_of_the_launch_policies(name, n):
     """The specialised CartPole kernels change shape with the batch size: resets in-lane for 49 152 .. 163 840 envs
     (nsg_specialize), one workgroup per chunk up to 1536 chunks (393 216 envs), 1536 workgroups walking 2-3 chunks up to 2^20
-    (step_grid_for).  Every env of batches one env either side of each threshold (and of a ragged last chunk) against the
+    (step_grid_for), one workgroup per chunk again beyond 2^20 envs (launch_grid_for).  Every env of batches one env either side of each threshold (and of a ragged last chunk) against the
     oracle for 60 steps - long enough for every env to have finished at least one episode."""
     import os
 
