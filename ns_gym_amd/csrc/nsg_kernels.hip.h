@@ -25,7 +25,8 @@ namespace nsg {
 // Workgroup size: NSG_BLOCK lanes = NSG_BLOCK / 256 consecutive 256-env layout chunks (the chunk-blocked rows are laid out in
 // 256-env chunks whatever the workgroup size, nsg_rng.hip.h blk_off8).  Measured with the counter-based env streams (C1,
 // specialised, 2^20 / 2^22 / 2^24 envs): 256 lanes 26.0 / 87.3 / 460 us, 512 lanes 25.8 / 87.2 / 447, 1024 lanes 26.4 / 87.4 / 447;
-// Acrobot and the full theta-engine lose with the larger ones (63 -> 65 -> 81 us, 34.4 -> 35.3 -> 40.4): 256 stays.
+// Acrobot and the full theta-engine lose with the larger ones (63 -> 65 -> 81 us, 34.4 -> 35.3 -> 40.4); 128 lanes (measured again on
+// round 2's final code): C1 23.9 -> 24.6 us at 2^20 envs, 80.8 -> 81.6 at 2^22, C2 32.9 -> 36.2, Pendulum 20.2 -> 20.9.  256 stays.
 #ifndef NSG_BLOCK
 #define NSG_BLOCK 256
 #endif
