@@ -66,11 +66,11 @@ struct ActionPtrs {
 };
 // Dynamic LDS layout (sized per handle at launch: a batch with tiny tables must not pay 22 KB of
 // LDS per workgroup, which would cap residency at 6-7 workgroups per CU):
-//   [ pad | reset_n[2] | pad | reset_q[kBlock] (u64) | reset_state[kBlock][4] (f64) |
+//   [ pad | reset_n[2] | pad | reset_list[kBlock] (short) | reset_state[kBlock][4] (f64) |
 //     table blob | ziggurat ki/wi/fi | streams[kBlock][4] (u64; fused rollouts of classic envs only) ]
 struct LdsTables {
   int* reset_n;         // [2] workgroup-level compaction of the autoreset lanes (double-buffered)
-  uint64_t* reset_q;    // [kBlock] queue of the chunk's resetting envs: (episode count << 16) | owner lane
+  short* reset_list;    // [kBlock] lanes whose env resets in this chunk (the owner leaves its episode count in its reset_state slot)
   double* reset_state;  // [kBlock][4] initial states drawn by the helper lanes, read back by the owners
   uint64_t* blob;       // constant-table blob
   uint64_t* zig;        // 768 words (normal) + 768 words (exponential), each only when needed
@@ -91,7 +91,9 @@ __host__ __device__ inline int upd_lds_count(const nsg_config& cfg) {
   const int n = upd_lds_index(cfg, cfg.n_params);
   return n < kMaxLdsUpd ? n : kMaxLdsUpd;
 }
-constexpr int kLdsHeaderBytes = 32 + kBlock * 8 + kBlock * 4 * 8;
+// (1.5 KB more here - a 64-bit queue entry instead of a lane index - once cost C2's fused rollout its fifth workgroup per CU:
+// 31.4 -> 32.9 KB of LDS each, 17.1 -> 18.8 us per step)
+constexpr int kLdsHeaderBytes = 32 + kBlock * 2 + kBlock * 4 * 8;
 
 __host__ __device__ constexpr int lds_bytes_for(int table_bytes, int uses_normal, int uses_exp) {
   return kLdsHeaderBytes + ((table_bytes + 7) & ~7) + (uses_normal ? 768 * 8 : 0) + (uses_exp ? 768 * 8 : 0);
@@ -101,13 +103,17 @@ __host__ __device__ constexpr int lds_bytes_for(int table_bytes, int uses_normal
 // a kernel gets without opting in to more
 static_assert(kBlock != 256 || lds_bytes_for(kMaxTableBytes, 1, 1) + kLdsStreamBytes * (1 + kMaxLdsUpd) <= 65536, "dynamic LDS budget");
 
+// ... and a fused rollout of the C2 shape (normal ziggurat, env streams + one update-fn stream in LDS) must keep FIVE workgroups per
+// CU (160 KB of LDS; its 94 VGPRs allow five): at 32.9 KB each it was four, and 11 % slower
+static_assert(kBlock != 256 || lds_bytes_for(256, 1, 0) + kLdsStreamBytes * 2 <= 160 * 1024 / 5, "LDS per workgroup of the C2-shaped rollout");
+
 // Cooperative staging of the constant tables into LDS (once per workgroup).
 __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, Tables& tb, ZigLds& zg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char nsg_dyn_lds[];
   unsigned char* base = nsg_dyn_lds;
   lds.reset_n = (int*)(base + 16);
-  lds.reset_q = (uint64_t*)(base + 32);
-  lds.reset_state = (double*)(base + 32 + kBlock * 8);
+  lds.reset_list = (short*)(base + 32);
+  lds.reset_state = (double*)(base + 32 + kBlock * 2);
   lds.blob = (uint64_t*)(base + kLdsHeaderBytes);
   lds.zig = (uint64_t*)(base + kLdsHeaderBytes + ((sg.table_bytes + 7) & ~7));
   lds.streams = (uint64_t*)(base + lds_bytes_for(sg.table_bytes, sg.uses_normal, sg.uses_exp));  // valid when the launch reserved it (fused rollouts)
@@ -531,16 +537,21 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   } else
   {
     constexpr int D = T::RESET_DRAWS;
-    static_assert(kBlock <= 65536 && (64 % D) == 0, "queue entry packing / helper-lane grouping");
+    static_assert((64 % D) == 0, "the D helper lanes of one reset must sit in one wavefront (see the count read below)");
     int* rn = lds.reset_n + (parity & 1);
-    if (do_reset) lds.reset_q[atomicAdd(rn, 1)] = ((uint64_t)(st >> NSG_EP_COUNT_SHIFT) << 16) | (uint64_t)tid;
+    // the owner queues its lane and leaves its episode count in the first word of its own result slot
+    uint64_t* slot = reinterpret_cast<uint64_t*>(lds.reset_state);
+    if (do_reset) {
+      lds.reset_list[atomicAdd(rn, 1)] = (short)tid;
+      slot[tid * 4] = (uint64_t)(st >> NSG_EP_COUNT_SHIFT);
+    }
     __syncthreads();
     const int n_reset = *rn;
     if (tid == 0) lds.reset_n[(parity + 1) & 1] = 0;  // the other buffer is idle until the next chunk
     if (io.lds_rng) {
       // fused rollout: the owner's stream sits in LDS, positioned at its next episode - D sequential draws by one helper lane
       if (tid < n_reset) {
-        const int owner = (int)(lds.reset_q[tid] & 0xffffu);
+        const int owner = lds.reset_list[tid];
         uint64_t* rec = lds.streams + owner * 4;
         Pcg g = {rec[0], rec[1], rec[2], rec[3]};
         double r0[T::PHYS];
@@ -555,20 +566,22 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
       // output.  No sequential PCG64 steps at all; a typical chunk's ~13 resets fill one wavefront.
 #if NSG_RESET_LANE_PER_DRAW
       for (int h = tid; h < n_reset * D; h += kBlock) {
-        const uint64_t qe = lds.reset_q[h / D];
-        const int owner = (int)(qe & 0xffffu), j = h % D;
+        const int owner = lds.reset_list[h / D], j = h % D;
+        // the count shares its word with result 0: the D lanes of a reset are neighbours in ONE wavefront (64 % D == 0), all of
+        // them execute this read before any of them reaches the store below
+        const uint64_t count = slot[owner * 4];
         Pcg g;
         const u64x2 desc = {zg.sd0, zg.sd1};
-        env_stream_at<2>(b.rng_env, base + owner, (qe >> 16) * (uint64_t)D + (uint64_t)j, zg.jump, g, &desc);
+        env_stream_at<2>(b.rng_env, base + owner, count * (uint64_t)D + (uint64_t)j, zg.jump, g, &desc);
         lds.reset_state[owner * 4 + j] = env_reset_map<ENV>(j, pcg_double_out(g));
       }
 #else   // one helper lane per reset: one jump, then D - 1 sequential PCG64 steps
       if (tid < n_reset) {
-        const uint64_t qe = lds.reset_q[tid];
-        const int owner = (int)(qe & 0xffffu);
+        const int owner = lds.reset_list[tid];
+        const uint64_t count = slot[owner * 4];
         Pcg g;
         const u64x2 desc = {zg.sd0, zg.sd1};
-        env_stream_at<2>(b.rng_env, base + owner, (qe >> 16) * (uint64_t)D, zg.jump, g, &desc);
+        env_stream_at<2>(b.rng_env, base + owner, count * (uint64_t)D, zg.jump, g, &desc);
         double r0[T::PHYS];
         env_reset_draw<ENV, true>(g, r0);
 #pragma unroll
