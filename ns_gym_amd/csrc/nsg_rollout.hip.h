@@ -105,8 +105,12 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
   flush_counts(b.counters, (int)blockIdx.x, wc);
 }
 
+// The plain-arithmetic CartPole rollout sits at the 80-VGPR boundary (80 in round 1, 82 after round 2's hand-over changes: five
+// wavefronts per SIMD instead of six, +4 % per step); the bound keeps it at six without spilling.
+template <int ENV, bool FULL> constexpr int kRolloutMinWaves = (ENV == NSG_ENV_CARTPOLE && !FULL) ? 6 : 1;
+
 template <int ENV, bool FULL>
-__global__ __launch_bounds__(kBlock) void rollout_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions,
+__global__ __launch_bounds__(kBlock, (kRolloutMinWaves<ENV, FULL>)) void rollout_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions,
                                                          int k_steps, nsg_rollout_out ro) {
   rollout_body<ENV, FULL>(seg->cfg, *seg, actions, k_steps, ro);
 }
