@@ -352,9 +352,20 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
                 void* stream);
 
 /* Heterogeneous batch: one launch over up to NSG_MAX_SEGMENTS handles of different env
- * types (per-env-type dispatch is wave-uniform because segments are block-aligned). */
+ * types (per-env-type dispatch is wave-uniform because segments are block-aligned).
+ * The first launch of a member list PLANS it (block ranges, a device-side segment table, the group's specialised unit when
+ * every member is specialised): that synchronises the device once.  The plan is kept per member list and stays valid until
+ * one of ITS members is re-bound, specialised or destroyed; other handles coming and going do not touch it.  A segment table
+ * is never overwritten while anything - a launch in flight, a captured HIP graph - may read it.  On a capturing stream a
+ * launch that would have to plan first is refused (NSG_EINVAL): launch the group once before the capture. */
 int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* actions_dev,
                    void* stream);
+/* Which kernel the current plan of this member list launches (>= 0), or a negative error code. */
+#define NSG_GROUP_UNPLANNED 0        /* not launched yet, or a member changed since */
+#define NSG_GROUP_GENERIC_SIMPLE 1   /* precompiled kernel, plain-arithmetic theta engine */
+#define NSG_GROUP_GENERIC_FULL 2     /* precompiled kernel, full theta engine */
+#define NSG_GROUP_SPECIALISED 3      /* the unit compiled for the ordered tuple of the members' configs (nsg_spec_group) */
+int nsg_step_group_kind(nsg_handle* const* hs, int32_t n_handles);
 
 /* θ-schedule engine alone (Scheduler.__call__ + UpdateFn.__call__, base.py:67-81,124-149)
  * on param slot `p` of the handle's config: n lanes, each starting from theta0[i] (3 doubles

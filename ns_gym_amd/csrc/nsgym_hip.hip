@@ -28,9 +28,7 @@ using namespace nsg;
 namespace {
 
 thread_local char g_err[512] = "";
-// Bumped whenever a handle's launch-relevant state changes (nsg_bind, nsg_specialize, nsg_destroy) - by any thread: what
-// nsg_step_group remembers about a member list (block ranges, the group's specialised unit) is valid for one generation.
-std::atomic<unsigned long long> g_generation{0};
+std::atomic<uint64_t> g_next_handle_id{1};
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -135,6 +133,11 @@ struct nsg_handle {
   int device;
   const nsg_spec::Module* spec;  // config-specialised step / rollout kernels (nsg_specialize), or NULL
   unsigned launches = 0;
+  // What nsg_step_group remembers about a member list is keyed on these two: `id` is unique per nsg_create for the life of the
+  // process (a new handle at a recycled address is a different member), `generation` counts the launch-relevant changes of
+  // THIS handle (nsg_bind, nsg_specialize) - other handles coming and going (planning copies) leave a group's plan alone.
+  uint64_t id = 0;
+  uint64_t generation = 0;
 };
 
 namespace {
@@ -397,6 +400,7 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
   if (!h) return fail(NSG_ENOMEM, "out of host memory");
   memset(h, 0, sizeof(*h));
   h->n = n;
+  h->id = g_next_handle_id++;
   // any failure below releases what was allocated so far (nsg_destroy frees the three device blocks and the handle)
 #define HIP_TRY_H(expr)                                                          \
   do {                                                                           \
@@ -413,13 +417,15 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
   if (table_bytes) HIP_TRY_H(hipMemcpy(h->d_tables, tables, table_bytes, hipMemcpyHostToDevice));
   static uint64_t zig[1536 + kJumpWords];   // ziggurat tables | PCG64 jump-ahead table (one device block)
   static std::once_flag jump_once;
-  std::call_once(jump_once, [] { nsg_pcg64_jump_table(zig + 1536); });
-  memcpy(zig, NSG_ZIG_KI, 2048);
-  memcpy(zig + 256, NSG_ZIG_WI_BITS, 2048);
-  memcpy(zig + 512, NSG_ZIG_FI_BITS, 2048);
-  memcpy(zig + 768, NSG_ZIGE_KE, 2048);
-  memcpy(zig + 1024, NSG_ZIGE_WE_BITS, 2048);
-  memcpy(zig + 1280, NSG_ZIGE_FE_BITS, 2048);
+  std::call_once(jump_once, [] {   // filled once: handles may be created from several threads
+    memcpy(zig, NSG_ZIG_KI, 2048);
+    memcpy(zig + 256, NSG_ZIG_WI_BITS, 2048);
+    memcpy(zig + 512, NSG_ZIG_FI_BITS, 2048);
+    memcpy(zig + 768, NSG_ZIGE_KE, 2048);
+    memcpy(zig + 1024, NSG_ZIGE_WE_BITS, 2048);
+    memcpy(zig + 1280, NSG_ZIGE_FE_BITS, 2048);
+    nsg_pcg64_jump_table(zig + 1536);
+  });
   HIP_TRY_H(hipMalloc((void**)&h->d_zig, sizeof(zig)));
   HIP_TRY_H(hipMemcpy(h->d_zig, zig, sizeof(zig), hipMemcpyHostToDevice));
   HIP_TRY_H(hipMalloc((void**)&h->dev, sizeof(Segment)));
@@ -510,7 +516,7 @@ int nsg_bind(nsg_handle* h, const nsg_buffers* bufs) {
   NEED(ep_return); NEED(ep_length); NEED(last_return); NEED(last_length);
 #undef NEED
   h->host.buf = *bufs;
-  g_generation++;
+  h->generation++;
   HIP_TRY(hipMemcpy(h->dev, &h->host, sizeof(Segment), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(init_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, 0, h->dev);
   HIP_TRY(hipGetLastError());
@@ -642,115 +648,200 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
   return NSG_OK;
 }
 
-int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* actions_dev, void* stream) {
-  if (!hs || !actions_dev || n_handles <= 0 || n_handles > NSG_MAX_SEGMENTS) return fail(NSG_EINVAL, "bad group arguments");
-  // The launch reads a segment table: copies of its members' segments with their block ranges, passed as a `const
-  // __restrict__` kernel argument (scalar loads, see step_group_kernel).  A table is written ONCE, when the plan for a member
-  // list is made (each of the calling thread's few plans owns its table; a plan slot is re-planned only after a device
-  // synchronisation), so alternating member lists never overwrite a table that a launch in flight may still read; and a plan is valid for one generation of the library's handles (bumped by nsg_bind,
-  // nsg_specialize and nsg_destroy on any thread), so a table never outlives the segments it was copied from.
-  struct Plan {
-    nsg_handle* members[NSG_MAX_SEGMENTS];
-    int n_members = 0;
-    unsigned long long built_at = ~0ULL;
-    Segment* d_table = nullptr;
-    int total_blocks = 0, all_simple = 0, group_lds = 0, device = -1;
-    const nsg_spec::Module* group_spec = nullptr;
+// ---- heterogeneous launches: plans ---------------------------------------------------------------------------------------
+// A launch of nsg_step_group reads a segment table: copies of its members' segments with their block ranges, passed as a
+// `const __restrict__` kernel argument (scalar loads, see step_group_kernel).  What is remembered about a member list is a PLAN:
+// the table, the launch shape and - when every member is specialised - the group's own unit.  Plans are process-wide (a mutex
+// guards the list; the launch itself is enqueued outside it), keyed on the members' ids and valid for the members' own
+// generations, so planning copies created or destroyed elsewhere in the process never invalidate a group they are not part of.
+// A table is written ONCE, before the first launch that reads it, and never overwritten: a re-plan (a member re-bound or
+// specialised since) allocates a new table and RETIRES the old one, which stays allocated - a launch in flight or a captured
+// HIP graph may still read it - until the retired list is drained behind a device synchronisation.  Plans whose member was
+// destroyed are dropped by nsg_destroy.  While the stream is capturing, a launch that would have to plan first is refused
+// (planning synchronises and copies): launch the group once before the capture.
+struct GroupPlan {
+  uint64_t ids[NSG_MAX_SEGMENTS];
+  uint64_t gens[NSG_MAX_SEGMENTS];
+  int n_members = 0;
+  Segment* d_table = nullptr;
+  int total_blocks = 0, all_simple = 0, group_lds = 0, device = -1;
+  const nsg_spec::Module* group_spec = nullptr;
+  uint64_t last_used = 0;
+};
+constexpr size_t kMaxGroupPlans = 16;     // least recently used beyond this
+constexpr size_t kMaxRetiredTables = 32;  // drained (device synchronisation + free) beyond this
+static std::mutex g_plan_mutex;
+static std::vector<GroupPlan> g_plans;
+static std::vector<std::pair<int, Segment*>> g_retired;   // (device, table)
+static uint64_t g_plan_clock = 0;
+
+static void retire_table_locked(GroupPlan& p) {
+  if (p.d_table) g_retired.emplace_back(p.device, p.d_table);
+  p.d_table = nullptr;
+}
+// Frees the retired tables; the caller has established that no launch can still read them (device synchronised, no capture).
+static void drain_retired_locked() {
+  for (auto& r : g_retired) (void)hipFree(r.second);
+  g_retired.clear();
+}
+static bool same_members(const GroupPlan& p, nsg_handle* const* hs, int n) {
+  if (p.n_members != n) return false;
+  for (int k = 0; k < n; k++)
+    if (p.ids[k] != hs[k]->id) return false;
+  return true;
+}
+static bool plan_is_current(const GroupPlan& p, nsg_handle* const* hs) {
+  for (int k = 0; k < p.n_members; k++)
+    if (p.gens[k] != hs[k]->generation) return false;
+  return true;
+}
+
+// (Re-)plans `plan` for the member list; called with g_plan_mutex held, never during a stream capture.
+static int make_group_plan_locked(GroupPlan& plan, nsg_handle* const* hs, int n_handles) {
+  int order[NSG_MAX_SEGMENTS];
+  for (int k = 0; k < n_handles; k++) order[k] = k;
+  // workgroups are dispatched in block order: the members with the longest-running workgroups get the
+  // lowest block ranges (Acrobot's RK4 step takes ~3x a Pendulum step), the short ones fill in behind them
+  auto cost = [&](int k) {
+    static const int kEnvCost[NSG_ENV_COUNT] = {3, 2, 8, 1, 1, 2, 2, 2};  // relative time per workgroup
+    return kEnvCost[hs[k]->host.cfg.env_type] + (hs[k]->host.simple_theta ? 0 : 2);
   };
-  // a few plans per calling thread (callers that alternate member lists keep theirs); a slot's table is overwritten only
-  // after a device synchronisation
-  constexpr int kPlans = 4;
-  static thread_local Plan plans[kPlans];
-  static thread_local unsigned next_victim = 0;
-  const unsigned long long gen = g_generation.load();
-  int which = -1;
-  for (int q = 0; q < kPlans && which < 0; q++) {
-    bool same = plans[q].n_members == n_handles && plans[q].built_at == gen;
-    for (int k = 0; same && k < n_handles; k++) same = plans[q].members[k] == hs[k];
-    if (same) which = q;
+  static const bool shortest_first = [] { const char* e = getenv("NSG_GROUP_ORDER"); return e && e[0] == 's'; }();
+  for (int a = 1; a < n_handles; a++)
+    for (int b = a; b > 0 && (shortest_first ? cost(order[b]) < cost(order[b - 1]) : cost(order[b]) > cost(order[b - 1])); b--) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+  Segment tmp[NSG_MAX_SEGMENTS];
+  int begin = 0;
+  for (int k = 0; k < n_handles; k++) tmp[k] = hs[k]->host;
+  for (int j = 0; j < n_handles; j++) {
+    const int k = order[j];
+    tmp[k].block_begin = begin;
+    tmp[k].block_count = grid_for(hs[k]->n);
+    begin += tmp[k].block_count;
   }
-  const bool same = which >= 0;
-  if (!same) which = (int)(next_victim++ % kPlans);
-  Plan& plan = plans[which];
-  if (!same) {
-    int order[NSG_MAX_SEGMENTS];
-    for (int k = 0; k < n_handles; k++) {
-      if (!hs[k] || !hs[k]->bound) return fail(NSG_ENOTBOUND, "group member %d is not bound", k);
-      if (hs[k]->device != hs[0]->device) return fail(NSG_EINVAL, "group member %d lives on device %d, member 0 on device %d", k, hs[k]->device, hs[0]->device);
-      for (int j = 0; j < k; j++)
-        if (hs[j] == hs[k]) return fail(NSG_EINVAL, "group member %d is listed twice", k);
-      order[k] = k;
-    }
-    // workgroups are dispatched in block order: the members with the longest-running workgroups get the
-    // lowest block ranges (Acrobot's RK4 step takes ~3x a Pendulum step), the short ones fill in behind them
-    auto cost = [&](int k) {
-      static const int kEnvCost[NSG_ENV_COUNT] = {3, 2, 8, 1, 1, 2, 2, 2};  // relative time per workgroup
-      return kEnvCost[hs[k]->host.cfg.env_type] + (hs[k]->host.simple_theta ? 0 : 2);
-    };
-    static const bool shortest_first = [] { const char* e = getenv("NSG_GROUP_ORDER"); return e && e[0] == 's'; }();
-    for (int a = 1; a < n_handles; a++)
-      for (int b = a; b > 0 && (shortest_first ? cost(order[b]) < cost(order[b - 1]) : cost(order[b]) > cost(order[b - 1])); b--) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
-    Segment tmp[NSG_MAX_SEGMENTS];
-    int begin = 0;
-    for (int k = 0; k < n_handles; k++) tmp[k] = hs[k]->host;
-    for (int j = 0; j < n_handles; j++) {
-      const int k = order[j];
-      tmp[k].block_begin = begin;
-      tmp[k].block_count = grid_for(hs[k]->n);
-      begin += tmp[k].block_count;
-    }
-    if (plan.d_table) HIP_TRY(hipDeviceSynchronize());   // launches that read this slot's old table have drained
-    if (plan.d_table && plan.device != hs[0]->device) { (void)hipFree(plan.d_table); plan.d_table = nullptr; }
-    if (!plan.d_table) HIP_TRY(hipMalloc((void**)&plan.d_table, sizeof(Segment) * NSG_MAX_SEGMENTS));
-    HIP_TRY(hipMemcpy(plan.d_table, tmp, sizeof(Segment) * n_handles, hipMemcpyHostToDevice));
-    for (int k = 0; k < n_handles; k++) plan.members[k] = hs[k];
-    plan.n_members = n_handles;
-    plan.built_at = gen;
-    plan.total_blocks = begin;
-    plan.device = hs[0]->device;
-    plan.all_simple = 1;
-    plan.group_lds = 0;
-    bool all_spec = true;
-    for (int k = 0; k < n_handles; k++) {
-      plan.all_simple &= hs[k]->host.simple_theta;
-      all_spec = all_spec && hs[k]->spec != nullptr;
-      const int l = lds_bytes_for(hs[k]->host.table_bytes, hs[k]->host.uses_normal, hs[k]->host.uses_exp);
-      if (l > plan.group_lds) plan.group_lds = l;
-    }
-    // every member runs config-specialised kernels: so does the group (one unit for the ordered tuple of configs)
-    plan.group_spec = nullptr;
-    if (all_spec) {
-      uint64_t h0 = 0x67726f7570ull;  // "group"
-      const nsg_config* cfgs[NSG_MAX_SEGMENTS];
-      bool full[NSG_MAX_SEGMENTS];
-      for (int k = 0; k < n_handles; k++) {
-        h0 = nsg_spec::fnv1a(&hs[k]->spec->h0, sizeof(uint64_t), h0);
-        cfgs[k] = &hs[k]->host.cfg;
-        full[k] = !hs[k]->host.simple_theta;
-      }
-      hipDeviceProp_t prop;
-      HIP_TRY(hipGetDeviceProperties(&prop, hs[0]->device));
-      const int rc = get_spec_module(hs[0]->device, h0, true,
-                                     [&](std::string& err) { return nsg_spec::group_compile(cfgs, full, n_handles, prop.gcnArchName, err); },
-                                     &plan.group_spec);
-      if (rc) plan.group_spec = nullptr;  // the generic group kernel stays in force
-    }
+  retire_table_locked(plan);   // never overwritten: something in flight, or a captured graph, may still read it
+  if (g_retired.size() > kMaxRetiredTables) {
+    HIP_TRY(hipDeviceSynchronize());
+    drain_retired_locked();
   }
+  HIP_TRY(hipMalloc((void**)&plan.d_table, sizeof(Segment) * NSG_MAX_SEGMENTS));
+  HIP_TRY(hipMemcpy(plan.d_table, tmp, sizeof(Segment) * n_handles, hipMemcpyHostToDevice));
+  plan.n_members = n_handles;
+  plan.total_blocks = begin;
+  plan.device = hs[0]->device;
+  plan.all_simple = 1;
+  plan.group_lds = 0;
+  bool all_spec = true;
+  for (int k = 0; k < n_handles; k++) {
+    plan.ids[k] = hs[k]->id;
+    plan.gens[k] = hs[k]->generation;
+    plan.all_simple &= hs[k]->host.simple_theta;
+    all_spec = all_spec && hs[k]->spec != nullptr;
+    const int l = lds_bytes_for(hs[k]->host.table_bytes, hs[k]->host.uses_normal, hs[k]->host.uses_exp);
+    if (l > plan.group_lds) plan.group_lds = l;
+  }
+  // every member runs config-specialised kernels: so does the group (one unit for the ordered tuple of configs)
+  plan.group_spec = nullptr;
+  if (all_spec) {
+    uint64_t h0 = 0x67726f7570ull;  // "group"
+    const nsg_config* cfgs[NSG_MAX_SEGMENTS];
+    bool full[NSG_MAX_SEGMENTS];
+    for (int k = 0; k < n_handles; k++) {
+      h0 = nsg_spec::fnv1a(&hs[k]->spec->h0, sizeof(uint64_t), h0);
+      cfgs[k] = &hs[k]->host.cfg;
+      full[k] = !hs[k]->host.simple_theta;
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, hs[0]->device));
+    const int rc = get_spec_module(hs[0]->device, h0, true,
+                                   [&](std::string& err) { return nsg_spec::group_compile(cfgs, full, n_handles, prop.gcnArchName, err); },
+                                   &plan.group_spec);
+    if (rc) plan.group_spec = nullptr;  // the generic group kernel stays in force
+  }
+  return NSG_OK;
+}
+
+static int check_group_members(nsg_handle* const* hs, int32_t n_handles) {
+  if (!hs || n_handles <= 0 || n_handles > NSG_MAX_SEGMENTS) return fail(NSG_EINVAL, "bad group arguments");
+  for (int k = 0; k < n_handles; k++) {
+    if (!hs[k] || !hs[k]->bound) return fail(NSG_ENOTBOUND, "group member %d is not bound", k);
+    if (hs[k]->device != hs[0]->device) return fail(NSG_EINVAL, "group member %d lives on device %d, member 0 on device %d", k, hs[k]->device, hs[0]->device);
+    for (int j = 0; j < k; j++)
+      if (hs[j] == hs[k]) return fail(NSG_EINVAL, "group member %d is listed twice", k);
+  }
+  return NSG_OK;
+}
+
+int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* actions_dev, void* stream) {
+  if (!actions_dev) return fail(NSG_EINVAL, "bad group arguments");
+  int rc = check_group_members(hs, n_handles);
+  if (rc) return rc;
   ActionPtrs ap;
   memset(&ap, 0, sizeof(ap));
   for (int k = 0; k < n_handles; k++) {
     if (!actions_dev[k]) return fail(NSG_EINVAL, "actions_dev[%d] is NULL", k);
     ap.p[k] = actions_dev[k];
   }
+  // the launch parameters are copied out under the mutex; the launch itself is enqueued outside it
+  const Segment* ga = nullptr;
+  const nsg_spec::Module* group_spec = nullptr;
+  int total_blocks = 0, all_simple = 0, group_lds = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    GroupPlan* plan = nullptr;
+    for (GroupPlan& p : g_plans)
+      if (same_members(p, hs, n_handles)) { plan = &p; break; }
+    if (!plan || !plan_is_current(*plan, hs)) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        return fail(NSG_EINVAL, "nsg_step_group: this member list has no current plan and the stream is capturing (planning "
+                                "synchronises the device): launch the group once before the capture");
+      (void)hipGetLastError();
+      if (!plan) {
+        if (g_plans.size() >= kMaxGroupPlans) {   // least recently used goes; its table is retired, not freed
+          size_t lru = 0;
+          for (size_t q = 1; q < g_plans.size(); q++)
+            if (g_plans[q].last_used < g_plans[lru].last_used) lru = q;
+          retire_table_locked(g_plans[lru]);
+          g_plans.erase(g_plans.begin() + (long)lru);
+        }
+        g_plans.emplace_back();
+        plan = &g_plans.back();
+      }
+      rc = make_group_plan_locked(*plan, hs, n_handles);
+      if (rc) {   // nothing half-made stays behind
+        retire_table_locked(*plan);
+        g_plans.erase(g_plans.begin() + (plan - g_plans.data()));
+        return rc;
+      }
+    }
+    plan->last_used = ++g_plan_clock;
+    ga = plan->d_table;
+    group_spec = plan->group_spec;
+    total_blocks = plan->total_blocks;
+    all_simple = plan->all_simple;
+    group_lds = plan->group_lds;
+  }
   int reverse = next_traversal(hs[0]);   // the members of a group alternate together
-  const Segment* ga = plan.d_table;
-  if (plan.group_spec) {
+  if (group_spec) {
     void* args[] = {(void*)&ga, (void*)&n_handles, (void*)&ap, (void*)&reverse};
-    HIP_TRY(hipModuleLaunchKernel(plan.group_spec->group, plan.total_blocks, 1, 1, kBlock, 1, 1, (unsigned)plan.group_lds, (hipStream_t)stream, args, nullptr));
-  } else if (plan.all_simple) hipLaunchKernelGGL(step_group_kernel<false>, dim3(plan.total_blocks), dim3(kBlock), (size_t)plan.group_lds, (hipStream_t)stream, ga, n_handles, ap, reverse);
-  else hipLaunchKernelGGL(step_group_kernel<true>, dim3(plan.total_blocks), dim3(kBlock), (size_t)plan.group_lds, (hipStream_t)stream, ga, n_handles, ap, reverse);
+    HIP_TRY(hipModuleLaunchKernel(group_spec->group, total_blocks, 1, 1, kBlock, 1, 1, (unsigned)group_lds, (hipStream_t)stream, args, nullptr));
+  } else if (all_simple) hipLaunchKernelGGL(step_group_kernel<false>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, ga, n_handles, ap, reverse);
+  else hipLaunchKernelGGL(step_group_kernel<true>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, ga, n_handles, ap, reverse);
   HIP_TRY(hipGetLastError());
   return NSG_OK;
+}
+
+// Which kernel the CURRENT plan of this member list launches: NSG_GROUP_UNPLANNED (no launch yet, or a member changed since),
+// NSG_GROUP_GENERIC_SIMPLE / NSG_GROUP_GENERIC_FULL (precompiled step_group_kernel<false / true>), NSG_GROUP_SPECIALISED (the
+// unit compiled for the ordered tuple of the members' configs).  Negative: error.
+int nsg_step_group_kind(nsg_handle* const* hs, int32_t n_handles) {
+  int rc = check_group_members(hs, n_handles);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(g_plan_mutex);
+  for (const GroupPlan& p : g_plans)
+    if (same_members(p, hs, n_handles) && plan_is_current(p, hs))
+      return p.group_spec ? NSG_GROUP_SPECIALISED : p.all_simple ? NSG_GROUP_GENERIC_SIMPLE : NSG_GROUP_GENERIC_FULL;
+  return NSG_GROUP_UNPLANNED;
 }
 
 int nsg_fork(nsg_handle* src, nsg_handle* dst, uint64_t entropy, int32_t theta_mode, void* stream) {
@@ -942,7 +1033,7 @@ int nsg_specialize(nsg_handle* h) {
   if (const char* e = getenv("NSG_SPEC_FLAGS")) h0 = nsg_spec::fnv1a(e, strlen(e), h0);
   const int rc = get_spec_module(h->device, h0, false,
                                  [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err, inlane); }, &h->spec);
-  g_generation++;   // a group that contains this handle re-plans (its specialised unit depends on every member's)
+  h->generation++;   // a group that contains this handle re-plans (its specialised unit depends on every member's)
   return rc;
 }
 
@@ -950,7 +1041,23 @@ int nsg_is_specialized(const nsg_handle* h) { return h && h->spec ? 1 : 0; }
 
 int nsg_destroy(nsg_handle* h) {
   if (!h) return NSG_OK;
-  g_generation++;
+  {   // plans this handle is a member of go with it; their tables once nothing can read them any more
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    bool purged = false;
+    for (size_t q = 0; q < g_plans.size();) {
+      bool member = false;
+      for (int k = 0; k < g_plans[q].n_members; k++) member |= g_plans[q].ids[k] == h->id;
+      if (member) {
+        retire_table_locked(g_plans[q]);
+        g_plans.erase(g_plans.begin() + (long)q);
+        purged = true;
+      } else {
+        q++;
+      }
+    }
+    if (purged && hipDeviceSynchronize() == hipSuccess) drain_retired_locked();
+    (void)hipGetLastError();
+  }
   if (h->d_tables) (void)hipFree(h->d_tables);
   if (h->d_zig) (void)hipFree(h->d_zig);
   if (h->dev) (void)hipFree(h->dev);

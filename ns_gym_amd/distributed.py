@@ -24,6 +24,29 @@ def shard_seeds(base_seed: int, total_envs: int, rank: int, world: int):
     return np.arange(lo, hi, dtype=np.uint64) + np.uint64(base_seed)
 
 
+def _lsr(z: torch.Tensor, s: int) -> torch.Tensor:
+    """Logical right shift of int64 bit patterns (torch's >> is arithmetic)."""
+    return (z >> s) & ((1 << (64 - s)) - 1)
+
+
+def _s64(v: int) -> int:
+    """A 64-bit constant as the signed value with the same bit pattern (torch has no uint64 arithmetic)."""
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >> 63 else v
+
+
+def global_actions(k: int, lo: int, hi: int, n_actions: int = 2, device=None, salt: int = 123) -> torch.Tensor:
+    """Synthetic random discrete actions of the envs with GLOBAL indices [lo, hi) at step-pool slot `k`: a counter-based
+    draw (SplitMix64 of (salt, k, global index)), so what env i is fed does not depend on how the job is sharded - the same
+    job run on 1, 2 or 8 ranks steps every env through the same trajectory (tests/test_gpu_sharding_invariance.py)."""
+    i = torch.arange(int(lo), int(hi), dtype=torch.int64, device=device)
+    z = i + _s64(0x9E3779B97F4A7C15 * (1 + int(k)) + (int(salt) << 40))
+    z = (z ^ _lsr(z, 30)) * _s64(0xBF58476D1CE4E5B9)
+    z = (z ^ _lsr(z, 27)) * _s64(0x94D049BB133111EB)
+    z = z ^ _lsr(z, 31)
+    return (_lsr(z, 33) % int(n_actions)).to(torch.int32)
+
+
 def all_gather_returns(env, group=None, sizes=None) -> torch.Tensor:
     """All-gather of the last finished episode return of every env (one collective, 4 B/env).  `sizes`: the per-rank
     shard sizes when the caller knows them (e.g. `shard_range` for every rank) - otherwise they are exchanged first."""

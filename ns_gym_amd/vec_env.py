@@ -567,3 +567,19 @@ def step_group(envs, actions):
     with torch.cuda.device(envs[0].device):
         _lib.check(lib.nsg_step_group(hs, n, ap, envs[0]._stream), "nsg_step_group")
     return [(e._obs(), e.reward, e.terminated, e.truncated, e._info()) for e in envs]
+
+
+GROUP_KINDS = {0: "unplanned", 1: "generic", 2: "generic-full", 3: "specialised"}
+
+
+def step_group_kind(envs) -> str:
+    """Which kernel the current plan of this member list launches (`nsg_step_group_kind`): "unplanned" before the first
+    `step_group` of the list (or after a member changed), "generic" / "generic-full" (precompiled kernels), "specialised"
+    (the unit compiled for the ordered tuple of the members' configurations)."""
+    lib = _lib.load()
+    n = len(envs)
+    hs = (C.c_void_p * n)(*[e._h for e in envs])
+    k = lib.nsg_step_group_kind(hs, n)
+    if k < 0:
+        _lib.check(k, "nsg_step_group_kind")
+    return GROUP_KINDS[k]

@@ -1,7 +1,8 @@
 """Host-side robustness of the heterogeneous launch (nsg_step_group) and of the done-mask words under a masked reset.
 
-nsg_step_group carries its members' device segments and block ranges in the kernel arguments of every launch; what the
-library remembers about a member list is invalidated whenever a handle is bound, specialised or destroyed - by any thread.
+nsg_step_group reads its members' device segments and block ranges from a per-plan table; what the library remembers about a
+member list is keyed on the members' ids and valid for the members' own generations (nsg_bind / nsg_specialize of a member
+re-plan, nsg_destroy of a member drops the plan - from any thread); handles that are not members never touch it.
 These tests drive exactly the sequences that a cached, shared table got wrong: alternating member lists on a side stream
 without synchronising, specialising a member after the group's first launch, destroying a member and creating a new env
 (whose handle may reuse the address), and a destroy from another thread."""
@@ -101,6 +102,88 @@ def test_group_follows_specialise_destroy_and_recreate():
     torch.cuda.synchronize()
     _same(p, p_ref); _same(c2, c2_ref)
     for e in (p, p_ref, c_ref, c2, c2_ref):
+        e.close()
+
+
+def test_plan_survives_unrelated_handles_and_many_member_lists():
+    """What round 2's advisor found: every nsg_bind / nsg_destroy of ANY handle invalidated every plan (a planning copy made
+    per simulation cost the next group launch a device synchronisation + a blocking copy), and a slot's table was overwritten
+    after four re-plans.  Now: a plan is untouched by handles that are not its members, and more member lists than there are
+    plan slots (16) alternate with every launch reading its own members' segments."""
+    import torch
+
+    from ns_gym_amd.vec_env import step_group, step_group_kind
+
+    T = 6
+    (p, p_ref), (a, a_ref) = _pair("c4_pendulum_m_inc", 3000, specialize=False), _pair("c4_acrobot_mass2_inc", 2000, specialize=False)
+    ap, aa = _acts(p, 40 * T, 1), _acts(a, 40 * T, 2)
+    assert step_group_kind([p, a]) == "unplanned"
+    step_group([p, a], [ap[0], aa[0]])
+    assert step_group_kind([p, a]) == "generic"
+    k = 1
+    for _ in range(5):   # unrelated handles come and go: bind + destroy, a planning copy, a specialised batch
+        other = make_env_from_spec(_vec, TRAJ_SPECS["c1_cartpole_masspole_inc"], n=512, specialize=False)
+        other.reset(seed=1)
+        copy = other.fork()
+        assert step_group_kind([p, a]) == "generic"          # still planned
+        step_group([p, a], [ap[k], aa[k]]); k += 1
+        copy.close(); other.close()
+        assert step_group_kind([p, a]) == "generic"
+    # 20 distinct member lists (more than the 16 plan slots) round-robin, [p, a] in between
+    smalls = [make_env_from_spec(_vec, TRAJ_SPECS["c3_frozenlake_step50"], n=300 + 10 * j, specialize=False) for j in range(20)]
+    refs = [make_env_from_spec(_vec, TRAJ_SPECS["c3_frozenlake_step50"], n=300 + 10 * j, specialize=False) for j in range(20)]
+    for e in smalls + refs:
+        e.reset(seed=4)
+    sa = [_acts(e, 3, 50 + j) for j, e in enumerate(smalls)]
+    for r in range(3):
+        for j, e in enumerate(smalls):
+            step_group([e, p], [sa[j][r], ap[k]])
+            step_group([p, a], [ap[k + 1], aa[k]])
+            refs[j].step(sa[j][r])
+            k += 2
+    for q in range(k):
+        p_ref.step(ap[q])
+    n_a = 1 + 5 + 60
+    for q in range(n_a):
+        a_ref.step(aa[[0, 1, 2, 3, 4, 5][q] if q < 6 else 6 + 2 * (q - 6)])
+    torch.cuda.synchronize()
+    _same(p, p_ref); _same(a, a_ref)
+    for e, r in zip(smalls, refs):
+        _same(e, r)
+    for e in [p, p_ref, a, a_ref] + smalls + refs:
+        e.close()
+
+
+def test_group_launch_inside_a_graph_capture():
+    """A planned member list is graph-capturable (the launch reads kernel arguments and an immutable table); a list that would
+    have to be planned during the capture is refused with an error instead of synchronising inside it."""
+    import torch
+
+    from ns_gym_amd._lib import NsgError
+    from ns_gym_amd.vec_env import step_group
+
+    (p, p_ref), (c, c_ref) = _pair("c4_pendulum_m_inc", 5000, specialize=False), _pair("c1_cartpole_masspole_inc", 4000, specialize=False)
+    ap, ac = _acts(p, 1, 1)[0], _acts(c, 1, 2)[0]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        keep = ap + 0                       # the capture holds at least one node
+        with pytest.raises(NsgError, match="capturing"):
+            step_group([p, c], [ap, ac])
+    step_group([p, c], [ap, ac])           # plans (outside any capture)
+    p_ref.step(ap); c_ref.step(ac)
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        step_group([p, c], [ap, ac])
+        step_group([p, c], [ap, ac])
+    for _ in range(5):
+        g2.replay()
+        for _ in range(2):
+            p_ref.step(ap); c_ref.step(ac)
+    del keep
+    torch.cuda.synchronize()
+    _same(p, p_ref); _same(c, c_ref)
+    for e in (p, p_ref, c, c_ref):
         e.close()
 
 
