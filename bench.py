@@ -7,13 +7,21 @@ configuration of BASELINE.json — CartPole-v1 + masspole IncrementUpdate(+0.1) 
 ContinuousScheduler — at 2^20 envs PER GPU (weak scaling; 8 GPUs = C5's 8,388,608 envs).
 Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL); envs are sharded by
 contiguous index with no per-step collective; the only exchange is one all-gather of the
-per-env episode returns at rollout end, inside the timed region.
+per-env episode returns at rollout END - per rollout, not per step - so it is timed on its own,
+right after the K timed steps and between the same barriers, OUTSIDE the K-step region that
+`value` is computed from (`config.returns_gather_ms`; `config.value_incl_gather` is the rate with
+the gather's time added to the K steps', `config.value_incl_gather_T1000` the same for a
+1000-step rollout).  Seeds AND actions are functions of the GLOBAL env index, so every env walks
+the same trajectory however the job is sharded (tests/test_gpu_sharding_invariance.py).
 
 `python bench.py --gpus N` without a torch.distributed launcher around it starts the N ranks ITSELF (one child per GPU under
 torch.distributed.run, before this process touches a GPU) and relays rank 0's line; under a launcher (WORLD_SIZE set) it is
 one rank and `--gpus` must equal WORLD_SIZE.  It refuses to run on fewer devices than ranks.
 
 Prints ONE JSON line on rank 0 (see the task contract) with `roofline`, `roofline_hbm_resident` and `cpu_baseline`.
+At N > 1 `roofline` prices the AGGREGATE: 120 B x `value` against N x 8 TB/s, rank 0's own kernel time beside it.
+`config.baseline_configs_at_own_size`: every BASELINE configuration at the batch size BASELINE quotes it at (C1 2^20, C2 65 536,
+C3 2^20, C4 Pendulum 2^18 + Acrobot 2^18 in one heterogeneous launch), step API and fused rollout, each with its own bytes.
 """
 import argparse
 import json
@@ -53,6 +61,73 @@ def cpu_baseline(n_envs, steps, threads):
     return n_envs * steps / dt, dt
 
 
+def baseline_configs_at_own_size(dev, c1_step_us, c1_rollout_rate, n_c1):
+    """Every BASELINE configuration at the batch size BASELINE quotes it at, on this GPU, config-specialised kernels: the step
+    API (average of 300 back-to-back launches, HIP events on the launch stream) against ITS algorithmic bytes and the 8 TB/s
+    peak, and the fused rollout (K = 64) with the bytes a rollout moves (action + recorded outputs).  C1's row repeats the
+    line's own measurement.  Not `value`."""
+    import torch
+
+    from ns_gym_amd import workloads as W
+    from ns_gym_amd.vec_env import step_group, step_group_kind
+
+    def frac(bytes_per_step, n_envs, us):
+        return bytes_per_step * n_envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+
+    def rollout_us(env, K=64, reps=4):
+        acts = torch.stack([W.random_actions(env) for _ in range(K)])
+        env.rollout(acts)
+        torch.cuda.synchronize()
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record()
+        for _ in range(reps):
+            env.rollout(acts)
+        r1.record()
+        torch.cuda.synchronize()
+        return r0.elapsed_time(r1) * 1e3 / (reps * K)
+
+    rows = {"C1": {"envs": n_c1, "step_us": c1_step_us, "bytes_per_env_step": BYTES_PER_ENV_STEP,
+                   "frac_of_hbm_peak": frac(BYTES_PER_ENV_STEP, n_c1, c1_step_us), "env_steps_per_sec": n_c1 / (c1_step_us * 1e-6),
+                   "rollout_k64_env_steps_per_sec": c1_rollout_rate}}
+    for tag, name in (("C2", "c2"), ("C3", "c3")):
+        w = W.WORKLOADS[name]
+        env = W.build(name, specialize=True, device=dev)
+        a = W.random_actions(env)
+        for _ in range(30):
+            env.step(a)
+        us = min(env.time_steps(a, 300) for _ in range(2)) * 1e3
+        ru = rollout_us(env)
+        rows[tag] = {"envs": env.N, "step_us": us, "bytes_per_env_step": w["bytes_per_env_step"],
+                     "frac_of_hbm_peak": frac(w["bytes_per_env_step"], env.N, us), "env_steps_per_sec": env.N / (us * 1e-6),
+                     "rollout_k64_us_per_step": ru, "rollout_k64_env_steps_per_sec": env.N / (ru * 1e-6)}
+        if env.N <= 1 << 16:
+            rows[tag]["regime"] = "one wavefront per SIMD: bound by launch latency + the step's serial chain, not by memory"
+        env.close()
+    pend, acro = W.build("pend", specialize=True, device=dev), W.build("acro", specialize=True, device=dev)
+    ap_, aa = W.random_actions(pend), W.random_actions(acro)
+    for _ in range(20):
+        step_group([pend, acro], [ap_, aa])
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(300):
+            step_group([pend, acro], [ap_, aa])
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / 300)
+    by = W.WORKLOADS["pend"]["bytes_per_env_step"] + W.WORKLOADS["acro"]["bytes_per_env_step"]
+    rows["C4"] = {"envs": [pend.N, acro.N], "launch": "one nsg_step_group launch (" + step_group_kind([pend, acro]) + " unit)",
+                  "step_us": best, "bytes_per_env_pair_step": by, "frac_of_hbm_peak": frac(by, pend.N, best),
+                  "env_steps_per_sec": (pend.N + acro.N) / (best * 1e-6),
+                  "pendulum_alone_us": min(pend.time_steps(ap_, 200) for _ in range(2)) * 1e3,
+                  "acrobot_alone_us": min(acro.time_steps(aa, 200) for _ in range(2)) * 1e3,
+                  "bound": "the Acrobot member's float64 vector-ALU issue (RK4: 15 sincos + 12 divisions per step), not HBM"}
+    pend.close(); acro.close()
+    return rows
+
+
 def self_launch(args, argv):
     """`--gpus N > 1` outside a launcher: run N ranks under torch.distributed.run as a child (this process never initialises a
     GPU: device_count() does not), relay its output, exit with its code."""
@@ -86,6 +161,9 @@ def main():
     ap.add_argument("--generic", action="store_true",
                     help="time the generic kernels instead of the config-specialised ones (nsg_specialize)")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the second roofline figure (2^24 envs)")
+    ap.add_argument("--no-all-configs", action="store_true", help="skip config.baseline_configs_at_own_size (C2 / C3 / C4 at their own sizes)")
+    ap.add_argument("--dump-shards", default=None, metavar="DIR",
+                    help="after the timed steps every rank writes its shard's final rows, rank 0 the gathered returns (sharding-invariance test)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -148,7 +226,10 @@ def main():
     env.reset(seed=torch.arange(rank * n, (rank + 1) * n, dtype=torch.int64).numpy().astype("uint64"))
     g = torch.Generator(device=dev)
     g.manual_seed(123 + rank)
-    pool = [torch.randint(0, 2, (n,), dtype=torch.int32, device=dev, generator=g) for _ in range(8)]
+    # synthetic random actions, a function of (pool slot, GLOBAL env index): what env i is fed does not depend on the sharding
+    from ns_gym_amd.distributed import global_actions
+
+    pool = [global_actions(k, rank * n, (rank + 1) * n, 2, device=dev) for k in range(8)]
 
     def barrier():
         if dist is not None:
@@ -211,6 +292,19 @@ def main():
     barrier()
     gather_ms = (time.perf_counter() - tg) * 1e3
 
+    if args.dump_shards:   # every row a sharded job must reproduce whatever its world size
+        import numpy as np
+
+        os.makedirs(args.dump_shards, exist_ok=True)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(args.dump_shards, f"world{world}_rank{rank}.npz"), lo=rank * n, hi=(rank + 1) * n,
+                 obs=env.state.cpu().numpy(), phys=env.phys.cpu().numpy(), t=env.t.cpu().numpy(), theta=env.theta.cpu().numpy(),
+                 episode=env.buf["episode"].cpu().numpy(), last_length=env.buf["last_length"].cpu().numpy(),
+                 reward=env.reward.cpu().numpy(), terminated=env.terminated.cpu().numpy(), truncated=env.truncated.cpu().numpy(),
+                 delta_change=env.gt_delta_change.cpu().numpy())
+        if rank == 0:
+            np.save(os.path.join(args.dump_shards, f"world{world}_gathered_returns.npy"), gathered.cpu().numpy())
+
     episodes_rank0 = env.counters()["episodes"]
     # secondary figure (not `value`): the same env-steps through nsg_rollout, K = 64 fused steps per launch
     # with the persistent rows held in registers (callers that supply K actions at once: planners' rollouts)
@@ -240,6 +334,13 @@ def main():
     except NsgError:
         pass
 
+    own_size = None
+    if world == 1 and not args.no_all_configs and not args.generic:
+        try:
+            own_size = baseline_configs_at_own_size(dev, kern_ms * 1e3, rollout_rate, n)
+        except (NsgError, RuntimeError) as e:
+            own_size = {"error": str(e)[:200]}
+
     # second roofline figure (not `value`): the same kernel on a batch whose rows cannot live in the Infinity Cache
     # (2^24 envs = 2.5 GB of rows against 256 MiB), i.e. streamed from HBM on every step.  Rank 0 of an N = 1 run only.
     hbm = None
@@ -262,15 +363,27 @@ def main():
         except (NsgError, RuntimeError) as e:     # e.g. not enough device memory next to another tenant
             hbm = {"error": str(e)[:200]}
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, gather_ms, kern_ms], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
+    dt_max, gather_ms_max, kern_ms_max = (float(x) for x in t.tolist())
     total_env_steps = float(n) * world * args.steps
     value = total_env_steps / dt_max
+    # the same job with its one exchange charged to it: this window's K steps + the gather, and a T = 1000 rollout + the gather
+    value_incl_gather = total_env_steps / (dt_max + gather_ms_max * 1e-3)
+    value_incl_gather_t1000 = float(n) * world * 1000 / (dt_max / args.steps * 1000 + gather_ms_max * 1e-3)
 
     if rank == 0:
         achieved = BYTES_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e9
+        peak = HBM_PEAK_GBS
+        multi = None
+        if world > 1:
+            # N > 1: the job's roofline is the aggregate - 120 B x all ranks' env-steps per second of the job's (max-over-ranks)
+            # time, against N x 8 TB/s; rank 0's own kernel stays beside it
+            multi = {"rank0_avg_launch_us": kern_ms * 1e3, "rank0_frac_of_one_gpu": achieved / HBM_PEAK_GBS,
+                     "slowest_rank_avg_launch_us": kern_ms_max * 1e3}
+            achieved = BYTES_PER_ENV_STEP * value / 1e9
+            peak = HBM_PEAK_GBS * world
         out = {
             "metric": "non-stationary env-steps/sec",
             "value": value,
@@ -291,14 +404,16 @@ def main():
                 "parallelism": f"env-sharded x{world}, no per-step collective; 1 all-gather of episode returns at rollout end (returns_gather_ms, outside the K timed steps)"
                                if world > 1 else "single GPU",
                 "episodes_finished_rank0": episodes_rank0,
-                "gathered_returns": int(gathered.numel()), "returns_gather_ms": gather_ms,
+                "gathered_returns": int(gathered.numel()), "returns_gather_ms": gather_ms_max,
+                "value_incl_gather": value_incl_gather, "value_incl_gather_T1000": value_incl_gather_t1000,
+                "actions": "counter-based uniform draws per (pool slot, global env index): independent of the sharding",
                 "rollout_k64_env_steps_per_sec_per_gpu": rollout_rate,
                 "kernels": "generic (precompiled)" if args.generic else "config-specialised (nsg_specialize, hiprtc)",
                 ("specialised_kernel_avg_launch_us" if args.generic else "generic_kernel_avg_launch_us"): other_us,
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic(n),
+                "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
+                "frac": achieved / peak, "traffic": _pmc_traffic(n),
                 "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of an "
                                   "earlier run of this kernel, scaled per env; not measured in this run)",
                 "residency": f"{n} envs = {n * 150 / 1e6:.0f} MB of rows: "
@@ -309,6 +424,12 @@ def main():
                 "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
             },
         }
+        if multi is not None:
+            out["roofline"].update(multi)
+            out["roofline"]["basis"] = (f"aggregate: {BYTES_PER_ENV_STEP} B x value (all {world} ranks, max-over-ranks time) against "
+                                        f"{world} x {HBM_PEAK_GBS:.0f} GB/s; avg_launch_us is rank 0's kernel")
+        if own_size is not None:
+            out["config"]["baseline_configs_at_own_size"] = own_size
         if hbm is not None:
             out["roofline_hbm_resident"] = hbm
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is reported on rank 0 at N = 1 only

@@ -328,12 +328,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   // episode word: bit 0 = needs reset, bits 1-31 = resets this env has drawn from its np_random so far (nsgym_hip.h)
   const unsigned st = !active ? 0u : io.load ? (unsigned)ldg(b.episode, o4) : ls.st;
   const int t = !active ? 0 : io.load ? ldg(b.t, o4) : ls.t;
-#ifdef NSG_X_INLINE_RESET  // TIMING ABLATION ONLY (wrong results): a finished env re-initialises in its own lane, no hand-over
-  const bool x_was_done = active && (st & NSG_ST_NEEDS_RESET);
-  const bool do_reset = false;
-#else
   const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);
-#endif
   const bool do_step = active && !do_reset;
   if (sim && io.load && active) ls.tf = ldg(b.t_fork, o4);
   const bool ld_state = NSG_UNCOND_LOADS ? active : do_step;
@@ -488,23 +483,8 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     }
   }
   if (do_step) {
-#ifdef NSG_X_FAKE_STEP  // TIMING ABLATION ONLY (wrong results): no integrator arithmetic, same episode-end rate
-#pragma unroll
-    for (int k = 0; k < T::PHYS; k++) s[k] = s[k] * 0.999 + th[0] * 1e-6;
-    term = (((uint32_t)i * 2654435761u + (uint32_t)t * 40503u) >> 22) < 46u;
-    reward = 1.0;
-#else
     term = env_step<ENV>(th, s, ai, af, reward);
-#endif
-#ifdef NSG_X_INLINE_RESET
-    if (x_was_done) {
-#pragma unroll
-      for (int k = 0; k < T::PHYS; k++) s[k] = 0.01 * (k + 1);
-    }
-    tnew = x_was_done ? 0 : t + 1;
-#else
     tnew = t + 1;  // base.py:314
-#endif
     // TimeLimit [UPSTREAM] counts the steps of ITS env: a planning copy restarts at the fork
     const int elapsed = tnew - (sim ? ls.tf : 0);
     trunc = cfg.max_episode_steps > 0 && elapsed >= cfg.max_episode_steps;
@@ -539,11 +519,12 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     constexpr int D = T::RESET_DRAWS;
     static_assert((64 % D) == 0, "the D helper lanes of one reset must sit in one wavefront (see the count read below)");
     int* rn = lds.reset_n + (parity & 1);
-    // the owner queues its lane and leaves its episode count in the first word of its own result slot
-    uint64_t* slot = reinterpret_cast<uint64_t*>(lds.reset_state);
+    // the owner queues its lane and leaves its episode count in the first word of its own result slot - as the BIT PATTERN of a
+    // double, so that every access to these words goes through one type (a uint64 view of the same words would be "no alias" to
+    // the compiler, which could then move the count's load past the helper's store below)
     if (do_reset) {
       lds.reset_list[atomicAdd(rn, 1)] = (short)tid;
-      slot[tid * 4] = (uint64_t)(st >> NSG_EP_COUNT_SHIFT);
+      lds.reset_state[tid * 4] = __longlong_as_double((long long)(st >> NSG_EP_COUNT_SHIFT));
     }
     __syncthreads();
     const int n_reset = *rn;
@@ -567,9 +548,11 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
 #if NSG_RESET_LANE_PER_DRAW
       for (int h = tid; h < n_reset * D; h += kBlock) {
         const int owner = lds.reset_list[h / D], j = h % D;
-        // the count shares its word with result 0: the D lanes of a reset are neighbours in ONE wavefront (64 % D == 0), all of
-        // them execute this read before any of them reaches the store below
-        const uint64_t count = slot[owner * 4];
+        // the count shares its word with result 0: the D lanes of a reset are neighbours in ONE wavefront (64 % D == 0) and a
+        // wavefront's LDS operations execute in issue order, so all of them have read the count before any of them stores a
+        // result; the wave barrier (no instruction: a scheduling fence) keeps the compiler from moving the load below the store
+        const uint64_t count = (uint64_t)__double_as_longlong(lds.reset_state[owner * 4]);
+        __builtin_amdgcn_wave_barrier();
         Pcg g;
         const u64x2 desc = {zg.sd0, zg.sd1};
         env_stream_at<2>(b.rng_env, base + owner, count * (uint64_t)D + (uint64_t)j, zg.jump, g, &desc);
@@ -578,7 +561,8 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
 #else   // one helper lane per reset: one jump, then D - 1 sequential PCG64 steps
       if (tid < n_reset) {
         const int owner = lds.reset_list[tid];
-        const uint64_t count = slot[owner * 4];
+        const uint64_t count = (uint64_t)__double_as_longlong(lds.reset_state[owner * 4]);
+        __builtin_amdgcn_wave_barrier();
         Pcg g;
         const u64x2 desc = {zg.sd0, zg.sd1};
         env_stream_at<2>(b.rng_env, base + owner, count * (uint64_t)D, zg.jump, g, &desc);

@@ -13,6 +13,7 @@
 #pragma once
 
 #include <dlfcn.h>
+#include <string.h>
 
 #include <map>
 #include <mutex>
@@ -81,7 +82,7 @@ inline const Rtc* rtc() {
 // ---- the specialised translation unit ----------------------------------------------------------
 // The config is emitted as its raw 64-bit words (independent of the struct's field list) and viewed
 // as nsg_config; after inlining every access is a load from a constant at a constant offset.
-constexpr const char* kGeneratorRev = "spec_source r2.3";   // part of the cache key (nsgym_hip.hip: spec_source_hash)
+constexpr const char* kGeneratorRev = "spec_source r3.0";   // part of the cache key (nsgym_hip.hip: spec_source_hash)
 inline std::string spec_source(const nsg_config& cfg, bool full, bool resets_in_lane = false, bool six_waves = true) {
   static_assert(sizeof(nsg_config) % 8 == 0, "nsg_config is emitted as 64-bit words");
   std::string s;
@@ -169,43 +170,65 @@ inline std::string group_source(const nsg_config* const* cfgs, const bool* full,
 
 inline std::vector<char> compile_source(const std::string& src, const char* arch, std::string& err);
 
-// VGPR spill count of kernel `name` from the code object's metadata note (msgpack: the kernel's map holds its keys in
-// alphabetical order, so ".vgpr_spill_count" follows ".name" of the same kernel).  -1 = not found.
-inline int vgpr_spill_count(const std::vector<char>& code, const char* name) {
-  const std::string kn = std::string(".name") + (char)(0xa0 + strlen(name)) + name;   // fixstr key, fixstr value (< 32 chars)
-  const std::string ks = "\xb1.vgpr_spill_count";                                      // fixstr of 17 chars
+// Largest .vgpr_spill_count / .private_segment_fixed_size over ALL kernels of a code object (-1: metadata not found).  A unit
+// is judged as a whole: its step, rollout and group kernels are all product paths.
+inline int max_metadata_value(const std::vector<char>& code, const char* key17or27) {
   const std::string blob(code.begin(), code.end());
-  const size_t a = blob.find(kn);
-  if (a == std::string::npos) return -1;
-  const size_t b = blob.find(ks, a);
-  if (b == std::string::npos || b + ks.size() >= blob.size()) return -1;
-  const unsigned char* v = (const unsigned char*)blob.data() + b + ks.size();
-  const size_t left = blob.size() - (b + ks.size());
-  if (v[0] < 0x80) return v[0];                                            // positive fixint
-  if (v[0] == 0xcc && left >= 2) return v[1];                              // uint8
-  if (v[0] == 0xcd && left >= 3) return (v[1] << 8) | v[2];                // uint16
-  if (v[0] == 0xce && left >= 5) return (int)(((unsigned)v[1] << 24) | (v[2] << 16) | (v[3] << 8) | v[4]);
-  return -1;
+  const size_t klen = strlen(key17or27);
+  std::string k;
+  if (klen < 32) k += (char)(0xa0 + klen);              // fixstr
+  else { k += (char)0xd9; k += (char)klen; }            // str8
+  k += key17or27;
+  int worst = -1;
+  for (size_t b = blob.find(k); b != std::string::npos; b = blob.find(k, b + 1)) {
+    if (b + k.size() >= blob.size()) break;
+    const unsigned char* v = (const unsigned char*)blob.data() + b + k.size();
+    const size_t left = blob.size() - (b + k.size());
+    int x = -1;
+    if (v[0] < 0x80) x = v[0];
+    else if (v[0] == 0xcc && left >= 2) x = v[1];
+    else if (v[0] == 0xcd && left >= 3) x = (v[1] << 8) | v[2];
+    else if (v[0] == 0xce && left >= 5) x = (int)(((unsigned)v[1] << 24) | (v[2] << 16) | (v[3] << 8) | v[4]);
+    if (x > worst) worst = x;
+  }
+  return worst;
+}
+// true when some kernel of the unit spills vector registers or owns scratch memory (or the metadata cannot be read)
+inline bool unit_uses_scratch(const std::vector<char>& code) {
+  return max_metadata_value(code, ".vgpr_spill_count") != 0 || max_metadata_value(code, ".private_segment_fixed_size") != 0;
+}
+// NSG_SPEC_ALLOW_SPILL=1: DIAGNOSTIC ONLY (tools/spill_probe.py) - keep a unit that spills instead of rebuilding / refusing it
+inline bool allow_spill() {
+  const char* e = getenv("NSG_SPEC_ALLOW_SPILL");
+  return e && e[0] == '1';
 }
 
 // Compile the specialised unit for `arch` (e.g. "gfx950"); no GPU needed.  Returns "" and fills `err` on failure.
-// A step kernel that spills vector registers is never shipped: spilling costs more than the occupancy the register bound was
-// asked for (a two-stochastic-param CartPole config: 65-100 spilled VGPRs, 228 B of scratch per lane) - and one such build
-// returned wrong results on MI355X (ROCm 7.2 hiprtc; spill stores placed under a partial exec mask, reloaded under the full
-// one).  Such a config is compiled again without the bound.
+// A unit in which ANY kernel - step or rollout - spills vector registers or uses scratch memory is never shipped: spilling costs
+// more than the occupancy the register bound was asked for (a two-update-fn CartPole config with its own stream: 54-100 spilled
+// VGPRs, 164-228 B of scratch per lane), and one such build returned wrong results on MI355X (round 2, random-configuration
+// case 61; profiles/r03_case61_spill_evidence.md).  Such a config is compiled again without the bound; if it still spills
+// (only reachable through NSG_SPEC_FLAGS forcing a register bound) the unit is refused and the generic kernels stay in force.
 inline std::vector<char> spec_compile(const nsg_config& cfg, bool full, const char* arch, std::string& err, bool resets_in_lane = false) {
   std::vector<char> code = compile_source(spec_source(cfg, full, resets_in_lane, true), arch, err);
-  if (!code.empty() && vgpr_spill_count(code, "nsg_spec_step") != 0)
+  if (!code.empty() && unit_uses_scratch(code) && !allow_spill())
     code = compile_source(spec_source(cfg, full, resets_in_lane, false), arch, err);
-  if (!code.empty() && vgpr_spill_count(code, "nsg_spec_step") > 0) {   // only reachable through NSG_SPEC_FLAGS (a forced register bound)
-    err = "the specialised step kernel spills vector registers under the given NSG_SPEC_FLAGS; such builds are not used "
-          "(see spec_compile)";
+  if (!code.empty() && unit_uses_scratch(code) && !allow_spill()) {
+    err = "a kernel of the specialised unit spills vector registers (scratch memory) under the given NSG_SPEC_FLAGS; such builds "
+          "are not used (see spec_compile)";
     code.clear();
   }
   return code;
 }
+// The heterogeneous launch's unit is held to the same rule: a group kernel that spills is refused (the generic group kernel
+// stays in force, nsg_step_group).
 inline std::vector<char> group_compile(const nsg_config* const* cfgs, const bool* full, int n, const char* arch, std::string& err) {
-  return compile_source(group_source(cfgs, full, n), arch, err);
+  std::vector<char> code = compile_source(group_source(cfgs, full, n), arch, err);
+  if (!code.empty() && unit_uses_scratch(code) && !allow_spill()) {
+    err = "the specialised group kernel spills vector registers (scratch memory); such builds are not used (see spec_compile)";
+    code.clear();
+  }
+  return code;
 }
 
 inline std::vector<char> compile_source(const std::string& src, const char* arch, std::string& err) {
@@ -248,7 +271,14 @@ inline std::vector<char> compile_source(const std::string& src, const char* arch
       }
     }
   }
-  for (const std::string& x : extra) opts.push_back(x.c_str());
+  for (const std::string& x : extra) {
+    if (x.compare(0, 8, "-DNSG_X_") == 0) {   // the timing ablations of earlier rounds (wrong results by design) are gone from the kernels
+      err = "NSG_SPEC_FLAGS: " + x + " names a timing ablation; those are not part of the product kernels";
+      r->destroy(&prog);
+      return code;
+    }
+    opts.push_back(x.c_str());
+  }
   const int rc = r->compile(prog, (int)opts.size(), opts.data());
   if (rc != 0) {
     size_t n = 0;

@@ -151,6 +151,7 @@ uint64_t spec_source_hash() {
   for (const char* src : {nsg_src_abi, nsg_src_math, nsg_src_rng, nsg_src_theta, nsg_src_envs, nsg_src_kernels, nsg_src_rollout})
     h1 = nsg_spec::fnv1a(src, strlen(src), h1);
   if (const char* e = getenv("NSG_SPEC_FLAGS")) h1 = nsg_spec::fnv1a(e, strlen(e), h1);  // extra compile options are part of the key
+  if (nsg_spec::allow_spill()) h1 = nsg_spec::fnv1a("allow-spill", 11, h1);              // a diagnostic build never shares a cache entry
   // so are the fixed options of nsg_spec::compile_source (keep this literal in step with them) and the toolchain the
   // library was built with: code objects persist on disk between processes (spec_cache_dir)
   static const char kFixed[] = "-O3 -std=c++17 -ffp-contract=off -Wno-unused-function block " NSG_STR(NSG_BLOCK) " hip " HIP_VERSION_STR;

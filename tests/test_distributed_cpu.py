@@ -1,5 +1,8 @@
 """N > 1 path on CPU: world_size-2 gloo run of the sharding helpers and of the one collective of
-the path (all-gather of per-env episode returns)."""
+the path (all-gather of per-env episode returns), and a world-8 rehearsal of the WHOLE sharded job's host logic - shard
+ranges, seeds by global index, counter-based actions by global index, the gather and its order - with the oracle standing
+in for the kernels (a test box allows at most six processes on its GPU; the 1 / 2 / 4-rank runs of the real kernels are
+tests/test_gpu_sharding_invariance.py)."""
 import os
 import socket
 import sys
@@ -64,3 +67,65 @@ def test_all_gather_returns_gloo_world2():
     for total in (12, 11):
         want = [i * 0.5 for i in range(total)]
         assert res[0][total] == want and res[1][total] == want
+
+
+def _job_worker(rank, world, port, total, steps, q):
+    """One rank of C5's job with the oracle as the stepper: its shard of the global index range, seeds and actions by
+    global index, then the job's one collective."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ns_gym_amd.distributed import all_gather_returns, global_actions, shard_range, shard_seeds
+
+    lo, hi = shard_range(total, rank, world)
+    env = _oracle_c1(hi - lo)
+    env.reset(seed=shard_seeds(0, total, rank, world))
+    for k in range(steps):
+        env.step(global_actions(k % 8, lo, hi).numpy())
+    sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+    got = all_gather_returns(_FakeEnv(torch.from_numpy(env.a["last_length"].astype(np.float32))), sizes=sizes)
+    q.put((rank, got.numpy().tobytes(), env.a["obs"].tobytes(), env.a["t"].tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _oracle_c1(n):
+    from ns_gym_amd import make
+    from ns_gym_amd.schedulers import ContinuousScheduler
+    from ns_gym_amd.update_functions import IncrementUpdate
+    from oracle.oracle import OracleVecEnv
+
+    return OracleVecEnv(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)}, n,
+                        change_notification=True, delta_change_notification=True, track_returns=True)
+
+
+@pytest.mark.parametrize("total", [4096, 4099])    # even shards and ragged ones
+def test_eight_rank_job_equals_the_unsharded_job(total):
+    from ns_gym_amd.distributed import global_actions
+
+    world, steps = 8, 120
+    ref = _oracle_c1(total)
+    ref.reset(seed=0)
+    for k in range(steps):
+        ref.step(global_actions(k % 8, 0, total).numpy())
+    assert (ref.a["last_length"] > 0).mean() > 0.99
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, total, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, gathered, obs, t = q.get(timeout=600)
+        res[r] = (gathered, obs, t)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = ref.a["last_length"].astype(np.float32).tobytes()
+    assert all(res[r][0] == want for r in range(world)), "every rank must hold the unsharded job's returns, in global env order"
+    assert b"".join(res[r][1] for r in range(world)) == ref.a["obs"].tobytes()
+    assert b"".join(res[r][2] for r in range(world)) == ref.a["t"].tobytes()

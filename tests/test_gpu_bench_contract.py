@@ -38,6 +38,16 @@ def test_single_process_line():
     h = d["roofline_hbm_resident"]                      # the same kernel on 2^24 envs: rows stream from HBM
     assert h["envs"] == 1 << 24 and h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / 8000.0) < 1e-9
     assert abs(h["achieved"] - 120 * (1 << 24) / (h["avg_launch_us"] * 1e-6) / 1e9) / h["achieved"] < 1e-6
+    # every BASELINE configuration at the size BASELINE quotes it at, each priced with its own bytes
+    own = d["config"]["baseline_configs_at_own_size"]
+    assert own["C2"]["envs"] == 65536 and own["C3"]["envs"] == 1 << 20 and own["C4"]["envs"] == [1 << 18, 1 << 18]
+    assert "specialised" in own["C4"]["launch"]
+    for tag, by in (("C2", 157), ("C3", 96)):
+        r = own[tag]
+        assert abs(r["frac_of_hbm_peak"] - by * r["envs"] / (r["step_us"] * 1e-6) / 8e12) < 1e-9 and r["rollout_k64_env_steps_per_sec"] > 0
+    assert abs(own["C4"]["frac_of_hbm_peak"] - 210 * (1 << 18) / (own["C4"]["step_us"] * 1e-6) / 8e12) < 1e-9
+    # a single-GPU line carries the gather-inclusive rates too (the "gather" is the local read-out there)
+    assert 0 < d["config"]["value_incl_gather"] <= d["value"]
 
 
 def test_two_ranks_aggregate_line():

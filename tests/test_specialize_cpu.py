@@ -56,15 +56,14 @@ def test_bad_config_is_rejected_not_compiled():
     assert not code.value and size.value == 0
 
 
-def test_group_unit_compiles_for_gfx950():
-    """The heterogeneous launch's specialised unit (nsg_spec_group) for C4's pair of configs: compiles without a GPU."""
+def _build_group(names, expect_rc=0):
     from ns_gym_amd import _lib
     from ns_gym_amd.envs import make
     from ns_gym_amd.spec import build_tunable_params, compile_config
 
     lib = _lib.load()
     cfgs = []
-    for name in ("c4_pendulum_m_inc", "c4_acrobot_mass2_inc", "c3_frozenlake_step50"):
+    for name in names:
         spec = TRAJ_SPECS[name]
         cfgs.append(compile_config(make(spec["env_id"], **spec.get("make_kwargs", {})), build_tunable_params(spec["params"]),
                                    **{**spec["flags"], **spec.get("wrapper_kwargs", {})})[0])
@@ -73,9 +72,17 @@ def test_group_unit_compiles_for_gfx950():
     rc = lib.nsg_spec_build_group(arr, len(cfgs), b"gfx950", C.byref(code), C.byref(size))
     if rc == -95 and b"libhiprtc" in lib.nsg_last_error():
         pytest.skip("libhiprtc.so not available in this environment")
-    assert rc == 0, lib.nsg_last_error().decode()
+    assert rc == expect_rc, lib.nsg_last_error().decode()
+    if rc:
+        return lib.nsg_last_error().decode()
     data = C.string_at(code, size.value)
     lib.nsg_spec_free(code)
+    return data
+
+
+def test_group_unit_compiles_for_gfx950():
+    """The heterogeneous launch's specialised unit (nsg_spec_group) for C4's pair of configs: compiles without a GPU."""
+    data = _build_group(("c4_pendulum_m_inc", "c4_acrobot_mass2_inc", "c3_frozenlake_step50"))
     assert data[:4] == b"\x7fELF" and b"nsg_spec_group" in data
 
 
@@ -98,6 +105,49 @@ def _notes(data):
         name = re.search(r"\.name:\s+(\S+)", blk).group(1)
         res[name] = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|vgpr_spill_count|private_segment_fixed_size):\s+(\d+)", blk)}
     return res
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_no_kernel_of_a_shipped_unit_spills_or_owns_scratch(name):
+    """The spill guard covers EVERY kernel of a unit - nsg_spec_step and nsg_spec_rollout alike (round 2 checked the step
+    kernel only): what nsg_spec_build hands out has no spilled vector register and no scratch segment in any kernel."""
+    notes = _notes(_build(TRAJ_SPECS[name]))
+    assert set(notes) == {"nsg_spec_step", "nsg_spec_rollout"}
+    for kernel, k in notes.items():
+        assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (name, kernel, k)
+
+
+def test_group_unit_does_not_spill_and_a_spilling_one_is_refused(monkeypatch):
+    """Same rule for the heterogeneous launch's unit (nsg_spec_group): C4's pair (+ a FrozenLake member) has no spill; the
+    same unit forced under an 8-wavefront register bound (64 VGPRs: Acrobot's RK4 cannot fit) spills and is REFUSED, so
+    nsg_step_group stays on the generic group kernel instead of launching it."""
+    names = ("c4_pendulum_m_inc", "c4_acrobot_mass2_inc", "c3_frozenlake_step50")
+    for kernel, k in _notes(_build_group(names)).items():
+        assert kernel == "nsg_spec_group" and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+    monkeypatch.setenv("NSG_SPEC_FLAGS", "-DNSG_MIN_WAVES=8")
+    assert "spills" in _build_group(names, expect_rc=-95)
+
+
+def test_a_unit_whose_rollout_or_step_spills_is_refused(monkeypatch):
+    """Random-configuration case 61 (the config whose spilling build returned wrong states on MI355X) under a forced
+    6-wavefront bound: both attempts of spec_compile spill, nsg_spec_build refuses with NSG_EUNSUPPORTED."""
+    import numpy as np
+
+    from ns_gym_amd import _lib
+    from ns_gym_amd.envs import make
+    from ns_gym_amd.spec import build_tunable_params, compile_config
+    from tests.test_gpu_random_configs import _decode, random_spec
+
+    spec = random_spec(np.random.default_rng(10_061))
+    cfg = compile_config(make(spec["env_id"], **spec["make_kwargs"]), build_tunable_params(spec["params"]),
+                         **{**spec["flags"], **_decode(spec), "track_returns": True})[0]
+    lib = _lib.load()
+    monkeypatch.setenv("NSG_SPEC_FLAGS", "-DNSG_MIN_WAVES=6")
+    code, size = C.c_void_p(), C.c_size_t()
+    rc = lib.nsg_spec_build(C.byref(cfg), b"gfx950", C.byref(code), C.byref(size))
+    if rc == -95 and b"libhiprtc" in lib.nsg_last_error():
+        pytest.skip("libhiprtc.so not available in this environment")
+    assert rc == -95 and b"spills" in lib.nsg_last_error() and not code.value
 
 
 def test_no_specialised_step_kernel_spills_vector_registers():

@@ -9,32 +9,16 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from ns_gym_amd import make  # noqa: E402
-from ns_gym_amd.schedulers import ContinuousScheduler, DiscreteScheduler, PeriodicScheduler  # noqa: E402
-from ns_gym_amd.update_functions import DistributionStepWiseUpdate, IncrementUpdate, RandomWalk  # noqa: E402
-from ns_gym_amd.vec_env import VecNSEnv, step_group  # noqa: E402
+from ns_gym_amd.vec_env import step_group  # noqa: E402
 
-# algorithmic bytes per env-step, fp64-internal variants of SURVEY §8(d)
-WORK = {
-    "c1": ("CartPole-v1", lambda: {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)}, {}, 120),
-    "c2": ("CartPole-v1", lambda: {"gravity": RandomWalk(PeriodicScheduler(period=3))}, {}, 157),
-    "c3": ("FrozenLake-v1", lambda: {"P": DistributionStepWiseUpdate(DiscreteScheduler({50}), [[0.6, 0.2, 0.2]])},
-           {"map_name": "8x8"}, 96),
-    "pend": ("Pendulum-v1", lambda: {"m": IncrementUpdate(ContinuousScheduler(), k=0.01)}, {}, 83),
-    "acro": ("Acrobot-v1", lambda: {"LINK_MASS_2": IncrementUpdate(ContinuousScheduler(), k=0.1)}, {}, 127),
-    "mcar": ("MountainCar-v0", lambda: {"force": IncrementUpdate(ContinuousScheduler(), k=1e-6)}, {}, 79),
-    "mcarc": ("MountainCarContinuous-v0", lambda: {"power": IncrementUpdate(ContinuousScheduler(), k=1e-6)}, {}, 79),
-}
+from ns_gym_amd import workloads as W  # noqa: E402
+
+# name -> algorithmic bytes per env-step, fp64-internal variants of SURVEY §8(d) (ns_gym_amd/workloads.py)
+WORK = {k: (v["env_id"], v["params"], v["make_kwargs"], v["bytes_per_env_step"]) for k, v in W.WORKLOADS.items()}
 
 
 def mk(name, n, track=True, spec=False):
-    env_id, tp, mkw, _ = WORK[name]
-    kw = dict(change_notification=True, delta_change_notification=True, track_returns=track)
-    if env_id == "FrozenLake-v1":
-        kw["initial_prob_dist"] = [1.0, 0.0, 0.0]
-    e = VecNSEnv(make(env_id, **mkw), tp(), n, specialize=spec, **kw)
-    e.reset(seed=0)
-    return e
+    return W.build(name, n, track_returns=track, specialize=spec)
 
 
 def actions(e, n):
