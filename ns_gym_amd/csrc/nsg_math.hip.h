@@ -21,6 +21,9 @@
 #ifndef NSG_SINCOS_FMA
 #define NSG_SINCOS_FMA 0
 #endif
+#ifndef NSG_SINCOS_FIRST_ROUND
+#define NSG_SINCOS_FIRST_ROUND 1   // 1: fdlibm's cheap first reduction round where it is accurate enough (per lane), else always the long one
+#endif
 #ifndef NSG_SINCOS_STAGES
 #define NSG_SINCOS_STAGES 3   // pieces of pi/2 the argument reduction subtracts (2 or 3)
 #endif
@@ -52,26 +55,52 @@ NSG_HD void nsg_sincos(double x, double* sn, double* cs) {
     n = 0;
   } else {
     const double r1 = x - fn * pio2_1;  // exact (Sterbenz)
-    const double c2 = -(fn * pio2_2);
-    const double r2 = r1 + c2;
-    const double b2 = r2 - r1;
-    const double e2 = (r1 - (r2 - b2)) + (c2 - b2);
-#if NSG_SINCOS_STAGES == 2
-    // pi/2 = pio2_1 + pio2_2 + pio2_2t to 119 bits: the reduced argument is off by |x| * 2^-119, i.e. by 2^(c-119) of itself
-    // when c leading bits cancel; no double below 2^20 * pi/2 cancels more than ~62 bits against a multiple of pi/2, so the
-    // third piece (fdlibm's third iteration) could only ever move the result by < 2^-57 of itself - 1/16 ulp.
-    const double tail = e2 - fn * pio2_2t;
-    y0 = r2 + tail;
-    y1 = (r2 - y0) + tail;
+#if NSG_SINCOS_FIRST_ROUND
+    // fdlibm's first round: pi/2 ~ pio2_1 + pio2_1t (86 bits).  (y0, y1) is r1 - fl(fn * pio2_1t) as an exact double-double; what
+    // it leaves out - the rounding of the product and of pio2_1t itself - is below |fn| * 1.4e-26, i.e. below 2^-70 of the
+    // reduced argument as long as no more than 16 leading bits cancelled (|y0| >= 2^-16 |x|): 2^-17 ulp on top of the kernels'
+    // own error.  Lanes closer than that to a multiple of pi/2 (one evaluation in ~2^15) take the compensated three-piece
+    // reduction below; the choice is PER LANE (a lane's result never depends on its neighbours), the branch around the long
+    // path is wave-uniform.  11 instructions instead of 25 on the path every Acrobot / Pendulum / MountainCar evaluation takes.
+    const double w1 = fn * pio2_1t;
+    y0 = r1 - w1;
+    y1 = (r1 - y0) - w1;
+    const bool first_round_ok = fabs(y0) * 65536.0 >= fabs(x);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!__all(first_round_ok))
 #else
-    const double c3 = -(fn * pio2_3);
-    const double r3 = r2 + c3;
-    const double b3 = r3 - r2;
-    const double e3 = (r2 - (r3 - b3)) + (c3 - b3);
-    const double tail = (e2 + e3) - fn * pio2_3t;
-    y0 = r3 + tail;
-    y1 = (r3 - y0) + tail;
+    if (!first_round_ok)
 #endif
+#endif
+    {
+      const double c2 = -(fn * pio2_2);
+      const double r2 = r1 + c2;
+      const double b2 = r2 - r1;
+      const double e2 = (r1 - (r2 - b2)) + (c2 - b2);
+#if NSG_SINCOS_STAGES == 2
+      // pi/2 = pio2_1 + pio2_2 + pio2_2t to 119 bits: the reduced argument is off by |x| * 2^-119, i.e. by 2^(c-119) of itself
+      // when c leading bits cancel; no double below 2^20 * pi/2 cancels more than ~62 bits against a multiple of pi/2, so the
+      // third piece (fdlibm's third iteration) could only ever move the result by < 2^-57 of itself - 1/16 ulp.
+      const double tail = e2 - fn * pio2_2t;
+      const double z0 = r2 + tail;
+      const double z1 = (r2 - z0) + tail;
+#else
+      const double c3 = -(fn * pio2_3);
+      const double r3 = r2 + c3;
+      const double b3 = r3 - r2;
+      const double e3 = (r2 - (r3 - b3)) + (c3 - b3);
+      const double tail = (e2 + e3) - fn * pio2_3t;
+      const double z0 = r3 + tail;
+      const double z1 = (r3 - z0) + tail;
+#endif
+#if NSG_SINCOS_FIRST_ROUND
+      y0 = first_round_ok ? y0 : z0;
+      y1 = first_round_ok ? y1 : z1;
+#else
+      y0 = z0;
+      y1 = z1;
+#endif
+    }
     n = (int)fn;
   }
   (void)pio2_1t; (void)pio2_2t; (void)pio2_3; (void)pio2_3t;

@@ -10,7 +10,7 @@ import re
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.environ.get("NSG_SRC_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # NSG_SRC_ROOT: a pinned source tree
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 HEADERS = [("nsgym_hip.h", "include/nsgym_hip.h")] + [(f, f"ns_gym_amd/csrc/{f}") for f in (
     "nsg_math.hip.h", "nsg_rng.hip.h", "nsg_theta.hip.h", "nsg_envs.hip.h", "nsg_kernels.hip.h", "nsg_rollout.hip.h")]
@@ -22,7 +22,7 @@ def hiprtc_build(src: str, extra=()):
     names = (C.c_char_p * len(HEADERS))(*[n.encode() for n, _ in HEADERS])
     texts = (C.c_char_p * len(HEADERS))(*[open(os.path.join(ROOT, p), "rb").read() for _, p in HEADERS])
     assert rtc.hiprtcCreateProgram(C.byref(prog), src.encode(), b"nsg_spec.hip", len(HEADERS), texts, names) == 0
-    opts = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function", "-DNSG_BLOCK=256", *extra]
+    opts = ["--offload-arch=" + os.environ.get("NSG_ARCH", "gfx950"), "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function", "-DNSG_BLOCK=256", *extra]
     arr = (C.c_char_p * len(opts))(*[o.encode() for o in opts])
     rc = rtc.hiprtcCompileProgram(prog, len(opts), arr)
     if rc != 0:
