@@ -118,7 +118,8 @@ enum {
 
 /* per-env status: grid envs keep a byte (buffers.status); classic-control envs keep an episode WORD (buffers.episode):
  * bit 0 = NSG_ST_NEEDS_RESET, bits 1-31 = how many resets the env has drawn from its np_random stream so far (= the index of
- * its next episode in that stream, see buffers.rng_env) */
+ * its next episode in that stream, see buffers.rng_env).  Pendulum never terminates: for a batch that is not a planning copy "needs
+ * reset" IS t >= max_episode_steps, bit 0 of its word stays clear and a single step touches the word only in the lanes that reset */
 #define NSG_ST_NEEDS_RESET 0x1u
 #define NSG_EP_COUNT_SHIFT 1
 /* classic-control env streams: descriptor word 0 of buffers.rng_env (see there) */
@@ -220,7 +221,8 @@ typedef struct nsg_buffers {
                             wrapper's t is preserved (classic_control.py:168-180)              */
   uint8_t* status;       /* [N]    grid envs: NSG_ST_* bits (classic-control envs: NULL, see episode)          */
   int32_t* episode;      /* [N]    classic-control envs: NSG_ST_NEEDS_RESET | resets drawn so far << 1.  A dense row that every
-                            step reads and rewrites; with it the env's np_random needs NO per-env stream state (rng_env)  */
+                            step reads and rewrites (Pendulum: resetting lanes only, see NSG_ST_NEEDS_RESET); with it the env's
+                            np_random needs NO per-env stream state (rng_env)  */
   uint64_t* rng_env;     /* env np_random (gymnasium seeding [UPSTREAM]; PCG64(SeedSequence(seed))).
                             Grid envs draw one uniform per env per step: chunk-blocked state rows [ceil(N/256)][4][256]
                             (state_hi, state_lo, inc_hi, inc_lo).

@@ -25,14 +25,15 @@ template <int ENV> struct EnvTraits;
 #ifndef NSG_CARTPOLE_INLANE   // measurement knob: 1 = CartPole resets in-lane too (no hand-over, no barriers)
 #define NSG_CARTPOLE_INLANE 0
 #endif
-template <> struct EnvTraits<NSG_ENV_CARTPOLE> { static constexpr bool RESET_IN_LANE = NSG_CARTPOLE_INLANE != 0; static constexpr int RESET_DRAWS = 4, PHYS = 4, OBS = 4, NTHETA = 6, NDERIVED = 2; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = 1.f; };
-template <> struct EnvTraits<NSG_ENV_PENDULUM> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 2, NDERIVED = 0, PHYS = 2, OBS = 3, NTHETA = 4; static constexpr bool FLOAT_ACT = true; static constexpr float RETURN_PER_STEP = 0.f; };
-template <> struct EnvTraits<NSG_ENV_ACROBOT> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 4, NDERIVED = 0, PHYS = 4, OBS = 6, NTHETA = 8; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = 0.f; };
-template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 1, NDERIVED = 0, PHYS = 2, OBS = 2, NTHETA = 2; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = -1.f; };
-template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR_CONT> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 1, NDERIVED = 0, PHYS = 2, OBS = 2, NTHETA = 1; static constexpr bool FLOAT_ACT = true; static constexpr float RETURN_PER_STEP = 0.f; };
+template <> struct EnvTraits<NSG_ENV_CARTPOLE> { static constexpr bool RESET_IN_LANE = NSG_CARTPOLE_INLANE != 0; static constexpr int RESET_DRAWS = 4, PHYS = 4, OBS = 4, NTHETA = 6, NDERIVED = 2; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = 1.f; static constexpr bool NEVER_TERMINATES = false; };
+template <> struct EnvTraits<NSG_ENV_PENDULUM> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 2, NDERIVED = 0, PHYS = 2, OBS = 3, NTHETA = 4; static constexpr bool FLOAT_ACT = true; static constexpr float RETURN_PER_STEP = 0.f; static constexpr bool NEVER_TERMINATES = true; };
+template <> struct EnvTraits<NSG_ENV_ACROBOT> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 4, NDERIVED = 0, PHYS = 4, OBS = 6, NTHETA = 8; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = 0.f; static constexpr bool NEVER_TERMINATES = false; };
+template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 1, NDERIVED = 0, PHYS = 2, OBS = 2, NTHETA = 2; static constexpr bool FLOAT_ACT = false; static constexpr float RETURN_PER_STEP = -1.f; static constexpr bool NEVER_TERMINATES = false; };
+template <> struct EnvTraits<NSG_ENV_MOUNTAINCAR_CONT> { static constexpr bool RESET_IN_LANE = true; static constexpr int RESET_DRAWS = 1, NDERIVED = 0, PHYS = 2, OBS = 2, NTHETA = 1; static constexpr bool FLOAT_ACT = true; static constexpr float RETURN_PER_STEP = 0.f; static constexpr bool NEVER_TERMINATES = false; };
 
 // ---- reset draws: np_random.uniform(low, high) = low + (high - low) * next_double ----------
 // EnvTraits::RESET_DRAWS = how many doubles a reset takes from the env's stream (the kernels jump to draw RESET_DRAWS * episode)
+// EnvTraits::NEVER_TERMINATES: the base MDP's step never returns terminated (Pendulum): episodes end by TimeLimit only (step_chunk)
 // EnvTraits::RESET_IN_LANE: how the step kernels run the reset path (seed -> jump-ahead -> draws, ~550 instructions).  CartPole
 // under random actions ends ~5 % of its episodes per step, i.e. 96 % of the wavefronts hold a resetting lane: the resets are
 // compacted per workgroup (two barriers, ONE wavefront runs the path).  The other env types end 0.5-1 % per step (TimeLimit

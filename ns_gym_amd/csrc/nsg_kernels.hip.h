@@ -325,12 +325,25 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
 
   const uint32_t o1 = (uint32_t)i, o4 = o1 * 4u, o8 = o1 * 8u;  // per-lane byte offsets (N <= 2^27)
   const bool track = (cfg.flags & NSG_F_TRACK_RETURNS) != 0;
-  // episode word: bit 0 = needs reset, bits 1-31 = resets this env has drawn from its np_random so far (nsgym_hip.h)
-  const unsigned st = !active ? 0u : io.load ? (unsigned)ldg(b.episode, o4) : ls.st;
   const int t = !active ? 0 : io.load ? ldg(b.t, o4) : ls.t;
-  const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);
-  const bool do_step = active && !do_reset;
   if (sim && io.load && active) ls.tf = ldg(b.t_fork, o4);
+  // episode word: bit 0 = needs reset, bits 1-31 = resets this env has drawn from its np_random so far (nsgym_hip.h).
+  // An env type that never terminates (Pendulum) ends its episodes by TimeLimit alone, so "needs reset" IS t >= max_episode_steps:
+  // its word carries the count only, a single step reads it in the lanes that reset (all of them on the same launch when the
+  // batch was started together, none on the other 199) and rewrites it there - 8 B per env-step less in dense rows.  Planning
+  // copies (TimeLimit counted from the fork; a copy of a finished env must still reset first) keep the stored bit.
+  const bool reset_from_t = T::NEVER_TERMINATES && !sim;
+  unsigned st;
+  bool do_reset;
+  if (reset_from_t) {
+    do_reset = active && cfg.max_episode_steps > 0 && t >= cfg.max_episode_steps;
+    // fused rollouts carry the count in registers from their first step on (its dense load positions the lane's LDS stream)
+    st = !active ? 0u : !io.load ? ls.st : (do_reset || io.lds_rng) ? (unsigned)ldg(b.episode, o4) & ~NSG_ST_NEEDS_RESET : 0u;
+  } else {
+    st = !active ? 0u : io.load ? (unsigned)ldg(b.episode, o4) : ls.st;
+    do_reset = active && (st & NSG_ST_NEEDS_RESET);
+  }
+  const bool do_step = active && !do_reset;
   const bool ld_state = NSG_UNCOND_LOADS ? active : do_step;
   double s[T::PHYS];
 #pragma unroll
@@ -581,7 +594,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   }
 
   // a reset consumed one more episode of the env's stream
-  const unsigned stw = (done ? NSG_ST_NEEDS_RESET : 0u) | (((st >> NSG_EP_COUNT_SHIFT) + (do_reset ? 1u : 0u)) << NSG_EP_COUNT_SHIFT);
+  const unsigned stw = (done && !reset_from_t ? NSG_ST_NEEDS_RESET : 0u) | (((st >> NSG_EP_COUNT_SHIFT) + (do_reset ? 1u : 0u)) << NSG_EP_COUNT_SHIFT);
 #pragma unroll
   for (int k = 0; k < T::PHYS; k++) ls.s[k] = s[k];
   ls.t = tnew;
@@ -603,7 +616,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     stg_out(out.reward, o4, (float)reward);
     stg_out(out.terminated, o1, (uint8_t)(term ? 1 : 0));
     stg_out(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
-    if (io.store) stg(b.episode, o4, (int32_t)stw);
+    if (io.store && (!reset_from_t || do_reset || io.lds_rng)) stg(b.episode, o4, (int32_t)stw);
     if (track) {  // the episode length is the wrapper time t: only the return needs a running row
       if constexpr (kReturnFromT) {
         // one scattered store per finished episode, not two: the return of these env types IS +-length (buffers.last_return is
@@ -1277,8 +1290,12 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
     const int t = sb.t[is];
     db.t[i] = t;
     db.t_fork[i] = t;
+    // a non-sim Pendulum source keeps no needs-reset bit (step_chunk: derived from t); the copy, whose TimeLimit restarts, gets it
+    const bool src_from_t = env == NSG_ENV_PENDULUM && !(cfg.flags & NSG_F_SIM_ENV);
+    const int src_needs_reset = fl ? 0 : src_from_t ? (cfg.max_episode_steps > 0 && t >= cfg.max_episode_steps ? 1 : 0)
+                                                    : (sb.episode[is] & (int32_t)NSG_ST_NEEDS_RESET);
     if (fl) db.status[i] = sb.status[is];
-    else db.episode[i] = sb.episode[is] & (int32_t)NSG_ST_NEEDS_RESET;   // the copy's own stream starts at its first episode
+    else db.episode[i] = src_needs_reset;   // the copy's own stream starts at its first episode
     for (int r = 0; r < (fl ? nd * P : P); r++) {
       const double cur = sb.theta[(int64_t)r * Ns + is];
       const double init = fl ? grid_initial(cfg, r / nd)[r % nd] : cfg.base_theta[cfg.params[r].theta_slot];
@@ -1340,7 +1357,7 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
       if (db.last_return) db.last_return[i] = 0.f;
       db.last_length[i] = 0;
     }
-    const unsigned long long done_mask = __ballot(((fl ? (int)sb.status[is] : sb.episode[is]) & (int)NSG_ST_NEEDS_RESET) != 0);  // == the source's ballot word when N == Ns
+    const unsigned long long done_mask = __ballot(((fl ? (int)sb.status[is] : src_needs_reset) & (int)NSG_ST_NEEDS_RESET) != 0);  // == the source's ballot word when N == Ns
     if (db.done_bits && (i & 63) == 0) db.done_bits[i >> 6] = done_mask;
   }
 }

@@ -21,6 +21,9 @@
 #ifndef NSG_SINCOS_FMA
 #define NSG_SINCOS_FMA 0
 #endif
+#ifndef NSG_SINCOS_SHORTCUT
+#define NSG_SINCOS_SHORTCUT 1      // 1: wave-uniform test for "no lane needs a reduction" (CartPole's pole angle) ahead of everything else
+#endif
 #ifndef NSG_SINCOS_FIRST_ROUND
 #define NSG_SINCOS_FIRST_ROUND 1   // 1: fdlibm's cheap first reduction round where it is accurate enough (per lane), else always the long one
 #endif
@@ -42,7 +45,9 @@ NSG_HD void nsg_sincos(double x, double* sn, double* cs) {
   // fdlibm's first branch (|x| <= π/4: no reduction), taken when it holds for EVERY lane of the
   // wavefront so the branch is uniform.  CartPole's pole angle never leaves it while an episode runs.
   // With fn == 0 the general path below yields y0 = x, y1 = 0, n = 0 exactly, so both paths agree bit for bit.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if !NSG_SINCOS_SHORTCUT
+  const bool no_reduction = false;
+#elif defined(__HIP_DEVICE_COMPILE__)
   const bool no_reduction = __all(fn == 0.0);
 #else
   const bool no_reduction = fn == 0.0;

@@ -191,6 +191,8 @@ class VecNSEnv:
         if seed is not None:
             if np.isscalar(seed):
                 base = int(seed)
+                if base < 0:   # np.random.default_rng(-1) raises; a wrapped 2^64 - 1 would be a different stream, silently
+                    raise ValueError(f"seed must be a non-negative integer (got {base})")
             else:
                 s = np.asarray(seed, dtype=np.uint64)
                 assert s.shape == (self.N,), "seed sequence must have one entry per env"
@@ -517,7 +519,7 @@ class VecNSEnv:
         deliberately re-seeds the streams: base.py:433-441.)  A restored batch continues bit for bit."""
         arena = self._arena.cpu() if to_cpu else self._arena.clone()
         return {"arena": arena, "signature": self._signature(), "has_reset": self.has_reset, "frozen": self.frozen,
-                "viol_seen": self._viol_seen}
+                "viol_seen": self._viol_seen, "err_seen": list(self._err_seen)}
 
     def load_state_dict(self, sd: dict):
         """Restore a `state_dict()` taken from a batch with the same configuration and size."""
@@ -527,6 +529,13 @@ class VecNSEnv:
             raise ValueError("load_state_dict: buffer size mismatch")
         self._arena.copy_(sd["arena"].to(self.device, non_blocking=False))
         self.has_reset, self.frozen, self._viol_seen = bool(sd["has_reset"]), bool(sd["frozen"]), int(sd["viol_seen"])
+        # the arena carries the raised-condition counters: what this object has already reported must follow them (a checkpoint
+        # from before "err_seen" existed: re-baseline on the restored counters, i.e. nothing old is raised again)
+        if "err_seen" in sd:
+            self._err_seen = [int(x) for x in sd["err_seen"]]
+        else:
+            c = self.counters()
+            self._err_seen = [c["lc_exhausted"], c["scheduler_overruns"]]
         return self
 
     def freeze(self, mode: bool = True):
