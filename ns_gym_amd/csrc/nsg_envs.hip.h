@@ -18,6 +18,21 @@ namespace nsg {
 
 #define NSG_PI 3.141592653589793238462643383279502884
 
+// Polynomial form of each env type's sincos (nsg_math.hip.h, nsg_sincos_t<POLY>).  Acrobot is bound by float64 vector-ALU issue
+// (15 sincos per step): the fused form with SGPR addends (2) takes its step from 59.6 to 55.0 us at 2^20 envs, its fused rollout
+// from 50.4 to 44.6 us per step, C4's mixed launch from 23.4 to 21.7 us, at unchanged occupancy.  Pendulum and the MountainCars
+// gain 1-3 %.  CartPole keeps fdlibm's form as written (0): its kernels sit on the 80-VGPR / 6-wavefront boundary the launch policy
+// is built on, the fused form costs them 4 VGPRs (the generic fused rollout would spill) and buys 0.7 %.
+#ifndef NSG_ACROBOT_SINCOS_POLY
+#define NSG_ACROBOT_SINCOS_POLY 2
+#endif
+#ifndef NSG_LIGHT_SINCOS_POLY
+#define NSG_LIGHT_SINCOS_POLY 2     // Pendulum, MountainCar, MountainCarContinuous
+#endif
+constexpr int kAcroPoly = NSG_ACROBOT_SINCOS_POLY;
+constexpr int kLightPoly = NSG_LIGHT_SINCOS_POLY;
+
+
 template <int ENV> struct EnvTraits;
 // RETURN_PER_STEP: env types whose reward is the same constant on EVERY step (CartPole-v1: 1.0 incl. the terminating
 // step; MountainCar-v0: -1.0) - their episode return is RETURN_PER_STEP * t exactly (float32 sums of +-1 are exact far
@@ -68,12 +83,12 @@ template <int ENV> __device__ __forceinline__ void env_obs(const double* s, floa
     for (int k = 0; k < 4; k++) o[k] = (float)s[k];
   } else if constexpr (ENV == NSG_ENV_PENDULUM) {
     double sn, cs;
-    nsg_sincos(s[0], &sn, &cs);
+    nsg_sincos_t<kLightPoly>(s[0], &sn, &cs);
     o[0] = (float)cs; o[1] = (float)sn; o[2] = (float)s[1];
   } else if constexpr (ENV == NSG_ENV_ACROBOT) {
     double s0, c0, s1, c1;
-    nsg_sincos(s[0], &s0, &c0);
-    nsg_sincos(s[1], &s1, &c1);
+    nsg_sincos_t<kAcroPoly>(s[0], &s0, &c0);
+    nsg_sincos_t<kAcroPoly>(s[1], &s1, &c1);
     o[0] = (float)c0; o[1] = (float)s0; o[2] = (float)c1; o[3] = (float)s1; o[4] = (float)s[2]; o[5] = (float)s[3];
   } else {
     o[0] = (float)s[0]; o[1] = (float)s[1];
@@ -128,12 +143,12 @@ __device__ __forceinline__ void acrobot_dsdt(const double* th, const double* y, 
   const double m1 = th[3], m2 = th[4], l1 = th[1], lc1 = th[5], lc2 = th[6], I1 = th[7], I2 = th[7], g = 9.8;
   const double theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
   double sin2, cos2;
-  nsg_sincos(theta2, &sin2, &cos2);
+  nsg_sincos_t<kAcroPoly>(theta2, &sin2, &cos2);
   double d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * cos2) + I1 + I2;
   double d2 = m2 * (lc2 * lc2 + l1 * lc2 * cos2) + I2;
-  double phi2 = m2 * lc2 * g * nsg_cos(theta1 + theta2 - NSG_PI / 2.0);
+  double phi2 = m2 * lc2 * g * nsg_cos_t<kAcroPoly>(theta1 + theta2 - NSG_PI / 2.0);
   double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * sin2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * sin2 +
-                (m1 * lc1 + m2 * l1) * g * nsg_cos(theta1 - NSG_PI / 2) + phi2;
+                (m1 * lc1 + m2 * l1) * g * nsg_cos_t<kAcroPoly>(theta1 - NSG_PI / 2) + phi2;
   double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * sin2 - phi2) /
                     (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
   double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
@@ -172,7 +187,7 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
     if (u > 2.0) u = 2.0;
     const double an = nsg_pymod_pos(t0 + NSG_PI, 2 * NSG_PI) - NSG_PI;  // angle_normalize: ((x + pi) % (2 pi)) - pi [UPSTREAM]
     double costs = an * an + 0.1 * (thdot * thdot) + 0.001 * (u * u);
-    double newthdot = thdot + (3 * g / (2 * l) * nsg_sin(t0) + 3.0 / (m * (l * l)) * u) * dt;
+    double newthdot = thdot + (3 * g / (2 * l) * nsg_sin_t<kLightPoly>(t0) + 3.0 / (m * (l * l)) * u) * dt;
     if (newthdot < -8.0) newthdot = -8.0;
     if (newthdot > 8.0) newthdot = 8.0;
     double newth = t0 + newthdot * dt;
@@ -207,12 +222,12 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
     ns[3] = fmin(fmax(ns[3], -mv2), mv2);
 #pragma unroll
     for (int k = 0; k < 4; k++) s[k] = ns[k];
-    bool term = (-nsg_cos(s[0]) - nsg_cos(s[1] + s[0])) > 1.0;
+    bool term = (-nsg_cos_t<kAcroPoly>(s[0]) - nsg_cos_t<kAcroPoly>(s[1] + s[0])) > 1.0;
     reward = term ? 0.0 : -1.0;
     return term;
   } else if constexpr (ENV == NSG_ENV_MOUNTAINCAR) {
     double position = s[0], velocity = s[1];
-    velocity += (double)(ai - 1) * th[1] + nsg_cos(3 * position) * (-th[0]);
+    velocity += (double)(ai - 1) * th[1] + nsg_cos_t<kLightPoly>(3 * position) * (-th[0]);
     if (velocity < -0.07) velocity = -0.07;
     if (velocity > 0.07) velocity = 0.07;
     position += velocity;
@@ -226,7 +241,7 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
     double position = s[0], velocity = s[1];
     double a0 = (double)af;
     double force = fmin(fmax(a0, -1.0), 1.0);
-    velocity += force * th[0] - 0.0025 * nsg_cos(3 * position);
+    velocity += force * th[0] - 0.0025 * nsg_cos_t<kLightPoly>(3 * position);
     if (velocity > 0.07) velocity = 0.07;
     if (velocity < -0.07) velocity = -0.07;
     position += velocity;

@@ -19,7 +19,7 @@
 #endif
 
 #ifndef NSG_SINCOS_FMA
-#define NSG_SINCOS_FMA 0
+#define NSG_SINCOS_FMA 0           // polynomial form of plain nsg_sincos (nsg_sincos_t<POLY>): 0 fdlibm as written, 1 compiler-fused, 2 SGPR-addend fma
 #endif
 #ifndef NSG_SINCOS_SHORTCUT
 #define NSG_SINCOS_SHORTCUT 1      // 1: wave-uniform test for "no lane needs a reduction" (CartPole's pole angle) ahead of everything else
@@ -33,7 +33,22 @@
 
 namespace nsg {
 
-NSG_HD void nsg_sincos(double x, double* sn, double* cs) {
+// fma(a, b, C) with C a literal coefficient.  Device, mode 2: ONE VOP3 v_fma_f64 whose addend is an SGPR pair.  (Left to itself the
+// compiler turns a Horner step with a constant addend into the two-address v_fmac_f64, which wants the coefficient in the
+// destination VGPR pair: it parks all eleven coefficients in VGPRs - +18-29 VGPRs, a wavefront of occupancy - or re-copies them.)
+NSG_HD double nsg_fma_coef(double a, double b, double coef) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(coef));
+  return r;
+#else
+  return __builtin_fma(a, b, coef);
+#endif
+}
+
+// POLY: 0 = fdlibm's kernels as written (a rounding after every multiply and every add), 1 = Horner steps fused by the compiler
+// (__builtin_fma), 2 = fused through nsg_fma_coef.  1 and 2 give the same values; all three are < 1 ulp (tests/test_math_cpu.py).
+template <int POLY> NSG_HD void nsg_sincos_t(double x, double* sn, double* cs) {
   const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
                pio2_1t = 6.07710050650619224932e-11, pio2_2 = 6.07710050630396597660e-11,
                pio2_2t = 2.02226624879595063154e-21, pio2_3 = 2.02226624871116645580e-21,
@@ -116,23 +131,31 @@ NSG_HD void nsg_sincos(double x, double* sn, double* cs) {
                C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
   const double z = y0 * y0;
   const double v = z * y0;
-#if NSG_SINCOS_FMA
-  // the same polynomials, Horner steps fused (one rounding per step instead of two: never less accurate); the two
-  // kernels together are 17 instructions instead of 35
-  const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2);
-  const double s = y0 - __builtin_fma(-v, S1, __builtin_fma(z, __builtin_fma(-v, rs, 0.5 * y1), -y1));
-  const double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
-  const double hz = 0.5 * z;
-  const double wc = 1.0 - hz;
-  const double c = wc + (((1.0 - wc) - hz) + __builtin_fma(z, rc, -(y0 * y1)));
-#else
-  const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-  const double s = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
-  const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
-  const double hz = 0.5 * z;
-  const double wc = 1.0 - hz;
-  const double c = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
-#endif
+  double s, c;
+  if constexpr (POLY == 1) {
+    // the same polynomials, Horner steps fused (one rounding per step instead of two: never less accurate); the two
+    // kernels together are 17 instructions instead of 35
+    const double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2);
+    s = y0 - __builtin_fma(-v, S1, __builtin_fma(z, __builtin_fma(-v, rs, 0.5 * y1), -y1));
+    const double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
+    const double hz = 0.5 * z;
+    const double wc = 1.0 - hz;
+    c = wc + (((1.0 - wc) - hz) + __builtin_fma(z, rc, -(y0 * y1)));
+  } else if constexpr (POLY == 2) {
+    const double rs = nsg_fma_coef(z, nsg_fma_coef(z, nsg_fma_coef(z, nsg_fma_coef(z, S6, S5), S4), S3), S2);
+    s = y0 - __builtin_fma(-v, S1, __builtin_fma(z, __builtin_fma(-v, rs, 0.5 * y1), -y1));
+    const double rc = z * nsg_fma_coef(z, nsg_fma_coef(z, nsg_fma_coef(z, nsg_fma_coef(z, nsg_fma_coef(z, C6, C5), C4), C3), C2), C1);
+    const double hz = 0.5 * z;
+    const double wc = 1.0 - hz;
+    c = wc + (((1.0 - wc) - hz) + __builtin_fma(z, rc, -(y0 * y1)));
+  } else {
+    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    s = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double hz = 0.5 * z;
+    const double wc = 1.0 - hz;
+    c = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+  }
   switch (n & 3) {
     case 0: *sn = s; *cs = c; break;
     case 1: *sn = c; *cs = -s; break;
@@ -154,8 +177,11 @@ NSG_HD double nsg_pymod_pos(double x, double m) {
   return r;
 }
 
+NSG_HD void nsg_sincos(double x, double* sn, double* cs) { nsg_sincos_t<NSG_SINCOS_FMA>(x, sn, cs); }
 NSG_HD double nsg_sin(double x) { double s, c; nsg_sincos(x, &s, &c); return s; }
 NSG_HD double nsg_cos(double x) { double s, c; nsg_sincos(x, &s, &c); return c; }
+template <int POLY> NSG_HD double nsg_cos_t(double x) { double s, c; nsg_sincos_t<POLY>(x, &s, &c); return c; }
+template <int POLY> NSG_HD double nsg_sin_t(double x) { double s, c; nsg_sincos_t<POLY>(x, &s, &c); return s; }
 
 }  // namespace nsg
 

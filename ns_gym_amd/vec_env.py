@@ -33,6 +33,10 @@ class ConstraintViolationWarning(Warning):
     (ns_gym/wrappers/classic_control.py:9-12)."""
 
 
+class SpecializationUnavailableWarning(RuntimeWarning):
+    """A batch large enough to be specialised by default fell back to the generic kernels (no runtime compiler)."""
+
+
 _AUTO_SPECIALIZE_MIN_ENVS = 1 << 16   # below this a launch is latency-bound and the compile is not worth a second
 
 
@@ -115,9 +119,14 @@ class VecNSEnv:
             if specialize or (specialize is None and self.N >= _AUTO_SPECIALIZE_MIN_ENVS):
                 try:
                     self.specialize()
-                except _lib.NsgError:
+                except _lib.NsgError as e:
                     if specialize:   # asked for explicitly
                         raise
+                    # a large batch on the precompiled generic kernels: correct, but 10-35 % slower than the numbers this
+                    # package quotes (they read the configuration through scalar loads and spill SGPRs doing so)
+                    warnings.warn(f"config-specialised kernels are not available ({e}); this batch of {self.N} envs runs on the "
+                                  f"precompiled generic kernels, 10-35 % slower per step (libhiprtc.so is needed for nsg_specialize)",
+                                  SpecializationUnavailableWarning, stacklevel=2)
         self._make_views()
         self._spaces = None   # built on first use: planning copies are made per simulation and rarely look at them
         self._zero_flags = None

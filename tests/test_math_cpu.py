@@ -15,6 +15,9 @@ SRC = r'''
 #include "%s/ns_gym_amd/csrc/nsg_math.hip.h"
 extern "C" {
 void t_sincos(const double* x, double* s, double* c, long n) { for (long i = 0; i < n; i++) nsg::nsg_sincos(x[i], s + i, c + i); }
+void t_sincos_poly0(const double* x, double* s, double* c, long n) { for (long i = 0; i < n; i++) nsg::nsg_sincos_t<0>(x[i], s + i, c + i); }
+void t_sincos_poly1(const double* x, double* s, double* c, long n) { for (long i = 0; i < n; i++) nsg::nsg_sincos_t<1>(x[i], s + i, c + i); }
+void t_sincos_poly2(const double* x, double* s, double* c, long n) { for (long i = 0; i < n; i++) nsg::nsg_sincos_t<2>(x[i], s + i, c + i); }
 void t_pymod(const double* x, double m, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_pymod_pos(x[i], m); }
 void t_exp(const double* x, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_exp(x[i]); }
 void t_log1p(const double* x, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_log1p(x[i]); }
@@ -54,9 +57,13 @@ def test_sincos_within_one_ulp(m):
     rel = 2.0 ** -np.arange(8, 30)[None, :, None] * np.array([1.0, -1.0, 0.7, -1.3])[None, None, :]
     edge = (kk * (1.0 + rel)).ravel()
     for x in xs + [near, edge]:
-        s, c = _call(m.t_sincos, x, 2)
         xl = x.astype(np.longdouble)
-        assert _ulps(s, np.sin(xl)) <= 1.0 and _ulps(c, np.cos(xl)) <= 1.0
+        got = {}
+        for fn in ("t_sincos", "t_sincos_poly0", "t_sincos_poly1", "t_sincos_poly2"):   # the default and every polynomial form
+            s, c = got[fn] = _call(getattr(m, fn), x, 2)
+            assert _ulps(s, np.sin(xl)) <= 1.0 and _ulps(c, np.cos(xl)) <= 1.0, fn
+        # compiler-fused and SGPR-addend forms are the same arithmetic (on the host both are __builtin_fma)
+        assert np.array_equal(got["t_sincos_poly1"][0], got["t_sincos_poly2"][0]) and np.array_equal(got["t_sincos_poly1"][1], got["t_sincos_poly2"][1])
 
 
 def test_exp_and_log1p_within_one_ulp(m):
