@@ -503,7 +503,8 @@ def _pmc_traffic(n_envs):
     try:
         with open(p) as f:
             doc = json.load(f)
-            key = "r02_step_kernel_cartpole_specialised_2p20" if "r02_step_kernel_cartpole_specialised_2p20" in doc else "step_kernel_cartpole_specialised"
+            key = next(k for k in ("r03_step_kernel_cartpole_specialised_2p20", "r02_step_kernel_cartpole_specialised_2p20",
+                                   "step_kernel_cartpole_specialised") if k in doc)
             return doc[key]["bytes_per_env_step"] * n_envs
     except Exception:
         return None

@@ -945,8 +945,14 @@ __device__ __forceinline__ void step_body(const nsg_config& cfg, const Segment& 
   flush_counts(b.counters, block_rel, wc);
 }
 
+// The precompiled full-engine step kernels sit just above the 128-VGPR line (130 for CartPole and Pendulum with the two-level sincos
+// reduction; 3 wavefronts per SIMD instead of 4: C2 on the generic kernels 44.5 -> 53.4 us at 2^20 envs): they are held at 4 wavefronts
+// per SIMD, which the compiler meets without spilling (csrc/resource_usage.txt, tests/test_generic_kernel_resources.py).  Acrobot's
+// full engine (154 VGPRs) cannot and keeps its natural count.
+template <int ENV, bool FULL> constexpr int kStepMinWaves = (FULL && ENV != NSG_ENV_ACROBOT && NSG_MIN_WAVES < 4) ? 4 : NSG_MIN_WAVES;
+
 template <int ENV, bool FULL>
-__global__ __launch_bounds__(kBlock, NSG_MIN_WAVES) void step_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions, int reverse) {
+__global__ __launch_bounds__(kBlock, (kStepMinWaves<ENV, FULL>)) void step_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions, int reverse) {
   step_body<ENV, FULL>(seg->cfg, *seg, actions, (int)blockIdx.x, (int)gridDim.x, reverse);
 }
 
