@@ -43,6 +43,9 @@ constexpr int kCntShards = NSG_CNT_SHARDS;
 #ifndef NSG_MIN_WAVES
 #define NSG_MIN_WAVES 1
 #endif
+#ifndef NSG_TABLES_DIRECT
+#define NSG_TABLES_DIRECT 0   // 1: constant tables are read from their global copies, not staged in LDS (stage_tables)
+#endif
 
 
 // Device-resident description of one homogeneous env segment (read through scalar loads).
@@ -108,6 +111,14 @@ static_assert(kBlock != 256 || lds_bytes_for(kMaxTableBytes, 1, 1) + kLdsStreamB
 static_assert(kBlock != 256 || lds_bytes_for(256, 1, 0) + kLdsStreamBytes * 2 <= 160 * 1024 / 5, "LDS per workgroup of the C2-shaped rollout");
 
 // Cooperative staging of the constant tables into LDS (once per workgroup).
+// DIRECT (single-step launches of a specialised unit whose config has no table blob, NSG_TABLES_DIRECT): nothing is staged.  A
+// launch of up to 1536 chunks runs one chunk per workgroup, i.e. it would stage the ziggurat tables - a global-load round trip,
+// the LDS writes and a barrier ahead of everything else - for 256 env-steps each, of which a third (C2) or none (C1) draws a
+// normal at all; the few lookups read the tables' global copies (6 KB, cache-resident after the first launch) instead.  Measured
+// (profiles/r03_ab_runs.txt): C2 at 65 536 envs 7.23 -> 6.88 us, at 2^18 12.1 -> 11.4, at 2^20 33.05 -> 32.44; C1 at 65 536 envs 5.42 ->
+// 5.20 (no barrier left in the kernel).  Not for the grid envs, whose map is looked up by every lane on every step (C3 +10-15 %),
+// nor for configs with schedule / value tables, nor for fused rollouts (K steps of lookups per launch).
+template <bool DIRECT = false, bool HANDOVER = true>
 __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, Tables& tb, ZigLds& zg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char nsg_dyn_lds[];
   unsigned char* base = nsg_dyn_lds;
@@ -119,6 +130,25 @@ __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, 
   lds.streams = (uint64_t*)(base + lds_bytes_for(sg.table_bytes, sg.uses_normal, sg.uses_exp));  // valid when the launch reserved it (fused rollouts)
   lds.ustreams = lds.streams + kBlock * 4;
   const int tid = threadIdx.x;
+  if constexpr (DIRECT) {
+    if constexpr (HANDOVER) {   // only the reset hand-over's queue counters still live in LDS
+      if (tid == 0) lds.reset_n[0] = lds.reset_n[1] = 0;
+      __syncthreads();
+    }
+    tb.base = sg.tables;
+    zg.ki = sg.zig;
+    zg.wi = (const double*)(sg.zig + 256);
+    zg.fi = (const double*)(sg.zig + 512);
+    zg.ke = sg.zig + 768;
+    zg.we = (const double*)(sg.zig + 1024);
+    zg.fe = (const double*)(sg.zig + 1280);
+    zg.jump = sg.jump;
+    if (sg.cfg.env_type <= NSG_ENV_MOUNTAINCAR_CONT && sg.buf.rng_env) {
+      zg.sd0 = sg.buf.rng_env[0];
+      zg.sd1 = sg.buf.rng_env[1];
+    }
+    return;
+  }
   uint64_t* zexp = lds.zig + (sg.uses_normal ? 768 : 0);
   if (sg.uses_normal) {
     for (int k = tid; k < 768; k += kBlock) lds.zig[k] = sg.zig[k];
@@ -922,7 +952,9 @@ __device__ __forceinline__ void step_body(const nsg_config& cfg, const Segment& 
   LdsTables lds;
   Tables tb;
   ZigLds zg;
-  stage_tables(sg, lds, tb, zg);
+  constexpr bool kGrid = ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE;
+  if constexpr (NSG_TABLES_DIRECT != 0 && !kGrid) stage_tables<true, !EnvTraits<kGrid ? NSG_ENV_CARTPOLE : ENV>::RESET_IN_LANE>(sg, lds, tb, zg);
+  else stage_tables(sg, lds, tb, zg);
   WaveCounts wc;
   const nsg_buffers& b = sg.buf;
   const int64_t N = sg.N;

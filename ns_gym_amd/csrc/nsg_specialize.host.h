@@ -82,7 +82,16 @@ inline const Rtc* rtc() {
 // ---- the specialised translation unit ----------------------------------------------------------
 // The config is emitted as its raw 64-bit words (independent of the struct's field list) and viewed
 // as nsg_config; after inlining every access is a load from a constant at a constant offset.
-constexpr const char* kGeneratorRev = "spec_source r3.0";   // part of the cache key (nsgym_hip.hip: spec_source_hash)
+constexpr const char* kGeneratorRev = "spec_source r3.1";   // part of the cache key (nsgym_hip.hip: spec_source_hash)
+// Does the config look anything up in the constant-table blob (schedule bit tables, value lists, grid maps)?
+inline bool cfg_uses_table_blob(const nsg_config& cfg) {
+  if (cfg.env_type == NSG_ENV_FROZENLAKE || cfg.env_type == NSG_ENV_CLIFFWALKING || cfg.env_type == NSG_ENV_BRIDGE) return true;
+  for (int p = 0; p < cfg.n_params; p++) {
+    const nsg_param_cfg& pc = cfg.params[p];
+    if (pc.sched_kind == NSG_SCHED_TABLE || pc.val_tab_len > 0) return true;
+  }
+  return false;
+}
 inline std::string spec_source(const nsg_config& cfg, bool full, bool resets_in_lane = false, bool six_waves = true) {
   static_assert(sizeof(nsg_config) % 8 == 0, "nsg_config is emitted as 64-bit words");
   std::string s;
@@ -93,6 +102,9 @@ inline std::string spec_source(const nsg_config& cfg, bool full, bool resets_in_
       "typedef unsigned long size_t;\n"
       "#define NSG_SPEC_BUILD 1\n";
   if (resets_in_lane) s += "#define NSG_CARTPOLE_INLANE 1\n";   // batch-size policy of nsg_specialize (nsg_envs.hip.h)
+  // a classic-control config without a table blob (no schedule bit table, no value list): the step kernel reads the ziggurat tables
+  // where they are instead of staging them per workgroup (nsg_kernels.hip.h: stage_tables<DIRECT>)
+  if (!cfg_uses_table_blob(cfg)) s += "#ifndef NSG_TABLES_DIRECT\n#define NSG_TABLES_DIRECT 1\n#endif\n";
   // CartPole's step is asked to keep 6 wavefronts per SIMD (<= 80 VGPRs): the launch policy (step_grid_for: 6 workgroups per
   // CU, all resident from the start) is built on it, and at 81 VGPRs the same kernel is 8 % slower (C1 2^20 envs: 23.9 ->
   // 26.3 us).  The compiler meets the bound without spilling for the usual configs (C1 69, C2 75 VGPRs); a config for which
