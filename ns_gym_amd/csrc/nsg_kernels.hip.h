@@ -143,10 +143,13 @@ __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, 
     zg.we = (const double*)(sg.zig + 1024);
     zg.fe = (const double*)(sg.zig + 1280);
     zg.jump = sg.jump;
-    if (sg.cfg.env_type <= NSG_ENV_MOUNTAINCAR_CONT && sg.buf.rng_env) {
-      zg.sd0 = sg.buf.rng_env[0];
-      zg.sd1 = sg.buf.rng_env[1];
-    }
+    // the batch's stream descriptor: two uniform words that no launch of this kernel writes - read through the scalar cache, and
+    // without the env-type / bound-handle tests of the general path (DIRECT is a bound classic-control step launch by construction),
+    // each of which would be one more dependent memory round trip ahead of the first row load
+    typedef const __attribute__((address_space(4))) uint64_t* scalar_words;
+    scalar_words d = (scalar_words)sg.buf.rng_env;
+    zg.sd0 = d[0];
+    zg.sd1 = d[1];
     return;
   }
   uint64_t* zexp = lds.zig + (sg.uses_normal ? 768 : 0);
@@ -952,12 +955,12 @@ __device__ __forceinline__ void step_body(const nsg_config& cfg, const Segment& 
   LdsTables lds;
   Tables tb;
   ZigLds zg;
+  const int64_t N = sg.N;   // asked for before the staging, so that it travels with the first batch of scalar loads
   constexpr bool kGrid = ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE;
   if constexpr (NSG_TABLES_DIRECT != 0 && !kGrid) stage_tables<true, !EnvTraits<kGrid ? NSG_ENV_CARTPOLE : ENV>::RESET_IN_LANE>(sg, lds, tb, zg);
   else stage_tables(sg, lds, tb, zg);
   WaveCounts wc;
   const nsg_buffers& b = sg.buf;
-  const int64_t N = sg.N;
   const StepOut out = default_out(b);
   const int64_t chunks = (N + kBlock - 1) / kBlock;
   int parity = 0;

@@ -154,7 +154,7 @@ uint64_t spec_source_hash() {
   if (nsg_spec::allow_spill()) h1 = nsg_spec::fnv1a("allow-spill", 11, h1);              // a diagnostic build never shares a cache entry
   // so are the fixed options of nsg_spec::compile_source (keep this literal in step with them) and the toolchain the
   // library was built with: code objects persist on disk between processes (spec_cache_dir)
-  static const char kFixed[] = "-O3 -std=c++17 -ffp-contract=off -Wno-unused-function block " NSG_STR(NSG_BLOCK) " hip " HIP_VERSION_STR;
+  static const char kFixed[] = "-O3 -std=c++17 -ffp-contract=off -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=4 block " NSG_STR(NSG_BLOCK) " hip " HIP_VERSION_STR;
   h1 = nsg_spec::fnv1a(kFixed, sizeof(kFixed), h1);
   // and the text spec_source() wraps around the headers (launch bounds, per-env-type defines): bump when it changes
   h1 = nsg_spec::fnv1a(nsg_spec::kGeneratorRev, strlen(nsg_spec::kGeneratorRev), h1);
