@@ -118,7 +118,10 @@ static_assert(kBlock != 256 || lds_bytes_for(256, 1, 0) + kLdsStreamBytes * 2 <=
 // (profiles/r03_ab_runs.txt): C2 at 65 536 envs 7.23 -> 6.88 us, at 2^18 12.1 -> 11.4, at 2^20 33.05 -> 32.44; C1 at 65 536 envs 5.42 ->
 // 5.20 (no barrier left in the kernel).  Not for the grid envs, whose map is looked up by every lane on every step (C3 +10-15 %),
 // nor for configs with schedule / value tables, nor for fused rollouts (K steps of lookups per launch).
-template <bool DIRECT = false, bool HANDOVER = true>
+// KIND: what the caller knows about the segment at compile time - 0 nothing (nsg_theta_trace on an unbound handle: run-time tests),
+// 1 a bound classic-control batch (its stream descriptor is fetched through the scalar cache, no dependent tests), 2 a grid env
+// (no descriptor).
+template <bool DIRECT = false, bool HANDOVER = true, int KIND = 0>
 __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, Tables& tb, ZigLds& zg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char nsg_dyn_lds[];
   unsigned char* base = nsg_dyn_lds;
@@ -172,9 +175,16 @@ __device__ __forceinline__ void stage_tables(const Segment& sg, LdsTables& lds, 
   zg.we = (const double*)(zexp + 256);
   zg.fe = (const double*)(zexp + 512);
   zg.jump = sg.jump;
-  if (sg.cfg.env_type <= NSG_ENV_MOUNTAINCAR_CONT && sg.buf.rng_env) {  // classic-control env types; unbound handles (nsg_theta_trace) have no rows
-    zg.sd0 = sg.buf.rng_env[0];
-    zg.sd1 = sg.buf.rng_env[1];
+  if constexpr (KIND == 1) {
+    typedef const __attribute__((address_space(4))) uint64_t* scalar_words;
+    scalar_words d = (scalar_words)sg.buf.rng_env;
+    zg.sd0 = d[0];
+    zg.sd1 = d[1];
+  } else if constexpr (KIND == 0) {
+    if (sg.cfg.env_type <= NSG_ENV_MOUNTAINCAR_CONT && sg.buf.rng_env) {  // classic-control env types; unbound handles (nsg_theta_trace) have no rows
+      zg.sd0 = sg.buf.rng_env[0];
+      zg.sd1 = sg.buf.rng_env[1];
+    }
   }
 }
 
@@ -957,8 +967,8 @@ __device__ __forceinline__ void step_body(const nsg_config& cfg, const Segment& 
   ZigLds zg;
   const int64_t N = sg.N;   // asked for before the staging, so that it travels with the first batch of scalar loads
   constexpr bool kGrid = ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE;
-  if constexpr (NSG_TABLES_DIRECT != 0 && !kGrid) stage_tables<true, !EnvTraits<kGrid ? NSG_ENV_CARTPOLE : ENV>::RESET_IN_LANE>(sg, lds, tb, zg);
-  else stage_tables(sg, lds, tb, zg);
+  if constexpr (NSG_TABLES_DIRECT != 0 && !kGrid) stage_tables<true, !EnvTraits<kGrid ? NSG_ENV_CARTPOLE : ENV>::RESET_IN_LANE, 1>(sg, lds, tb, zg);
+  else stage_tables<false, true, kGrid ? 2 : 1>(sg, lds, tb, zg);
   WaveCounts wc;
   const nsg_buffers& b = sg.buf;
   const StepOut out = default_out(b);

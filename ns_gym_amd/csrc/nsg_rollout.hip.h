@@ -18,7 +18,8 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
   LdsTables lds;
   Tables tb;
   ZigLds zg;
-  stage_tables(sg, lds, tb, zg);
+  constexpr bool GRID_ENV = ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE;
+  stage_tables<false, true, GRID_ENV ? 2 : 1>(sg, lds, tb, zg);
   WaveCounts wc;
   const nsg_buffers& b = sg.buf;
   const int64_t N = sg.N;

@@ -82,7 +82,7 @@ inline const Rtc* rtc() {
 // ---- the specialised translation unit ----------------------------------------------------------
 // The config is emitted as its raw 64-bit words (independent of the struct's field list) and viewed
 // as nsg_config; after inlining every access is a load from a constant at a constant offset.
-constexpr const char* kGeneratorRev = "spec_source r3.1";   // part of the cache key (nsgym_hip.hip: spec_source_hash)
+constexpr const char* kGeneratorRev = "spec_source r3.2";   // part of the cache key (nsgym_hip.hip: spec_source_hash)
 // Does the config look anything up in the constant-table blob (schedule bit tables, value lists, grid maps)?
 inline bool cfg_uses_table_blob(const nsg_config& cfg) {
   if (cfg.env_type == NSG_ENV_FROZENLAKE || cfg.env_type == NSG_ENV_CLIFFWALKING || cfg.env_type == NSG_ENV_BRIDGE) return true;
@@ -157,7 +157,17 @@ inline std::string group_source(const nsg_config* const* cfgs, const bool* full,
       "typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
       "typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t;\n"
       "typedef unsigned long size_t;\n"
-      "#define NSG_SPEC_BUILD 1\n"
+      "#define NSG_SPEC_BUILD 1\n";
+  // classic-control members read their tables where they are when none of them uses a table blob (stage_tables<DIRECT>; grid
+  // members keep staging their maps either way)
+  bool direct = true;
+  for (int k = 0; k < n; k++) {
+    const int e = cfgs[k]->env_type;
+    const bool grid = e == NSG_ENV_FROZENLAKE || e == NSG_ENV_CLIFFWALKING || e == NSG_ENV_BRIDGE;
+    if (!grid && cfg_uses_table_blob(*cfgs[k])) direct = false;
+  }
+  if (direct) s += "#ifndef NSG_TABLES_DIRECT\n#define NSG_TABLES_DIRECT 1\n#endif\n";
+  s +=
       "#include \"nsg_kernels.hip.h\"\n"
       "namespace nsg {\n";
   for (int k = 0; k < n; k++) emit_cfg_words(s, *cfgs[k], k);
