@@ -150,6 +150,13 @@ class _NSSingle:
             self._act = torch.zeros(1, dtype=torch.float32 if v.action_is_float else torch.int32).pin_memory()
             self._act_np = self._act.numpy()
         self._act_np[0] = float(np.asarray(action, dtype=np.float64).reshape(-1)[0]) if v.action_is_float else int(action)
+        if self._done:
+            # The reference leaves a step() after the episode has ended to gymnasium (undefined there: CartPole warns and keeps
+            # integrating, a TimeLimit keeps reporting truncated).  Here the env is a 1-env batch with next-step autoreset, so this
+            # call RESETS it (reward 0, flags clear, relative_time 0, streams continue) - a stated deviation, not a silent one.
+            warnings.warn("step() was called although this environment had already returned terminated or truncated = True: "
+                          "ns_gym_amd resets it on this call (gymnasium's next-step autoreset); call reset() to control the seed",
+                          UserWarning, stacklevel=3)
         v._step_raw(self._act.data_ptr())
         o, inf = self._scalars()
         if v.may_raise:      # what the reference raises inside step() (LCBounded exhaustion, see VecNSEnv.check_errors)
@@ -157,6 +164,7 @@ class _NSSingle:
         h = self._host
         r = float(h["reward"][0])
         terminated, truncated = bool(h["terminated"][0]), bool(h["truncated"][0])
+        self._done = terminated or truncated
         if not v.is_grid:
             if "violation" not in h:
                 v.check_constraints()

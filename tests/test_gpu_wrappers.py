@@ -178,3 +178,37 @@ def test_episode_harness_rows_match_step_by_step_accounting(tmp_path):
     assert len(rd) == n + 1
     obs, rew = type_mismatch_checker({"state": 3, "env_change": {}}, m["nsg"].Reward(1.0, {}, {}, 1))
     assert obs == 3 and rew == 1.0
+
+
+def test_step_after_done_resets_and_says_so():
+    """Stated deviation: the N = 1 adaptors inherit the batch's next-step autoreset, so a step() on a finished
+    env performs the reset where the reference would keep stepping gymnasium's finished env (undefined there).  It must not
+    be silent: the call warns, returns the reset observation (relative_time 0, reward 0, flags clear) and the episode goes on."""
+    import warnings
+
+    from ns_gym_amd import make
+    from ns_gym_amd.schedulers import ContinuousScheduler
+    from ns_gym_amd.update_functions import IncrementUpdate
+    from ns_gym_amd.wrappers import NSClassicControlWrapper
+
+    env = NSClassicControlWrapper(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)},
+                                  change_notification=True)
+    env.reset(seed=3)
+    done = False
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")            # no warning while the episode runs
+        for _ in range(500):
+            obs, r, term, trunc, info = env.step(1)
+            if term or trunc:
+                done = True
+                break
+    assert done
+    with pytest.warns(UserWarning, match="already returned terminated or truncated"):
+        obs, r, term, trunc, info = env.step(1)
+    assert obs["relative_time"] == 0 and r == 0.0 and not term and not trunc
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        obs, r, term, trunc, info = env.step(1)   # the new episode runs on without a warning
+    assert obs["relative_time"] == 1 and r == 1.0
+    env.reset(seed=4)                             # an explicit reset after done is the silent, reference way
+    env.close()
