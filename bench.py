@@ -272,13 +272,21 @@ def main():
         env.step(pool[(args.warmup + k) % 8])
     ew.record()
     drain(ew)
-    t0 = time.perf_counter()
+    # The timed region is the K steps and nothing else: the opening event is enqueued (on the idle stream) before the clock is
+    # read, and the clock is read again the moment the event behind the K-th step has completed - the device has drained - with the
+    # closing torch.cuda.synchronize() + barrier right behind it.  (A synchronize() on a device that is already idle takes ~20 us
+    # of host time and the event record ~6: in the driver's 20-step window - 0.46 ms of kernels - they were 6 % of the quotient,
+    # tools/window_probe.py.  The clock read AFTER the synchronize is kept as config.ms_per_step_clock_after_synchronize.)
     e0.record()
+    t0 = time.perf_counter()
     for k in range(args.steps):
         env.step(pool[k % 8])
     e1.record()
-    drain(e1)
+    while not e1.query():
+        pass
     dt = time.perf_counter() - t0      # this rank's K steps, device drained; the MAX over ranks below is the job's time
+    torch.cuda.synchronize()
+    dt_after_sync = time.perf_counter() - t0
     barrier()                          # closing bracket (its own latency - an RCCL collective - is not part of the steps)
     torch.cuda.synchronize()
     kern_ms = e0.elapsed_time(e1) / args.steps   # average launch duration incl. back-to-back gap
@@ -409,6 +417,9 @@ def main():
                 "episodes_finished_rank0": episodes_rank0,
                 "gathered_returns": int(gathered.numel()), "returns_gather_ms": gather_ms_max,
                 "value_incl_gather": value_incl_gather, "value_incl_gather_T1000": value_incl_gather_t1000,
+                "ms_per_step_clock_after_synchronize": dt_after_sync / args.steps * 1e3,
+                "timed_region": "clock read after the opening event is enqueued and again when the event behind the K-th step has completed "
+                                "(device drained); the closing synchronize() + barrier follow immediately",
                 "actions": "counter-based uniform draws per (pool slot, global env index): independent of the sharding",
                 "rollout_k64_env_steps_per_sec_per_gpu": rollout_rate,
                 "kernels": "generic (precompiled)" if args.generic else "config-specialised (nsg_specialize, hiprtc)",
