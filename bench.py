@@ -128,6 +128,18 @@ def baseline_configs_at_own_size(dev, c1_step_us, c1_rollout_rate, n_c1):
     return rows
 
 
+def job_roofline(value, world, n_per_gpu, kern_ms_rank0, kern_ms_slowest):
+    """(achieved GB/s, peak GB/s, extra fields) of the line's `roofline` block.  One GPU: the kernel's own rate - algorithmic bytes
+    per launch over its average launch duration - against 8 TB/s.  N > 1: the job's aggregate - 120 B x all ranks' env-steps per
+    second of the job's (max-over-ranks) time - against N x 8 TB/s, rank 0's own kernel beside it."""
+    achieved = BYTES_PER_ENV_STEP * n_per_gpu / (kern_ms_rank0 * 1e-3) / 1e9
+    if world == 1:
+        return achieved, HBM_PEAK_GBS, None
+    multi = {"rank0_avg_launch_us": kern_ms_rank0 * 1e3, "rank0_frac_of_one_gpu": achieved / HBM_PEAK_GBS,
+             "slowest_rank_avg_launch_us": kern_ms_slowest * 1e3}
+    return BYTES_PER_ENV_STEP * value / 1e9, HBM_PEAK_GBS * world, multi
+
+
 def self_launch(args, argv):
     """`--gpus N > 1` outside a launcher: run N ranks under torch.distributed.run as a child (this process never initialises a
     GPU: device_count() does not), relay its output, exit with its code."""
@@ -385,16 +397,7 @@ def main():
     value_incl_gather_t1000 = float(n) * world * 1000 / (dt_max / args.steps * 1000 + gather_ms_max * 1e-3)
 
     if rank == 0:
-        achieved = BYTES_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e9
-        peak = HBM_PEAK_GBS
-        multi = None
-        if world > 1:
-            # N > 1: the job's roofline is the aggregate - 120 B x all ranks' env-steps per second of the job's (max-over-ranks)
-            # time, against N x 8 TB/s; rank 0's own kernel stays beside it
-            multi = {"rank0_avg_launch_us": kern_ms * 1e3, "rank0_frac_of_one_gpu": achieved / HBM_PEAK_GBS,
-                     "slowest_rank_avg_launch_us": kern_ms_max * 1e3}
-            achieved = BYTES_PER_ENV_STEP * value / 1e9
-            peak = HBM_PEAK_GBS * world
+        achieved, peak, multi = job_roofline(value, world, n, kern_ms, kern_ms_max)
         out = {
             "metric": "non-stationary env-steps/sec",
             "value": value,

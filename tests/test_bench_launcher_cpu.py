@@ -27,3 +27,19 @@ def test_launcher_and_flag_must_agree():
 
 def test_bad_flag():
     assert _run("--gpus", "0").returncode != 0
+
+
+def test_eight_gpu_line_prices_the_aggregate_against_eight_peaks():
+    """C5's line as the driver will read it at N = 8 (no 8-GPU node exists for this build to run on): the `roofline` block is
+    the job's 120 B x value against 8 x 8 TB/s, with rank 0's kernel beside it; at N = 1 it is the kernel's own rate."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    n, kern_ms = 1 << 20, 0.0228
+    value8 = 8 * n / (0.0235e-3)                   # eight ranks, the slowest needing 23.5 us per step
+    ach, peak, extra = bench.job_roofline(value8, 8, n, kern_ms, 0.0235)
+    assert peak == 8 * 8000.0 and abs(ach - 120 * value8 / 1e9) < 1e-6 and 0.6 < ach / peak < 0.75
+    assert abs(extra["rank0_frac_of_one_gpu"] - 120 * n / (kern_ms * 1e-3) / 1e9 / 8000.0) < 1e-12
+    assert extra["slowest_rank_avg_launch_us"] == 23.5 and extra["rank0_avg_launch_us"] == 22.8
+    ach1, peak1, extra1 = bench.job_roofline(n / (kern_ms * 1e-3), 1, n, kern_ms, kern_ms)
+    assert peak1 == 8000.0 and extra1 is None and abs(ach1 - 120 * n / (kern_ms * 1e-3) / 1e9) < 1e-9
