@@ -192,3 +192,31 @@ def test_specialised_group_launch_equals_generic_group_launch():
         _same_rows(a, b, f"reordered group member {nm}")
     for e in gen + spc:
         e.close()
+
+
+def test_large_batch_without_runtime_compiler_warns_and_runs_generic():
+    """No libhiprtc (simulated with NSG_NO_HIPRTC=1 in a child process): a batch that would be specialised by default falls back
+    to the precompiled generic kernels WITH a SpecializationUnavailableWarning; asking for specialize=True raises."""
+    import os
+    import subprocess
+    import sys
+
+    child = ("import warnings, torch\n"
+             "from ns_gym_amd import workloads as W\n"
+             "from ns_gym_amd._lib import NsgError\n"
+             "from ns_gym_amd.vec_env import SpecializationUnavailableWarning\n"
+             "with warnings.catch_warnings(record=True) as w:\n"
+             "    warnings.simplefilter('always')\n"
+             "    e = W.build('c1', 65536)\n"
+             "assert any(issubclass(x.category, SpecializationUnavailableWarning) for x in w), [str(x.message) for x in w]\n"
+             "assert not e.specialized\n"
+             "ref = W.build('c1', 65536, specialize=False)\n"
+             "a = W.random_actions(e)\n"
+             "for _ in range(30): e.step(a); ref.step(a)\n"
+             "assert torch.equal(e.state, ref.state) and torch.equal(e.theta, ref.theta)\n"
+             "try:\n"
+             "    W.build('c1', 4096, specialize=True); raise SystemExit('specialize=True must raise without the compiler')\n"
+             "except NsgError as err:\n"
+             "    assert 'libhiprtc' in str(err)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", child], cwd=root, check=True, env=dict(os.environ, NSG_NO_HIPRTC="1", NSG_SPEC_CACHE="off"), timeout=300)

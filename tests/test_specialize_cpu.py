@@ -165,3 +165,24 @@ def test_no_specialised_step_kernel_spills_vector_registers():
         spec = {**spec, "wrapper_kwargs": _decode(spec)}
         for name, k in _notes(_build(spec, track_returns=True)).items():
             assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (case, name, k)
+
+
+def test_without_the_runtime_compiler_the_build_is_refused_not_faked():
+    """A box without libhiprtc (simulated: NSG_NO_HIPRTC=1, read once per process): nsg_spec_build answers NSG_EUNSUPPORTED and
+    names the missing library - the caller (VecNSEnv) then stays on the generic kernels and warns."""
+    import os
+    import subprocess
+    import sys
+
+    child = ("import ctypes as C\n"
+             "from ns_gym_amd import _lib\n"
+             "from ns_gym_amd.envs import make\n"
+             "from ns_gym_amd.spec import build_tunable_params, compile_config\n"
+             "from tests.util import TRAJ_SPECS\n"
+             "spec = TRAJ_SPECS['c1_cartpole_masspole_inc']\n"
+             "cfg = compile_config(make(spec['env_id']), build_tunable_params(spec['params']), **spec['flags'])[0]\n"
+             "lib = _lib.load(); code, size = C.c_void_p(), C.c_size_t()\n"
+             "rc = lib.nsg_spec_build(C.byref(cfg), b'gfx950', C.byref(code), C.byref(size))\n"
+             "assert rc == -95 and b'libhiprtc' in lib.nsg_last_error() and not code.value, (rc, lib.nsg_last_error())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", child], cwd=root, check=True, env=dict(os.environ, NSG_NO_HIPRTC="1"), timeout=300)
