@@ -670,7 +670,8 @@ struct GroupPlan {
   uint64_t last_used = 0;
 };
 constexpr size_t kMaxGroupPlans = 16;     // least recently used beyond this
-constexpr size_t kMaxRetiredTables = 32;  // drained (device synchronisation + free) beyond this
+constexpr size_t kMaxRetiredTables = 1024;  // 16 KB each; drained (device synchronisation + free) beyond this: a captured graph that still
+                                            // points at a table outlives at most this many later re-plans / evictions (nsgym_hip.h)
 static std::mutex g_plan_mutex;
 static std::vector<GroupPlan> g_plans;
 static std::vector<std::pair<int, Segment*>> g_retired;   // (device, table)
@@ -1044,19 +1045,21 @@ int nsg_destroy(nsg_handle* h) {
   if (!h) return NSG_OK;
   {   // plans this handle is a member of go with it; their tables once nothing can read them any more
     std::lock_guard<std::mutex> lock(g_plan_mutex);
-    bool purged = false;
+    // only THEIR tables are freed here (nothing can legitimately launch a group with a destroyed member again); tables retired by
+    // re-plans or evictions of other groups stay parked - a captured graph of live handles may still point at them
+    std::vector<Segment*> dead;
     for (size_t q = 0; q < g_plans.size();) {
       bool member = false;
       for (int k = 0; k < g_plans[q].n_members; k++) member |= g_plans[q].ids[k] == h->id;
       if (member) {
-        retire_table_locked(g_plans[q]);
+        if (g_plans[q].d_table) dead.push_back(g_plans[q].d_table);
         g_plans.erase(g_plans.begin() + (long)q);
-        purged = true;
       } else {
         q++;
       }
     }
-    if (purged && hipDeviceSynchronize() == hipSuccess) drain_retired_locked();
+    if (!dead.empty() && hipDeviceSynchronize() == hipSuccess)
+      for (Segment* t : dead) (void)hipFree(t);
     (void)hipGetLastError();
   }
   if (h->d_tables) (void)hipFree(h->d_tables);
