@@ -129,3 +129,41 @@ def test_eight_rank_job_equals_the_unsharded_job(total):
     assert all(res[r][0] == want for r in range(world)), "every rank must hold the unsharded job's returns, in global env order"
     assert b"".join(res[r][1] for r in range(world)) == ref.a["obs"].tobytes()
     assert b"".join(res[r][2] for r in range(world)) == ref.a["t"].tobytes()
+
+
+def test_global_actions_are_a_function_of_the_global_index_only():
+    """The bench's synthetic actions: the draw of env i at pool slot k must not depend on how [0, N) is cut into shards, must
+    differ between slots, and must be (close to) uniform over the action set - also for three actions."""
+    from ns_gym_amd.distributed import global_actions, shard_range
+
+    n = 100_003
+    for n_actions in (2, 3):
+        whole = global_actions(5, 0, n, n_actions)
+        for world in (2, 7, 8):
+            parts = [global_actions(5, *shard_range(n, r, world), n_actions) for r in range(world)]
+            assert torch.equal(torch.cat(parts), whole)
+        assert whole.dtype == torch.int32 and int(whole.min()) == 0 and int(whole.max()) == n_actions - 1
+        freq = torch.bincount(whole.long(), minlength=n_actions).double() / n
+        assert float((freq - 1.0 / n_actions).abs().max()) < 0.01
+        other = global_actions(6, 0, n, n_actions)
+        assert 0.9 / n_actions < float((whole == other).double().mean()) < 1.1 / n_actions    # independent slots
+
+
+def test_named_workloads_compile_to_configs():
+    """ns_gym_amd.workloads: BASELINE's configurations as named workloads - each compiles into an nsg_config on the host (no
+    GPU), with the env type, parameter count and table blob the kernels' launch policies key on."""
+    from ns_gym_amd import _abi as A, make
+    from ns_gym_amd import workloads as W
+    from ns_gym_amd.spec import compile_config
+
+    want = {"c1": (A.ENV_CARTPOLE, 1, False), "c2": (A.ENV_CARTPOLE, 1, False), "c3": (A.ENV_FROZENLAKE, 1, True),
+            "pend": (A.ENV_PENDULUM, 1, False), "acro": (A.ENV_ACROBOT, 1, False), "mcar": (A.ENV_MOUNTAINCAR, 1, False)}
+    for name, (env_type, n_params, blob) in want.items():
+        w = W.WORKLOADS[name]
+        cfg, tables, _, names = compile_config(make(w["env_id"], **w["make_kwargs"]), w["params"](), change_notification=True,
+                                               delta_change_notification=True, track_returns=True, **w["wrapper_kwargs"])
+        assert (cfg.env_type, cfg.n_params, len(names)) == (env_type, n_params, n_params), name
+        uses_blob = cfg.env_type in A.GRID_ENVS or any(cfg.params[p].sched_kind == A.SCHED_TABLE or cfg.params[p].val_tab_len > 0
+                                                        for p in range(cfg.n_params))
+        assert uses_blob == blob, name      # blob-free classic-control configs take the no-staging step kernels (cfg_uses_table_blob)
+    assert W.WORKLOADS["c2"]["baseline_envs"] == 65536 and W.WORKLOADS["c1"]["bytes_per_env_step"] == 120
