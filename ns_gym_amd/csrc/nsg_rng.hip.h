@@ -44,9 +44,18 @@ template <typename T> __device__ __forceinline__ T ldg(const T* base, uint32_t b
   const NSG_GLOBAL char* p = (const NSG_GLOBAL char*)pin_sgpr((uint64_t)base);
   return *(const NSG_GLOBAL T*)(p + byte_off);
 }
+// NSG_STREAM_STATE 1 (specialised units of batches whose rows cannot live in the 256-MiB Infinity Cache, nsg_specialize): the
+// persistent rows leave non-temporally too - nothing written by this launch is still cached when the next one reads it anyway.
+#ifndef NSG_STREAM_STATE
+#define NSG_STREAM_STATE 0
+#endif
 template <typename T> __device__ __forceinline__ void stg(T* base, uint32_t byte_off, T v) {
   NSG_GLOBAL char* p = (NSG_GLOBAL char*)pin_sgpr((uint64_t)base);
+#if NSG_STREAM_STATE
+  __builtin_nontemporal_store(v, (NSG_GLOBAL T*)(p + byte_off));
+#else
   *(NSG_GLOBAL T*)(p + byte_off) = v;
+#endif
 }
 // Persistent rows of the grid envs: agent-scope stores (`global_store ... sc1`: written through the XCD's L2 instead of
 // sitting there dirty until something evicts them).  Measured on C3 (FrozenLake 8x8, 2^20 envs, two interleaved

@@ -84,7 +84,7 @@ inline const Rtc* rtc() {
 // ---- the specialised translation unit ----------------------------------------------------------
 // The config is emitted as its raw 64-bit words (independent of the struct's field list) and viewed
 // as nsg_config; after inlining every access is a load from a constant at a constant offset.
-constexpr const char* kGeneratorRev = "spec_source r3.2";   // part of the cache key (nsgym_hip.hip: spec_source_hash)
+constexpr const char* kGeneratorRev = "spec_source r3.3";   // part of the cache key (nsgym_hip.hip: spec_source_hash)
 // Does the config look anything up in the constant-table blob (schedule bit tables, value lists, grid maps)?
 inline bool cfg_uses_table_blob(const nsg_config& cfg) {
   if (cfg.env_type == NSG_ENV_FROZENLAKE || cfg.env_type == NSG_ENV_CLIFFWALKING || cfg.env_type == NSG_ENV_BRIDGE) return true;
@@ -94,7 +94,7 @@ inline bool cfg_uses_table_blob(const nsg_config& cfg) {
   }
   return false;
 }
-inline std::string spec_source(const nsg_config& cfg, bool full, bool resets_in_lane = false, bool six_waves = true) {
+inline std::string spec_source(const nsg_config& cfg, bool full, bool resets_in_lane = false, bool six_waves = true, bool stream_state = false) {
   static_assert(sizeof(nsg_config) % 8 == 0, "nsg_config is emitted as 64-bit words");
   std::string s;
   s.reserve(16384);
@@ -104,6 +104,7 @@ inline std::string spec_source(const nsg_config& cfg, bool full, bool resets_in_
       "typedef unsigned long size_t;\n"
       "#define NSG_SPEC_BUILD 1\n";
   if (resets_in_lane) s += "#define NSG_CARTPOLE_INLANE 1\n";   // batch-size policy of nsg_specialize (nsg_envs.hip.h)
+  if (stream_state) s += "#ifndef NSG_STREAM_STATE\n#define NSG_STREAM_STATE 1\n#endif\n";   // likewise (nsg_rng.hip.h: stg)
   // a classic-control config without a table blob (no schedule bit table, no value list): the step kernel reads the ziggurat tables
   // where they are instead of staging them per workgroup (nsg_kernels.hip.h: stage_tables<DIRECT>)
   if (!cfg_uses_table_blob(cfg)) s += "#ifndef NSG_TABLES_DIRECT\n#define NSG_TABLES_DIRECT 1\n#endif\n";
@@ -233,10 +234,11 @@ inline bool allow_spill() {
 // VGPRs, 164-228 B of scratch per lane), and one such build returned wrong results on MI355X (round 2, random-configuration
 // case 61; profiles/r03_case61_spill_evidence.md).  Such a config is compiled again without the bound; if it still spills
 // (only reachable through NSG_SPEC_FLAGS forcing a register bound) the unit is refused and the generic kernels stay in force.
-inline std::vector<char> spec_compile(const nsg_config& cfg, bool full, const char* arch, std::string& err, bool resets_in_lane = false) {
-  std::vector<char> code = compile_source(spec_source(cfg, full, resets_in_lane, true), arch, err);
+inline std::vector<char> spec_compile(const nsg_config& cfg, bool full, const char* arch, std::string& err, bool resets_in_lane = false,
+                                      bool stream_state = false) {
+  std::vector<char> code = compile_source(spec_source(cfg, full, resets_in_lane, true, stream_state), arch, err);
   if (!code.empty() && unit_uses_scratch(code) && !allow_spill())
-    code = compile_source(spec_source(cfg, full, resets_in_lane, false), arch, err);
+    code = compile_source(spec_source(cfg, full, resets_in_lane, false, stream_state), arch, err);
   if (!code.empty() && unit_uses_scratch(code) && !allow_spill()) {
     err = "a kernel of the specialised unit spills vector registers (scratch memory) under the given NSG_SPEC_FLAGS; such builds "
           "are not used (see spec_compile)";

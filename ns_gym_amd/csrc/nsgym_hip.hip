@@ -1031,10 +1031,16 @@ int nsg_specialize(nsg_handle* h) {
   // 2^16, +-0 at 2^17; smaller and larger batches lose (2^14: 5.3 -> 6.0, 2^18: 9.4 -> 10.1, 2^20: 23.7 -> 26.1)
   const bool inlane = h->host.cfg.env_type == NSG_ENV_CARTPOLE && h->n >= 49152 && h->n <= 163840;
   h0 = nsg_spec::fnv1a(&inlane, sizeof(inlane), h0);
+  // classic-control batches of 2^24 envs and more (2.5 GB of rows: nothing a launch writes is still in the 256-MiB Infinity Cache
+  // when the next launch reads it) store their persistent rows non-temporally as well: C1 359.9 -> 348.6 us at 2^24 envs, C2 634.9
+  // -> 610.3, Pendulum 298.5 -> 290.7 (+-0 at 2^23 and below, and for the grid envs, whose rows already leave through agent-scope
+  // stores)
+  const bool stream_state = !is_grid_env(h->host.cfg.env_type) && h->n >= (1 << 24);
+  h0 = nsg_spec::fnv1a(&stream_state, sizeof(stream_state), h0);
   h0 = nsg_spec::fnv1a(prop.gcnArchName, strlen(prop.gcnArchName), h0);
   if (const char* e = getenv("NSG_SPEC_FLAGS")) h0 = nsg_spec::fnv1a(e, strlen(e), h0);
   const int rc = get_spec_module(h->device, h0, false,
-                                 [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err, inlane); }, &h->spec);
+                                 [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err, inlane, stream_state); }, &h->spec);
   h->generation++;   // a group that contains this handle re-plans (its specialised unit depends on every member's)
   return rc;
 }
