@@ -220,3 +220,24 @@ def test_large_batch_without_runtime_compiler_warns_and_runs_generic():
              "    assert 'libhiprtc' in str(err)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.run([sys.executable, "-c", child], cwd=root, check=True, env=dict(os.environ, NSG_NO_HIPRTC="1", NSG_SPEC_CACHE="off"), timeout=300)
+
+
+def test_units_from_a_filled_cache_load_without_the_runtime_compiler(tmp_path):
+    """Deployment on a box without libhiprtc: a cache directory filled elsewhere (here: by a first child process that has the
+    compiler) serves the specialised units - the second child runs with NSG_NO_HIPRTC=1 and still gets them."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = ("import torch\n"
+             "from ns_gym_amd import workloads as W\n"
+             "e = W.build('c2', 8192, specialize=True)\n"
+             "assert e.specialized\n"
+             "a = W.random_actions(e)\n"
+             "for _ in range(5): e.step(a)\n"
+             "torch.cuda.synchronize()\n")
+    env = dict(os.environ, NSG_SPEC_CACHE=str(tmp_path))
+    subprocess.run([sys.executable, "-c", child], cwd=root, check=True, env=env, timeout=300)
+    assert len(list(tmp_path.glob("nsg_*.hsaco"))) == 1
+    subprocess.run([sys.executable, "-c", child], cwd=root, check=True, env=dict(env, NSG_NO_HIPRTC="1"), timeout=300)
