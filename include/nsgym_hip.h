@@ -431,7 +431,11 @@ int nsg_read_back(const void* src_dev, void* dst_host_mapped, int64_t bytes, uin
  * keyed by config, kernel sources, compile options and HIP version; an unusable cached object is rebuilt)
  * and routes nsg_step / nsg_rollout of this handle through them.
  * Results are bit-identical to the generic kernels.  Returns NSG_EUNSUPPORTED (generic path stays in
- * force) when libhiprtc is missing or the compilation fails.
+ * force) when libhiprtc is missing (a unit already in the cache directory loads without it) or the compilation fails.
+ * The unit also depends on the batch size where a launch policy does: CartPole batches of 49 152 - 163 840 envs reset in-lane,
+ * classic-control batches of >= 2^24 envs store their persistent rows non-temporally, configs without a table blob stage
+ * nothing into LDS.  A unit in which any kernel spills vector registers or owns scratch memory is never loaded (rebuilt
+ * without the register bound, else refused: profiles/r03_case61_spill_evidence.md).
  * nsg_spec_build compiles only (no GPU needed; arch e.g. "gfx950"): *code_out is a malloc'ed code
  * object to be released with nsg_spec_free. */
 int nsg_specialize(nsg_handle* h);
