@@ -117,10 +117,25 @@ def baseline_configs_at_own_size(dev, c1_step_us, c1_rollout_rate, n_c1):
         e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e3 / 300)
+    # ... and the pair through ONE fused launch of K = 64 steps (nsg_rollout_group)
+    from ns_gym_amd.vec_env import rollout_group
+
+    K = 64
+    gacts = [torch.stack([W.random_actions(e) for _ in range(K)]) for e in (pend, acro)]
+    rollout_group([pend, acro], gacts)
+    torch.cuda.synchronize()
+    r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    r0.record()
+    for _ in range(4):
+        rollout_group([pend, acro], gacts)
+    r1.record()
+    torch.cuda.synchronize()
+    group_rollout_us = r0.elapsed_time(r1) * 1e3 / (4 * K)
     by = W.WORKLOADS["pend"]["bytes_per_env_step"] + W.WORKLOADS["acro"]["bytes_per_env_step"]
     rows["C4"] = {"envs": [pend.N, acro.N], "launch": "one nsg_step_group launch (" + step_group_kind([pend, acro]) + " unit)",
                   "step_us": best, "bytes_per_env_pair_step": by, "frac_of_hbm_peak": frac(by, pend.N, best),
                   "env_steps_per_sec": (pend.N + acro.N) / (best * 1e-6),
+                  "rollout_k64_us_per_step": group_rollout_us, "rollout_k64_env_steps_per_sec": (pend.N + acro.N) / (group_rollout_us * 1e-6),
                   "pendulum_alone_us": min(pend.time_steps(ap_, 200) for _ in range(2)) * 1e3,
                   "acrobot_alone_us": min(acro.time_steps(aa, 200) for _ in range(2)) * 1e3,
                   "bound": "the Acrobot member's float64 vector-ALU issue (RK4: 15 sincos + 12 divisions per step), not HBM"}

@@ -363,6 +363,11 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
  * stream a launch that would have to plan first is refused (NSG_EINVAL): launch the group once before the capture. */
 int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* actions_dev,
                    void* stream);
+/* K fused steps of EVERY member in one launch: nsg_rollout's heterogeneous counterpart (same plan, same block ranges as
+ * nsg_step_group; every member's persistent rows stay in registers / LDS for the K steps).  actions_dev[k]: member k's [K][N_k]
+ * actions; outs: NULL or one nsg_rollout_out per member (any pointer may be NULL).  Bit-identical to K nsg_step_group calls. */
+int nsg_rollout_group(nsg_handle* const* hs, int32_t n_handles, const void* const* actions_dev, int32_t k_steps,
+                      const nsg_rollout_out* outs, void* stream);
 /* Which kernel the current plan of this member list launches (>= 0), or a negative error code. */
 #define NSG_GROUP_UNPLANNED 0        /* not launched yet, or a member changed since */
 #define NSG_GROUP_GENERIC_SIMPLE 1   /* precompiled kernel, plain-arithmetic theta engine */

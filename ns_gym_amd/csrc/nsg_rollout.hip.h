@@ -12,9 +12,11 @@
 
 namespace nsg {
 
+// `block_rel` / `block_count`: the workgroup's index within, and the size of, the range of workgroups that walks this segment
+// (the whole launch for nsg_rollout; a member's block range for nsg_rollout_group).
 template <int ENV, bool FULL>
 __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segment& sg, const void* __restrict__ actions,
-                                             int k_steps, const nsg_rollout_out& ro) {
+                                             int k_steps, const nsg_rollout_out& ro, const int block_rel, const int block_count) {
   LdsTables lds;
   Tables tb;
   ZigLds zg;
@@ -30,7 +32,7 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
   constexpr bool FA = ENV == NSG_ENV_PENDULUM || ENV == NSG_ENV_MOUNTAINCAR_CONT;
   const int64_t chunks = (N + kBlock - 1) / kBlock;
   int parity = 0;
-  for (int64_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+  for (int64_t c = block_rel; c < chunks; c += block_count) {
     [[maybe_unused]] LaneState<GRID ? NSG_ENV_CARTPOLE : ENV> ls;
     [[maybe_unused]] GridLane<ENV == NSG_ENV_CLIFFWALKING ? 4 : 3> gl;
     // classic envs: the first stochastic update fns' streams live in LDS for the K steps (each lane touches only its own
@@ -103,7 +105,7 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
       __syncthreads();  // the next chunk refills the records
     }
   }
-  flush_counts(b.counters, (int)blockIdx.x, wc);
+  flush_counts(b.counters, block_rel, wc);
 }
 
 // The plain-arithmetic CartPole rollout sits at the 80-VGPR boundary (80 in round 1, 82 after round 2's hand-over changes: five
@@ -113,7 +115,36 @@ template <int ENV, bool FULL> constexpr int kRolloutMinWaves = (ENV == NSG_ENV_C
 template <int ENV, bool FULL>
 __global__ __launch_bounds__(kBlock, (kRolloutMinWaves<ENV, FULL>)) void rollout_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions,
                                                          int k_steps, nsg_rollout_out ro) {
-  rollout_body<ENV, FULL>(seg->cfg, *seg, actions, k_steps, ro);
+  rollout_body<ENV, FULL>(seg->cfg, *seg, actions, k_steps, ro, (int)blockIdx.x, (int)gridDim.x);
 }
+
+// Heterogeneous fused rollout (nsg_rollout_group): K steps of every member in ONE launch, a block range per member like
+// step_group_kernel; each member's persistent rows stay in registers / LDS for the K steps exactly as in nsg_rollout.
+struct RolloutOuts {
+  nsg_rollout_out o[NSG_MAX_SEGMENTS];
+};
+
+#ifndef NSG_SPEC_BUILD
+template <bool FULL>
+__global__ __launch_bounds__(kBlock) void rollout_group_kernel(const Segment* __restrict__ segs, int nseg, ActionPtrs acts, int k_steps,
+                                                               RolloutOuts outs) {
+  const int sidx = group_segment_of_block(segs, nseg);
+  const Segment& sg = segs[sidx];
+  const void* actions = acts.p[sidx];
+  const nsg_rollout_out& ro = outs.o[sidx];
+  const int rel = (int)blockIdx.x - sg.block_begin;
+  const int cnt = sg.block_count;
+  switch (sg.cfg.env_type) {
+    case NSG_ENV_CARTPOLE: rollout_body<NSG_ENV_CARTPOLE, FULL>(sg.cfg, sg, actions, k_steps, ro, rel, cnt); break;
+    case NSG_ENV_PENDULUM: rollout_body<NSG_ENV_PENDULUM, FULL>(sg.cfg, sg, actions, k_steps, ro, rel, cnt); break;
+    case NSG_ENV_ACROBOT: rollout_body<NSG_ENV_ACROBOT, FULL>(sg.cfg, sg, actions, k_steps, ro, rel, cnt); break;
+    case NSG_ENV_MOUNTAINCAR: rollout_body<NSG_ENV_MOUNTAINCAR, FULL>(sg.cfg, sg, actions, k_steps, ro, rel, cnt); break;
+    case NSG_ENV_MOUNTAINCAR_CONT: rollout_body<NSG_ENV_MOUNTAINCAR_CONT, FULL>(sg.cfg, sg, actions, k_steps, ro, rel, cnt); break;
+    case NSG_ENV_FROZENLAKE: rollout_body<NSG_ENV_FROZENLAKE, FULL>(sg.cfg, sg, actions, k_steps, ro, rel, cnt); break;
+    case NSG_ENV_CLIFFWALKING: rollout_body<NSG_ENV_CLIFFWALKING, FULL>(sg.cfg, sg, actions, k_steps, ro, rel, cnt); break;
+    default: rollout_body<NSG_ENV_BRIDGE, FULL>(sg.cfg, sg, actions, k_steps, ro, rel, cnt); break;
+  }
+}
+#endif
 
 }  // namespace nsg

@@ -84,7 +84,7 @@ inline const Rtc* rtc() {
 // ---- the specialised translation unit ----------------------------------------------------------
 // The config is emitted as its raw 64-bit words (independent of the struct's field list) and viewed
 // as nsg_config; after inlining every access is a load from a constant at a constant offset.
-constexpr const char* kGeneratorRev = "spec_source r3.3";   // part of the cache key (nsgym_hip.hip: spec_source_hash)
+constexpr const char* kGeneratorRev = "spec_source r3.4";   // part of the cache key (nsgym_hip.hip: spec_source_hash)
 // Does the config look anything up in the constant-table blob (schedule bit tables, value lists, grid maps)?
 inline bool cfg_uses_table_blob(const nsg_config& cfg) {
   if (cfg.env_type == NSG_ENV_FROZENLAKE || cfg.env_type == NSG_ENV_CLIFFWALKING || cfg.env_type == NSG_ENV_BRIDGE) return true;
@@ -134,7 +134,7 @@ inline std::string spec_source(const nsg_config& cfg, bool full, bool resets_in_
        "extern \"C\" __global__ __launch_bounds__(NSG_BLOCK) void nsg_spec_rollout(const nsg::Segment* __restrict__ seg,\n"
        "                                                                   const void* __restrict__ actions, int k_steps,\n"
        "                                                                   nsg_rollout_out ro) {\n"
-       "  nsg::rollout_body<" + targs + ">(NSG_SPEC_CFG, *seg, actions, k_steps, ro);\n"
+       "  nsg::rollout_body<" + targs + ">(NSG_SPEC_CFG, *seg, actions, k_steps, ro, (int)blockIdx.x, (int)gridDim.x);\n"
        "}\n";
   return s;
 }
@@ -171,7 +171,7 @@ inline std::string group_source(const nsg_config* const* cfgs, const bool* full,
   }
   if (direct) s += "#ifndef NSG_TABLES_DIRECT\n#define NSG_TABLES_DIRECT 1\n#endif\n";
   s +=
-      "#include \"nsg_kernels.hip.h\"\n"
+      "#include \"nsg_rollout.hip.h\"\n"
       "namespace nsg {\n";
   for (int k = 0; k < n; k++) emit_cfg_words(s, *cfgs[k], k);
   s += "}  // namespace nsg\n"
@@ -187,6 +187,20 @@ inline std::string group_source(const nsg_config* const* cfgs, const bool* full,
              "    case %d: nsg::step_body<%d, %s>(*reinterpret_cast<const nsg_config*>(nsg::kCfgWords%d), sg, acts.p[%d], rel, "
              "sg.block_count, reverse); break;\n",
              k, (int)cfgs[k]->env_type, full[k] ? "true" : "false", k, k);
+    s += buf;
+  }
+  s += "    default: break;\n  }\n}\n"
+       "extern \"C\" __global__ __launch_bounds__(NSG_BLOCK) void nsg_spec_group_rollout(const nsg::Segment* __restrict__ segs, int nseg,\n"
+       "                                                                 nsg::ActionPtrs acts, int k_steps, nsg::RolloutOuts outs) {\n"
+       "  const int sidx = nsg::group_segment_of_block(segs, nseg);\n"
+       "  const nsg::Segment& sg = segs[sidx];\n"
+       "  const int rel = (int)blockIdx.x - sg.block_begin;\n"
+       "  switch (sidx) {\n";
+  for (int k = 0; k < n; k++) {
+    snprintf(buf, sizeof(buf),
+             "    case %d: nsg::rollout_body<%d, %s>(*reinterpret_cast<const nsg_config*>(nsg::kCfgWords%d), sg, acts.p[%d], k_steps, "
+             "outs.o[%d], rel, sg.block_count); break;\n",
+             k, (int)cfgs[k]->env_type, full[k] ? "true" : "false", k, k, k);
     s += buf;
   }
   s += "    default: break;\n  }\n}\n";
@@ -337,7 +351,7 @@ inline uint64_t fnv1a(const void* p, size_t n, uint64_t h = 0xcbf29ce484222325ul
 struct Module {
   hipModule_t mod = nullptr;
   hipFunction_t step = nullptr, rollout = nullptr;  // single-config unit
-  hipFunction_t group = nullptr;                     // heterogeneous-launch unit
+  hipFunction_t group = nullptr, group_rollout = nullptr;   // heterogeneous-launch unit (single step, fused rollout)
   uint64_t h0 = 0;                                    // config key (group keys are built from their members')
   int step_waves = 0;                                 // wavefronts per SIMD the step kernel's registers allow (0 = unknown)
 };

@@ -275,6 +275,7 @@ int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, cons
     if (le != hipSuccess) return fail(NSG_EHIP, "hipModuleLoadData: %s", hipGetErrorString(le));
     if (group) {
       HIP_TRY(hipModuleGetFunction(&m.group, m.mod, "nsg_spec_group"));
+      HIP_TRY(hipModuleGetFunction(&m.group_rollout, m.mod, "nsg_spec_group_rollout"));
     } else {
       HIP_TRY(hipModuleGetFunction(&m.step, m.mod, "nsg_spec_step"));
       HIP_TRY(hipModuleGetFunction(&m.rollout, m.mod, "nsg_spec_rollout"));
@@ -665,7 +666,7 @@ struct GroupPlan {
   uint64_t gens[NSG_MAX_SEGMENTS];
   int n_members = 0;
   Segment* d_table = nullptr;
-  int total_blocks = 0, all_simple = 0, group_lds = 0, device = -1;
+  int total_blocks = 0, all_simple = 0, group_lds = 0, group_rollout_lds = 0, device = -1;
   const nsg_spec::Module* group_spec = nullptr;
   uint64_t last_used = 0;
 };
@@ -731,7 +732,7 @@ static int make_group_plan_locked(GroupPlan& plan, nsg_handle* const* hs, int n_
   plan.total_blocks = begin;
   plan.device = hs[0]->device;
   plan.all_simple = 1;
-  plan.group_lds = 0;
+  plan.group_lds = plan.group_rollout_lds = 0;
   bool all_spec = true;
   for (int k = 0; k < n_handles; k++) {
     plan.ids[k] = hs[k]->id;
@@ -740,6 +741,9 @@ static int make_group_plan_locked(GroupPlan& plan, nsg_handle* const* hs, int n_
     all_spec = all_spec && hs[k]->spec != nullptr;
     const int l = lds_bytes_for(hs[k]->host.table_bytes, hs[k]->host.uses_normal, hs[k]->host.uses_exp);
     if (l > plan.group_lds) plan.group_lds = l;
+    // a fused rollout keeps the chunk's env streams (and its first stochastic update fns' streams) in LDS as well (nsg_rollout)
+    const int lr = l + (is_grid_env(hs[k]->host.cfg.env_type) ? 0 : kLdsStreamBytes * (1 + upd_lds_count(hs[k]->host.cfg)));
+    if (lr > plan.group_rollout_lds) plan.group_rollout_lds = lr;
   }
   // every member runs config-specialised kernels: so does the group (one unit for the ordered tuple of configs)
   plan.group_spec = nullptr;
@@ -773,6 +777,53 @@ static int check_group_members(nsg_handle* const* hs, int32_t n_handles) {
   return NSG_OK;
 }
 
+// What a launch needs from its plan, copied out under the mutex (the launch itself is enqueued outside it).
+struct PlanSnapshot {
+  const Segment* table = nullptr;
+  const nsg_spec::Module* group_spec = nullptr;
+  int total_blocks = 0, all_simple = 0, group_lds = 0, group_rollout_lds = 0;
+};
+
+// Finds the current plan of the member list, or makes it (never while `stream` is capturing).
+static int acquire_group_plan(nsg_handle* const* hs, int32_t n_handles, void* stream, PlanSnapshot* out) {
+  std::lock_guard<std::mutex> lock(g_plan_mutex);
+  GroupPlan* plan = nullptr;
+  for (GroupPlan& p : g_plans)
+    if (same_members(p, hs, n_handles)) { plan = &p; break; }
+  if (!plan || !plan_is_current(*plan, hs)) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      return fail(NSG_EINVAL, "nsg_step_group: this member list has no current plan and the stream is capturing (planning "
+                              "synchronises the device): launch the group once before the capture");
+    (void)hipGetLastError();
+    if (!plan) {
+      if (g_plans.size() >= kMaxGroupPlans) {   // least recently used goes; its table is retired, not freed
+        size_t lru = 0;
+        for (size_t q = 1; q < g_plans.size(); q++)
+          if (g_plans[q].last_used < g_plans[lru].last_used) lru = q;
+        retire_table_locked(g_plans[lru]);
+        g_plans.erase(g_plans.begin() + (long)lru);
+      }
+      g_plans.emplace_back();
+      plan = &g_plans.back();
+    }
+    const int rc = make_group_plan_locked(*plan, hs, n_handles);
+    if (rc) {   // nothing half-made stays behind
+      retire_table_locked(*plan);
+      g_plans.erase(g_plans.begin() + (plan - g_plans.data()));
+      return rc;
+    }
+  }
+  plan->last_used = ++g_plan_clock;
+  out->table = plan->d_table;
+  out->group_spec = plan->group_spec;
+  out->total_blocks = plan->total_blocks;
+  out->all_simple = plan->all_simple;
+  out->group_lds = plan->group_lds;
+  out->group_rollout_lds = plan->group_rollout_lds;
+  return NSG_OK;
+}
+
 int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* actions_dev, void* stream) {
   if (!actions_dev) return fail(NSG_EINVAL, "bad group arguments");
   int rc = check_group_members(hs, n_handles);
@@ -783,53 +834,64 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
     if (!actions_dev[k]) return fail(NSG_EINVAL, "actions_dev[%d] is NULL", k);
     ap.p[k] = actions_dev[k];
   }
-  // the launch parameters are copied out under the mutex; the launch itself is enqueued outside it
-  const Segment* ga = nullptr;
-  const nsg_spec::Module* group_spec = nullptr;
-  int total_blocks = 0, all_simple = 0, group_lds = 0;
-  {
-    std::lock_guard<std::mutex> lock(g_plan_mutex);
-    GroupPlan* plan = nullptr;
-    for (GroupPlan& p : g_plans)
-      if (same_members(p, hs, n_handles)) { plan = &p; break; }
-    if (!plan || !plan_is_current(*plan, hs)) {
-      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-        return fail(NSG_EINVAL, "nsg_step_group: this member list has no current plan and the stream is capturing (planning "
-                                "synchronises the device): launch the group once before the capture");
-      (void)hipGetLastError();
-      if (!plan) {
-        if (g_plans.size() >= kMaxGroupPlans) {   // least recently used goes; its table is retired, not freed
-          size_t lru = 0;
-          for (size_t q = 1; q < g_plans.size(); q++)
-            if (g_plans[q].last_used < g_plans[lru].last_used) lru = q;
-          retire_table_locked(g_plans[lru]);
-          g_plans.erase(g_plans.begin() + (long)lru);
-        }
-        g_plans.emplace_back();
-        plan = &g_plans.back();
-      }
-      rc = make_group_plan_locked(*plan, hs, n_handles);
-      if (rc) {   // nothing half-made stays behind
-        retire_table_locked(*plan);
-        g_plans.erase(g_plans.begin() + (plan - g_plans.data()));
-        return rc;
-      }
-    }
-    plan->last_used = ++g_plan_clock;
-    ga = plan->d_table;
-    group_spec = plan->group_spec;
-    total_blocks = plan->total_blocks;
-    all_simple = plan->all_simple;
-    group_lds = plan->group_lds;
-  }
+  PlanSnapshot ps;
+  rc = acquire_group_plan(hs, n_handles, stream, &ps);
+  if (rc) return rc;
   int reverse = next_traversal(hs[0]);   // the members of a group alternate together
-  if (group_spec) {
+  const Segment* ga = ps.table;
+  if (ps.group_spec) {
     void* args[] = {(void*)&ga, (void*)&n_handles, (void*)&ap, (void*)&reverse};
-    HIP_TRY(hipModuleLaunchKernel(group_spec->group, total_blocks, 1, 1, kBlock, 1, 1, (unsigned)group_lds, (hipStream_t)stream, args, nullptr));
-  } else if (all_simple) hipLaunchKernelGGL(step_group_kernel<false>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, ga, n_handles, ap, reverse);
-  else hipLaunchKernelGGL(step_group_kernel<true>, dim3(total_blocks), dim3(kBlock), (size_t)group_lds, (hipStream_t)stream, ga, n_handles, ap, reverse);
+    HIP_TRY(hipModuleLaunchKernel(ps.group_spec->group, ps.total_blocks, 1, 1, kBlock, 1, 1, (unsigned)ps.group_lds, (hipStream_t)stream, args, nullptr));
+  } else if (ps.all_simple) hipLaunchKernelGGL(step_group_kernel<false>, dim3(ps.total_blocks), dim3(kBlock), (size_t)ps.group_lds, (hipStream_t)stream, ga, n_handles, ap, reverse);
+  else hipLaunchKernelGGL(step_group_kernel<true>, dim3(ps.total_blocks), dim3(kBlock), (size_t)ps.group_lds, (hipStream_t)stream, ga, n_handles, ap, reverse);
   HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
+// K fused steps of every member in ONE launch (nsg_rollout per member, a block range each): the heterogeneous counterpart of
+// nsg_rollout.  actions_dev[k]: [K][N_k]; outs[k]: member k's trajectory buffers (any pointer, or `outs` itself, may be NULL).
+int nsg_rollout_group(nsg_handle* const* hs, int32_t n_handles, const void* const* actions_dev, int32_t k_steps,
+                      const nsg_rollout_out* outs, void* stream) {
+  if (!actions_dev || k_steps <= 0) return fail(NSG_EINVAL, "bad group rollout arguments");
+  int rc = check_group_members(hs, n_handles);
+  if (rc) return rc;
+  ActionPtrs ap;
+  RolloutOuts ro;
+  memset(&ap, 0, sizeof(ap));
+  memset(&ro, 0, sizeof(ro));
+  for (int k = 0; k < n_handles; k++) {
+    if (!actions_dev[k]) return fail(NSG_EINVAL, "actions_dev[%d] is NULL", k);
+    ap.p[k] = actions_dev[k];
+    if (outs) ro.o[k] = outs[k];
+  }
+  PlanSnapshot ps;
+  rc = acquire_group_plan(hs, n_handles, stream, &ps);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const Segment* ga = ps.table;
+  if (ps.group_spec) {
+    void* args[] = {(void*)&ga, (void*)&n_handles, (void*)&ap, (void*)&k_steps, (void*)&ro};
+    HIP_TRY(hipModuleLaunchKernel(ps.group_spec->group_rollout, ps.total_blocks, 1, 1, kBlock, 1, 1, (unsigned)ps.group_rollout_lds, s, args, nullptr));
+  } else if (ps.all_simple) hipLaunchKernelGGL(rollout_group_kernel<false>, dim3(ps.total_blocks), dim3(kBlock), (size_t)ps.group_rollout_lds, s, ga, n_handles, ap, k_steps, ro);
+  else hipLaunchKernelGGL(rollout_group_kernel<true>, dim3(ps.total_blocks), dim3(kBlock), (size_t)ps.group_rollout_lds, s, ga, n_handles, ap, k_steps, ro);
+  HIP_TRY(hipGetLastError());
+  // like nsg_rollout: the last step landed in each member's own output rows - mirror them into its last trajectory slice
+  for (int m = 0; m < n_handles; m++) {
+    const nsg_rollout_out& o = ro.o[m];
+    const nsg_buffers& bb = hs[m]->host.buf;
+    const int64_t n = hs[m]->n, K1 = k_steps - 1;
+    const int e = hs[m]->host.cfg.env_type;
+    const int P = hs[m]->host.cfg.n_params > 0 ? hs[m]->host.cfg.n_params : 1;
+    if (o.obs) {
+      if (is_grid_env(e)) HIP_TRY(hipMemcpyAsync((int32_t*)o.obs + K1 * n, bb.cell, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+      else HIP_TRY(hipMemcpyAsync(o.obs + K1 * n * kObsDim[e], bb.obs, n * kObsDim[e] * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    if (o.reward) HIP_TRY(hipMemcpyAsync(o.reward + K1 * n, bb.reward, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (o.terminated) HIP_TRY(hipMemcpyAsync(o.terminated + K1 * n, bb.terminated, n, hipMemcpyDeviceToDevice, s));
+    if (o.truncated) HIP_TRY(hipMemcpyAsync(o.truncated + K1 * n, bb.truncated, n, hipMemcpyDeviceToDevice, s));
+    if (o.env_change) HIP_TRY(hipMemcpyAsync(o.env_change + K1 * P * n, bb.env_change, (size_t)P * n, hipMemcpyDeviceToDevice, s));
+    if (o.delta_change) HIP_TRY(hipMemcpyAsync(o.delta_change + K1 * P * n, bb.delta_change, (size_t)P * n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
   return NSG_OK;
 }
 

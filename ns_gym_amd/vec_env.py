@@ -587,6 +587,36 @@ def step_group(envs, actions):
     return [(e._obs(), e.reward, e.terminated, e.truncated, e._info()) for e in envs]
 
 
+def rollout_group(envs, actions, record=("obs", "reward", "terminated", "truncated")):
+    """K fused steps of several VecNSEnv of different env types in ONE launch (`nsg_rollout_group`): `actions[k]` is member k's
+    [K, N_k] tensor.  Returns one dict of [K, ...] trajectory tensors per member, like `VecNSEnv.rollout`."""
+    lib = _lib.load()
+    n = len(envs)
+    K = int(actions[0].shape[0])
+    acts, outs = [], []
+    ros = (A.RolloutOut * n)()
+    for j, (e, a) in enumerate(zip(envs, actions)):
+        assert int(a.shape[0]) == K, "every member takes the same number of steps"
+        dt = torch.float32 if e.action_is_float else torch.int32
+        acts.append(a.to(device=e.device, dtype=dt).reshape(K, e.N).contiguous())
+        P, N = max(e.cfg.n_params, 1), e.N
+        shapes = {"obs": ((K, N) if e.is_grid else (K, N, e.obs_dim), torch.int32 if e.is_grid else torch.float32),
+                  "reward": ((K, N), torch.float32), "terminated": ((K, N), torch.uint8), "truncated": ((K, N), torch.uint8),
+                  "env_change": ((K, P, N), torch.uint8), "delta_change": ((K, P, N), torch.float32)}
+        out = {k: torch.empty(shapes[k][0], dtype=shapes[k][1], device=e.device) for k in record}
+        ros[j] = A.RolloutOut(**{k: v.data_ptr() for k, v in out.items()})
+        outs.append(out)
+    hs = (C.c_void_p * n)(*[e._h for e in envs])
+    ap = (C.c_void_p * n)(*[a.data_ptr() for a in acts])
+    with torch.cuda.device(envs[0].device):
+        _lib.check(lib.nsg_rollout_group(hs, n, ap, K, ros, envs[0]._stream), "nsg_rollout_group")
+    for out in outs:
+        for k in ("terminated", "truncated"):
+            if k in out:
+                out[k] = out[k].view(torch.bool)
+    return outs
+
+
 GROUP_KINDS = {0: "unplanned", 1: "generic", 2: "generic-full", 3: "specialised"}
 
 

@@ -41,7 +41,7 @@ def test_single_process_line():
     # every BASELINE configuration at the size BASELINE quotes it at, each priced with its own bytes
     own = d["config"]["baseline_configs_at_own_size"]
     assert own["C2"]["envs"] == 65536 and own["C3"]["envs"] == 1 << 20 and own["C4"]["envs"] == [1 << 18, 1 << 18]
-    assert "specialised" in own["C4"]["launch"]
+    assert "specialised" in own["C4"]["launch"] and own["C4"]["rollout_k64_env_steps_per_sec"] > 0
     for tag, by in (("C2", 157), ("C3", 96)):
         r = own[tag]
         assert abs(r["frac_of_hbm_peak"] - by * r["envs"] / (r["step_us"] * 1e-6) / 8e12) < 1e-9 and r["rollout_k64_env_steps_per_sec"] > 0

@@ -90,3 +90,44 @@ def test_grid_rollout_equals_single_steps(name, n, K):
             assert torch.equal(a.buf[row], b.buf[row]), row
     assert a.counters() == b.counters()
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("specialize", [False, True], ids=["generic-group-kernel", "specialised-group-unit"])
+def test_group_rollout_equals_single_group_steps(specialize):
+    """nsg_rollout_group - K fused steps of a Pendulum, an Acrobot, a FrozenLake and a full-engine CartPole member in ONE launch -
+    leaves every member exactly where K nsg_step_group launches (and K nsg_step launches per member) leave it, and records the same
+    trajectory: bit-identical rows, streams and counters."""
+    import torch
+
+    from ns_gym_amd.vec_env import VecNSEnv, rollout_group, step_group, step_group_kind
+    from tests.golden.make_golden import make_actions
+    from tests.util import TRAJ_SPECS, make_env_from_spec
+
+    names = ["c4_pendulum_m_inc", "c4_acrobot_mass2_inc", "c3_frozenlake_step50", "c2_cartpole_gravity_rw"]
+    ns = [5000, 3000, 4096, 2500]
+    K, reps = 48, 3
+    mk = lambda: [make_env_from_spec(lambda *a, **k: VecNSEnv(*a, **k), TRAJ_SPECS[nm], n=n, track_returns=True, specialize=specialize)  # noqa: E731
+                  for nm, n in zip(names, ns)]
+    fused, stepped = mk(), mk()
+    for e in fused + stepped:
+        e.reset(seed=77)
+    acts = [torch.from_numpy(make_actions(TRAJ_SPECS[nm]["env_id"], K * reps, n)).cuda() for nm, n in zip(names, ns)]
+    rec = ("obs", "reward", "terminated", "truncated", "env_change", "delta_change")
+    for r in range(reps):
+        outs = rollout_group(fused, [a[r * K:(r + 1) * K] for a in acts], record=rec)
+        for k in range(K):
+            step_group(stepped, [a[r * K + k] for a in acts])
+            for e, o in zip(stepped, outs):
+                assert torch.equal(o["reward"][k], e.reward) and torch.equal(o["terminated"][k], e.terminated) and torch.equal(o["truncated"][k], e.truncated)
+                assert torch.equal(o["obs"][k], e.state)
+                P = e.cfg.n_params
+                assert torch.equal(o["env_change"][k][:P], e.gt_env_change) and torch.equal(o["delta_change"][k][:P], e.gt_delta_change)
+    assert step_group_kind(fused) == ("specialised" if specialize else "generic-full")
+    for a, b, nm in zip(fused, stepped, names):
+        for row in ("phys", "cell", "theta", "table_prob", "t", "status", "episode", "rng_env", "rng_upd", "cursor", "obs", "reward", "terminated",
+                    "truncated", "env_change", "delta_change", "prob", "ep_return", "last_return", "last_length"):
+            if a.buf[row] is not None:
+                assert torch.equal(a.buf[row], b.buf[row]), (nm, row)
+        assert a.counters() == b.counters(), nm
+    for e in fused + stepped:
+        e.close()

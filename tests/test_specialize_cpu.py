@@ -122,8 +122,10 @@ def test_group_unit_does_not_spill_and_a_spilling_one_is_refused(monkeypatch):
     same unit forced under an 8-wavefront register bound (64 VGPRs: Acrobot's RK4 cannot fit) spills and is REFUSED, so
     nsg_step_group stays on the generic group kernel instead of launching it."""
     names = ("c4_pendulum_m_inc", "c4_acrobot_mass2_inc", "c3_frozenlake_step50")
-    for kernel, k in _notes(_build_group(names)).items():
-        assert kernel == "nsg_spec_group" and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+    notes = _notes(_build_group(names))
+    assert set(notes) == {"nsg_spec_group", "nsg_spec_group_rollout"}
+    for kernel, k in notes.items():
+        assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (kernel, k)
     monkeypatch.setenv("NSG_SPEC_FLAGS", "-DNSG_MIN_WAVES=8")
     assert "spills" in _build_group(names, expect_rc=-95)
 

@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from ns_gym_amd.vec_env import step_group  # noqa: E402
+from ns_gym_amd.vec_env import rollout_group, step_group  # noqa: E402
 
 from ns_gym_amd import workloads as W  # noqa: E402
 
@@ -92,6 +92,24 @@ def main():
         ms = e0.elapsed_time(e1) / args.iters
         gbs = (83 + 127) * n / (ms * 1e-3) / 1e9
         print("c4_group", json.dumps({"us": ms * 1e3, "GB/s": gbs, "frac": gbs / 8000, "Gsteps/s": 2 * n / (ms * 1e-3) / 1e9}), flush=True)
+        if args.rollout:   # the same pair through ONE fused launch of K steps (nsg_rollout_group)
+            K = args.rollout
+            acts = [torch.stack([actions(e, n) for _ in range(K)]) for e in (ep, ea)]
+            for _ in range(2):
+                rollout_group([ep, ea], acts)
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                reps = max(args.iters // K, 2)
+                for _ in range(reps):
+                    rollout_group([ep, ea], acts)
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / (reps * K))
+            print("c4_group_rollout", json.dumps({"us_per_step": best * 1e3, "Gsteps/s": 2 * n / (best * 1e-3) / 1e9,
+                                                  "launch": "one nsg_rollout_group launch per K steps, both members"}), flush=True)
 
 
 if __name__ == "__main__":
