@@ -122,15 +122,16 @@ def baseline_configs_at_own_size(dev, c1_step_us, c1_rollout_rate, n_c1):
 
     K = 64
     gacts = [torch.stack([W.random_actions(e) for _ in range(K)]) for e in (pend, acro)]
-    rollout_group([pend, acro], gacts)
+    for _ in range(3):
+        rollout_group([pend, acro], gacts)
     torch.cuda.synchronize()
     r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     r0.record()
-    for _ in range(4):
+    for _ in range(8):
         rollout_group([pend, acro], gacts)
     r1.record()
     torch.cuda.synchronize()
-    group_rollout_us = r0.elapsed_time(r1) * 1e3 / (4 * K)
+    group_rollout_us = r0.elapsed_time(r1) * 1e3 / (8 * K)
     by = W.WORKLOADS["pend"]["bytes_per_env_step"] + W.WORKLOADS["acro"]["bytes_per_env_step"]
     rows["C4"] = {"envs": [pend.N, acro.N], "launch": "one nsg_step_group launch (" + step_group_kind([pend, acro]) + " unit)",
                   "step_us": best, "bytes_per_env_pair_step": by, "frac_of_hbm_peak": frac(by, pend.N, best),
