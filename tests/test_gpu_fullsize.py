@@ -319,3 +319,37 @@ def test_maximum_batch_per_handle(name):
     c = big.counters()
     assert c["env_steps"] + c["episodes"] - int((big.terminated | big.truncated).sum()) == big_n * T
     big.close(); small.close()
+
+
+def test_c4_group_rollout_at_full_size_equals_group_steps():
+    """C4 at BASELINE's size through the fused group rollout: Pendulum 262 144 + Acrobot 262 144, 200 steps as 5 launches of
+    K = 40 (`nsg_rollout_group`, the specialised group unit), against the same 200 steps as single `nsg_step_group` launches -
+    which the test above holds against the oracle: every persistent row and every recorded step bit-identical."""
+    import torch
+
+    from ns_gym_amd.vec_env import rollout_group, step_group, step_group_kind
+
+    n, K, reps = 262144, 40, 5
+    names = ("c4_pendulum_m_inc", "c4_acrobot_mass2_inc")
+    fused = [make_env_from_spec(_vec, TRAJ_SPECS[nm], n=n, track_returns=True, specialize=True) for nm in names]
+    stepped = [make_env_from_spec(_vec, TRAJ_SPECS[nm], n=n, track_returns=True, specialize=True) for nm in names]
+    for e in fused + stepped:
+        e.reset(seed=4242)
+    g = torch.Generator(device="cuda").manual_seed(31)
+    for r in range(reps):
+        ap = torch.rand((K, n), device="cuda", generator=g) * 4 - 2
+        aa = torch.randint(0, 3, (K, n), dtype=torch.int32, device="cuda", generator=g)
+        outs = rollout_group(fused, [ap, aa], record=("obs", "reward", "terminated", "truncated"))
+        for k in range(K):
+            step_group(stepped, [ap[k], aa[k]])
+            if k % 13 == 0 or k == K - 1:
+                for e, o in zip(stepped, outs):
+                    assert torch.equal(o["obs"][k], e.state) and torch.equal(o["reward"][k], e.reward)
+                    assert torch.equal(o["terminated"][k], e.terminated) and torch.equal(o["truncated"][k], e.truncated)
+    assert step_group_kind(fused) == "specialised"
+    for a, b, nm in zip(fused, stepped, names):
+        for row in ("phys", "theta", "t", "episode", "obs", "reward", "terminated", "truncated", "ep_return", "last_return", "last_length"):
+            assert torch.equal(a.buf[row], b.buf[row]), (nm, row)
+        assert a.counters() == b.counters(), nm
+    for e in fused + stepped:
+        e.close()
