@@ -122,6 +122,15 @@ enum {
  * reset" IS t >= max_episode_steps, bit 0 of its word stays clear and a single step touches the word only in the lanes that reset */
 #define NSG_ST_NEEDS_RESET 0x1u
 #define NSG_EP_COUNT_SHIFT 1
+/* grid envs, bits 1-7 of the status byte: WHICH distribution buffers.table_prob holds for this env, when the config already holds
+ * it - a step then skips the table_prob rows (24-32 B per env-step).  The rows stay authoritative: every writer of table_prob
+ * (construction, a fire, nsg_fork) also sets these bits, NSG_ST_TABLE_ROWS ("read the rows") is always valid, and a caller that
+ * writes table_prob itself must clear them */
+#define NSG_ST_TABLE_SHIFT 1
+#define NSG_ST_TABLE_ROWS 0u      /* no statement: read buffers.table_prob                                       */
+#define NSG_ST_TABLE_INITIAL 1u   /* == cfg.initial_prob[0] (initial_prob_dist)                                   */
+#define NSG_ST_TABLE_LIST0 2u     /* 2 + j: == entry j of params[0]'s value list (DistributionStepWise / Cyclic)  */
+#define NSG_ST_TABLE_MAX 127u
 /* classic-control env streams: descriptor word 0 of buffers.rng_env (see there) */
 #define NSG_STREAM_AFFINE (1ULL << 63)
 
@@ -219,7 +228,7 @@ typedef struct nsg_buffers {
   int32_t* t_fork;       /* [N]    planning copies only: t at fork time.  __deepcopy__ builds a fresh
                             gym.make() env, so TimeLimit's elapsed count restarts at 0 while the
                             wrapper's t is preserved (classic_control.py:168-180)              */
-  uint8_t* status;       /* [N]    grid envs: NSG_ST_* bits (classic-control envs: NULL, see episode)          */
+  uint8_t* status;       /* [N]    grid envs: NSG_ST_NEEDS_RESET | NSG_ST_TABLE_* << 1 (classic-control envs: NULL, see episode) */
   int32_t* episode;      /* [N]    classic-control envs: NSG_ST_NEEDS_RESET | resets drawn so far << 1.  A dense row that every
                             step reads and rewrites (Pendulum: resetting lanes only, see NSG_ST_NEEDS_RESET); with it the env's
                             np_random needs NO per-env stream state (rng_env)  */

@@ -743,11 +743,27 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
     if (track && !return_is_last_reward) gl.er = ldg(b.ep_return, o4);
     pcg_load<true>(b.rng_env, N, i, gl.g);
     if constexpr (ENV != NSG_ENV_BRIDGE) {
+      // the P table of most envs is a distribution the config already holds (NSG_ST_TABLE_*): only the lanes whose status byte
+      // names none fetch their table_prob rows (C3: 24 of 114 B per env-step)
+      const unsigned hint = gl.st >> NSG_ST_TABLE_SHIFT;
+      const nsg_param_cfg& p0 = cfg.params[0];
+      const bool listed = hint >= NSG_ST_TABLE_LIST0 && (p0.upd_kind == NSG_UPD_D_STEPWISE || p0.upd_kind == NSG_UPD_D_CYCLIC) &&
+                          (int)(hint - NSG_ST_TABLE_LIST0) < p0.val_tab_len;   // (a byte that names no entry of THIS config: the rows)
+      if (hint != NSG_ST_TABLE_INITIAL && !listed) {
 #pragma unroll
-      for (int k = 0; k < ND; k++) gl.tp[k] = ldg(b.table_prob, blk_off8(ND, k, i));
+        for (int k = 0; k < ND; k++) gl.tp[k] = ldg(b.table_prob, blk_off8(ND, k, i));
+      } else if (hint == NSG_ST_TABLE_INITIAL) {
+#pragma unroll
+        for (int k = 0; k < ND; k++) gl.tp[k] = cfg.initial_prob[0][k];
+      } else {
+        const double* v = tb.vals(p0.val_tab_off) + ND * (int)(hint - NSG_ST_TABLE_LIST0);
+#pragma unroll
+        for (int k = 0; k < ND; k++) gl.tp[k] = v[k];
+      }
     }
   }
   const unsigned st = active ? gl.st : 0u;
+  unsigned table_hint = st >> NSG_ST_TABLE_SHIFT;
   const int t = active ? gl.t : 0;
   const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);
   const bool do_step = active && !do_reset;
@@ -794,7 +810,12 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       Pcg ur = {0, 0, 0, 0};
       if (FULL && pc.uses_rng) pcg_load(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, ur);
       bool exhausted;
+      const int list_entry = cursor;
       upd_dist<ND, FULL>(pc, tb, zg, pp, t, cursor, ur, q, exhausted);
+      if constexpr (ENV != NSG_ENV_BRIDGE)  // q goes into the P table below: name it in the status byte when it is list entry `list_entry`
+        table_hint = (p == 0 && (pc.upd_kind == NSG_UPD_D_STEPWISE || pc.upd_kind == NSG_UPD_D_CYCLIC) && list_entry < pc.val_tab_len &&
+                      list_entry <= (int)(NSG_ST_TABLE_MAX - NSG_ST_TABLE_LIST0))
+                         ? NSG_ST_TABLE_LIST0 + (unsigned)list_entry : NSG_ST_TABLE_ROWS;
       n_exhausted |= exhausted ? 1u : 0u;
       if (FULL && pc.uses_rng) pcg_store_state(b.rng_upd + (int64_t)pc.fn_slot * 4 * N, N, i, ur);
       if (has_cur && pc.upd_kind != NSG_UPD_D_LCBOUNDED) stg_p(io.wt, b.cursor + (int64_t)pc.fn_slot * N, o4, cursor);
@@ -910,7 +931,7 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
   if (active) {
     gl.cell = cell;
     gl.t = tnew;
-    gl.st = done ? NSG_ST_NEEDS_RESET : 0u;
+    gl.st = (done ? NSG_ST_NEEDS_RESET : 0u) | (table_hint << NSG_ST_TABLE_SHIFT);
     if (out.obs) stg_out((int32_t*)out.obs, o4, cell);  // trajectory slice (rollout); NULL for nsg_step: cell[] is the obs
     stg_out(out.reward, o4, (float)reward);
     stg_out(out.terminated, o1, (uint8_t)(term ? 1 : 0));
@@ -1128,7 +1149,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const Segment* __restrict
     b.reward[i] = 0.f;
     b.terminated[i] = 0;
     b.truncated[i] = 0;
-    if constexpr (GRID) b.status[i] = 0;
+    if constexpr (GRID) b.status[i] &= (uint8_t)~NSG_ST_NEEDS_RESET;  // the table hint stays: reset does not restore the P table
     if (cfg.flags & NSG_F_TRACK_RETURNS) {
       if (b.ep_return) b.ep_return[i] = 0.f;
       if (b.ep_length) b.ep_length[i] = 0;
@@ -1190,7 +1211,7 @@ __global__ __launch_bounds__(kBlock) void init_kernel(const Segment* __restrict_
       Pcg g;
       pcg_seed(g, (uint64_t)i, 999);
       pcg_store_all<true>(b.rng_env, N, i, g);
-      b.status[i] = 0;
+      b.status[i] = (uint8_t)((b.table_prob ? NSG_ST_TABLE_INITIAL : NSG_ST_TABLE_ROWS) << NSG_ST_TABLE_SHIFT);
     } else {
       b.episode[i] = 0;
     }
@@ -1345,7 +1366,7 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
     const bool src_from_t = env == NSG_ENV_PENDULUM && !(cfg.flags & NSG_F_SIM_ENV);
     const int src_needs_reset = fl ? 0 : src_from_t ? (cfg.max_episode_steps > 0 && t >= cfg.max_episode_steps ? 1 : 0)
                                                     : (sb.episode[is] & (int32_t)NSG_ST_NEEDS_RESET);
-    if (fl) db.status[i] = sb.status[is];
+    if (fl) db.status[i] = sb.status[is];  // (its table hint is settled with the table, below)
     else db.episode[i] = src_needs_reset;   // the copy's own stream starts at its first episode
     for (int r = 0; r < (fl ? nd * P : P); r++) {
       const double cur = sb.theta[(int64_t)r * Ns + is];
@@ -1372,6 +1393,7 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
         const bool use_initial = env == NSG_ENV_FROZENLAKE ? (in_sim_change || theta_mode == 1) : (theta_mode == 1 && !in_sim_change);
         for (int k = 0; k < nd; k++)
           db.table_prob[blk_off8(nd, k, i) / 8] = use_initial ? cfg.initial_prob[0][k] : sb.table_prob[blk_off8(nd, k, is) / 8];
+        if (use_initial) db.status[i] = (uint8_t)((sb.status[is] & NSG_ST_NEEDS_RESET) | (NSG_ST_TABLE_INITIAL << NSG_ST_TABLE_SHIFT));
       }
       if (db.prob && sb.prob) db.prob[i] = sb.prob[is];
     }
