@@ -217,10 +217,13 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
     dist = None
-    if world > 1:
+    # NSG_BENCH_FORCE_DIST=1: a single rank still opens its process group, so that the barriers, the all-gather of returns and the
+    # max-over-ranks reduction of an N = 1 run go through RCCL - the one way a one-GPU box can exercise that library at all
+    if world > 1 or os.environ.get("NSG_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -435,6 +438,7 @@ def main():
                                if world > 1 else "single GPU",
                 "episodes_finished_rank0": episodes_rank0,
                 "gathered_returns": int(gathered.numel()), "returns_gather_ms": gather_ms_max,
+                "collectives": (f"torch.distributed backend {dist.get_backend()}, {world} rank(s)" if dist is not None else "none (single process)"),
                 "value_incl_gather": value_incl_gather, "value_incl_gather_T1000": value_incl_gather_t1000,
                 "ms_per_step_clock_after_synchronize": dt_after_sync / args.steps * 1e3,
                 "timed_region": "clock read after the opening event is enqueued and again when the event behind the K-th step has completed "

@@ -63,6 +63,20 @@ def test_two_ranks_aggregate_line():
     assert d["config"]["returns_gather_ms"] > 0.0       # the end-of-rollout exchange, timed on its own
 
 
+def test_single_rank_through_rccl():
+    """NSG_BENCH_FORCE_DIST=1: one rank opens an RCCL (backend "nccl") process group anyway, so the barriers, the all-gather of
+    episode returns and the max-over-ranks reduction of the N > 1 path execute through the library a one-GPU box can otherwise
+    never reach (two ranks cannot share a device under RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NSG_BENCH_SINGLE_DEVICE", "NSG_BENCH_BACKEND")}
+    env.update(NSG_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29573")
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "40", "--warmup", "10", "--envs-per-gpu", "65536", "--no-cpu-baseline",
+                        "--no-all-configs", "--no-hbm-resident"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["collectives"] == "torch.distributed backend nccl, 1 rank(s)"
+    assert d["config"]["gathered_returns"] == 65536 and d["config"]["returns_gather_ms"] > 0.0
+
+
 def test_gpus_flag_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (here both on the one GPU of the test box,
     collectives through gloo) and prints ONE line with n_gpus = 2."""
