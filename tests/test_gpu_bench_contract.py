@@ -68,7 +68,12 @@ def test_single_rank_through_rccl():
     episode returns and the max-over-ranks reduction of the N > 1 path execute through the library a one-GPU box can otherwise
     never reach (two ranks cannot share a device under RCCL)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NSG_BENCH_SINGLE_DEVICE", "NSG_BENCH_BACKEND")}
-    env.update(NSG_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29573")
+    import socket
+
+    with socket.socket() as sock:                      # a free rendezvous port (the launcher-driven tests use fixed ones)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env.update(NSG_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     p = subprocess.run([sys.executable, "bench.py", "--steps", "40", "--warmup", "10", "--envs-per-gpu", "65536", "--no-cpu-baseline",
                         "--no-all-configs", "--no-hbm-resident"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
