@@ -7,6 +7,7 @@ NSG_ABI_VERSION = 3
 NSG_MAX_PARAMS = 8
 NSG_MAX_THETA = 8
 NSG_MAX_SEGMENTS = 8
+MAX_TABLE_BYTES = 16384   # kMaxTableBytes (csrc/nsg_kernels.hip.h): the constant-table blob a batch may stage in LDS
 
 # env types
 (ENV_CARTPOLE, ENV_PENDULUM, ENV_ACROBOT, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONT, ENV_FROZENLAKE,

@@ -34,18 +34,36 @@ class Scheduler:
         self.start = start
         self.end = end
 
+    def _check(self, t: int) -> bool:
+        """Core scheduling logic of a subclass (ns_gym/base.py:83-95): called only for start <= t <= end.  A USER-DEFINED
+        subclass defines this and nothing else; it is sampled into a bit table over t when a batch is built
+        (`ns_gym_amd.extension`).  The deterministic built-ins define it too (used when a user-defined update function behind
+        them is sampled); the stochastic built-ins draw from a per-env device stream and have no host-side answer."""
+        from ._lib import NsgError
+
+        raise NsgError(f"{type(self).__name__} defines no `_check(t)`: subclass ns_gym_amd.base.Scheduler and implement it "
+                       f"(ns_gym/base.py:83-95), or use one of ns_gym_amd.schedulers")
+
     # -- compile-time description ------------------------------------------------------
     def _compile(self, tables: "TableBuilder", horizon: int | None) -> dict:
-        raise NotImplementedError
+        """Built-in schedulers override this.  A user-defined subclass (one that defines `_check`) never gets here:
+        `spec.compile_config` samples it through `ns_gym_amd.extension.tabulate`."""
+        from ._lib import NsgError
+
+        raise NsgError(f"{type(self).__name__} cannot be compiled for the kernels: it neither is a built-in scheduler nor defines `_check(t)`")
 
     def _range(self) -> dict:
         return {"sched_start": float(self.start), "sched_end": float(self.end)}
 
-    # -- evaluation (device) -------------------------------------------------------------
+    # -- evaluation ------------------------------------------------------------------------
     def __call__(self, t: int) -> bool:
-        """`start <= t <= end and _check(t)` evaluated by the device θ-engine.  A stochastic scheduler
-        (Random, DecayingProbability, Memoryless) keeps its stream / transition_time between calls like
-        the reference object does (schedulers.py:25-28,107-116,173-177)."""
+        """`start <= t <= end and _check(t)` (ns_gym/base.py:67-81).  Built-in schedulers are evaluated by the device θ-engine;
+        a stochastic one (Random, DecayingProbability, Memoryless) keeps its stream / transition_time between calls like
+        the reference object does (schedulers.py:25-28,107-116,173-177).  A user-defined subclass runs its own `_check`."""
+        from . import extension
+
+        if extension.is_user_scheduler(self):
+            return extension.host_fires(self, t)
         from . import functional
 
         if getattr(self, "_stochastic", False):
@@ -70,7 +88,39 @@ class UpdateFn:
         self.prev_time = -1
 
     def _compile(self, tables: "TableBuilder") -> dict:
-        raise NotImplementedError
+        """Built-in update functions override this.  A user-defined subclass (one that defines `_update`) never gets here:
+        `spec.compile_config` samples its chain through `ns_gym_amd.extension.tabulate`."""
+        from ._lib import NsgError
+
+        raise NsgError(f"{type(self).__name__} cannot be compiled for the kernels: it neither is a built-in update function nor defines "
+                       f"`_update(param, t)` (ns_gym/base.py:160-170)")
+
+    def _update(self, param: Any, t: int) -> Any:
+        """The update rule of a subclass (ns_gym/base.py:160-170), called when the scheduler fires.  A USER-DEFINED subclass
+        defines this; the built-in update functions are arithmetic inside the kernels and have no host-side `_update`."""
+        from ._lib import NsgError
+
+        raise NsgError(f"{type(self).__name__}._update runs on the device only (csrc/nsg_theta.hip.h); call the object, or step a batch")
+
+    def _get_delta_change(self, param: Any, updated_param: Any, t: int) -> float:
+        """`updated_param - param` (ns_gym/base.py:172-182)."""
+        return updated_param - param
+
+    def _call_user(self, param: Any, t) -> tuple[Any, int, float]:
+        """`UpdateFn.__call__` of the reference (ns_gym/base.py:139-149) for a user-defined subclass: its own Python."""
+        import copy
+
+        from . import extension
+
+        s = self.scheduler
+        fire = extension.host_fires(s, t) if extension.has_host_check(s) else bool(s(t))
+        if fire:
+            updated = self._update(copy.copy(param), t)
+            delta = self._get_delta_change(param, updated, t)
+            self.prev_param, self.prev_time = param, t
+            return (updated, 1, delta)
+        self.prev_param, self.prev_time = param, t
+        return (param, 0, 0.0)
 
     @property
     def _uses_rng(self) -> bool:
@@ -92,8 +142,10 @@ class UpdateFn:
         assert isinstance(t, (int, float)), (
             f"Expected t to be an int or float, got {type(t)}, Arrays operations need to inherit from UpdateDistributionFn"
         )
-        from . import functional
+        from . import extension, functional
 
+        if extension.is_user_update_fn(self):
+            return self._call_user(param, t)
         if not hasattr(self, "_call_state"):
             self._call_state = {}
         th, fired, delta = functional.theta_trace(self, param, t0=int(t), T=1, state=self._call_state)
@@ -114,6 +166,12 @@ class UpdateDistributionFn(UpdateFn):
     def __call__(self, param: Any, t: Union[int, float]) -> Any:
         assert isinstance(param, list), f"param must be a list, got {type(param)}"
         return super().__call__(param, t)
+
+    def _get_delta_change(self, param: Any, updated_param: Any, t: int) -> float:
+        """1-Wasserstein distance between the two pmfs (ns_gym/base.py:192-203)."""
+        from .utils import wasserstein_distance
+
+        return wasserstein_distance(param, updated_param)
 
 
 class TableBuilder:

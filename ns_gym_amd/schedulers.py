@@ -2,7 +2,10 @@
 
 Deterministic schedulers that are pure functions of t compile either to a closed form the
 kernel evaluates (Continuous, Periodic, Burst) or to a bit table over t staged in LDS
-(Discrete, Window, Custom).
+(Discrete, Window, Custom).  Their `_check(t)` (the reference's method name, schedulers.py:52-53,73-74,88-89,139-140,197-198)
+exists for ONE purpose: when a user-defined update function sits behind such a scheduler, its θ chain is sampled on the host
+(`ns_gym_amd.extension`) and needs the fire pattern there.  Calling a built-in scheduler object evaluates it on the device.
+A user-defined scheduler is a `base.Scheduler` subclass that defines `_check` (ns_gym/base.py:83-95); see `ns_gym_amd.extension`.
 """
 from __future__ import annotations
 
@@ -19,6 +22,9 @@ class ContinuousScheduler(Scheduler):
     def __init__(self, start=0, end=np.inf) -> None:
         super().__init__(start, end)
 
+    def _check(self, t):
+        return True
+
     def _compile(self, tables, horizon):
         return {"sched_kind": A.SCHED_CONTINUOUS, **self._range()}
 
@@ -29,6 +35,9 @@ class PeriodicScheduler(Scheduler):
     def __init__(self, period: int, start=0, end=np.inf) -> None:
         super().__init__(start, end)
         self.period = period
+
+    def _check(self, t):
+        return t % self.period == 0
 
     def _compile(self, tables, horizon):
         if int(self.period) != self.period or self.period <= 0:
@@ -45,6 +54,9 @@ class BurstScheduler(Scheduler):
         self.on_duration = on_duration
         self.off_duration = off_duration
         self.cycle = on_duration + off_duration
+
+    def _check(self, t):
+        return (t % self.cycle) < self.on_duration
 
     def _compile(self, tables, horizon):
         if self.cycle <= 0:
@@ -79,6 +91,9 @@ class DiscreteScheduler(Scheduler):
         assert min(event_list) >= start, "Scheduler start time occurs after first event in event list"
         assert max(event_list) <= end, "Scheduler end time occurs before last event in event list"
 
+    def _check(self, t):
+        return t in self.event_list
+
     def _compile(self, tables, horizon):
         n, beyond = _fit_table(int(max(self.event_list)) + 1, horizon, "DiscreteScheduler")
         bits = np.zeros(max(n, 1), dtype=np.uint8)
@@ -96,6 +111,9 @@ class WindowScheduler(Scheduler):
     def __init__(self, windows: list, start=0, end=np.inf) -> None:
         super().__init__(start, end)
         self.windows = windows
+
+    def _check(self, t):
+        return any(w_start <= t <= w_end for w_start, w_end in self.windows)
 
     def _compile(self, tables, horizon):
         finite = [w_end for _, w_end in self.windows if np.isfinite(w_end)]
@@ -128,6 +146,9 @@ class CustomScheduler(Scheduler):
         super().__init__(start, end)
         self.event_function = event_function
         self.horizon = horizon
+
+    def _check(self, t):
+        return self.event_function(t)
 
     def _compile(self, tables, horizon):
         if self.horizon is not None:

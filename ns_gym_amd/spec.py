@@ -19,10 +19,33 @@ from .envs import BaseEnvSpec, from_gym_env
 _INF = "inf"
 
 
-def compile_config(env, tunable_params: dict, *, change_notification=False, delta_change_notification=False,
-                   in_sim_change=False, scalar_reward=True, persistent_params=False, track_returns=False, initial_prob_dist=None, modified_rewards=None, is_sim_env=False, terminal_cliff=False, violation_mask=False,
-                   table_horizon=None):
-    """Returns (Config, tables_blob: bytes, BaseEnvSpec, param_names)."""
+def compile_config(env, tunable_params: dict, **kwargs):
+    """Returns (Config, tables_blob: bytes, BaseEnvSpec, param_names).
+
+    User-defined schedulers / update functions (`ns_gym_amd.extension`) are sampled into tables over t = 0 .. horizon; the horizon
+    is 2 x TimeLimit (what a planning copy taken late in an episode can reach, see CustomScheduler) when the tables then fit the
+    kernels' constant-table budget, else 1 x TimeLimit (every t the batch itself can reach; a copy that runs past it is counted
+    and raised, never answered silently)."""
+    from . import extension
+    from ._lib import NsgError
+
+    user = any(extension.is_user_update_fn(fn) or extension.is_user_scheduler(getattr(fn, "scheduler", None))
+               for fn in tunable_params.values())
+    out = _compile_once(env, tunable_params, horizon_factor=2, **kwargs)
+    if user and len(out[1]) > A.MAX_TABLE_BYTES:
+        out = _compile_once(env, tunable_params, horizon_factor=1, **kwargs)
+        if len(out[1]) > A.MAX_TABLE_BYTES:
+            raise NsgError(f"the user-defined schedulers / update functions of this configuration need {len(out[1])} bytes of tables "
+                           f"(8 bytes per fire and value, over t = 0 .. TimeLimit); the kernels stage at most {A.MAX_TABLE_BYTES} per batch. "
+                           f"Fire less often, tune fewer parameters this way, or set `<object>.nsg_horizon` to a shorter reachable horizon")
+    return out
+
+
+def _compile_once(env, tunable_params: dict, *, change_notification=False, delta_change_notification=False,
+                  in_sim_change=False, scalar_reward=True, persistent_params=False, track_returns=False, initial_prob_dist=None, modified_rewards=None, is_sim_env=False, terminal_cliff=False, violation_mask=False,
+                  table_horizon=None, horizon_factor=2):
+    from . import extension
+
     spec: BaseEnvSpec = from_gym_env(env)
     et = spec.env_type
     if delta_change_notification:
@@ -115,12 +138,30 @@ def compile_config(env, tunable_params: dict, *, change_notification=False, delt
     first_fn = {id(fn): min(k for k, g in enumerate(fns) if g is fn) for fn in fns}
     last_fn = {id(fn): max(k for k, g in enumerate(fns) if g is fn) for fn in fns}
     first_sched = {id(fn.scheduler): min(k for k, g in enumerate(fns) if g.scheduler is fn.scheduler) for fn in fns}
-    for j, (name, fn) in enumerate(tunable_params.items()):
+    for name, fn in tunable_params.items():
         assert isinstance(fn, UpdateFn), f"tunable_params[{name!r}] must be an UpdateFn, got {type(fn)}"
         if is_fl:
             assert isinstance(fn, UpdateDistributionFn), f"{spec.class_name} '{name}' needs an UpdateDistributionFn"
         else:
             assert not isinstance(fn, UpdateDistributionFn), f"{name}: scalar parameter needs a scalar UpdateFn"
+    # `table_horizon`: how far sampled schedules must reach when the caller knows the t it will ask about (host-side
+    # `scheduler(t)` / `fn(param, t)` calls); a batch derives it from its TimeLimit
+    horizon = table_horizon or (horizon_factor * cfg.max_episode_steps if cfg.max_episode_steps > 0 else None)
+    # user-defined Scheduler / UpdateFn subclasses (ns_gym/base.py:50-203): their chain, sampled on the host in the reference's
+    # call order, goes into the table kinds below (ns_gym_amd.extension)
+    if is_fl:
+        if spec.class_name == "Bridge":
+            theta0 = {n: (list(left) if n != "P_right" else list(right)) for n in names}
+        else:
+            theta0 = {n: list(ipd) for n in names}
+        all_theta = {}
+    else:
+        all_theta = {n: float(cfg.base_theta[k]) for k, n in enumerate(et.theta_names)}
+        theta0 = {n: all_theta[n] for n in names}
+    sampled = extension.tabulate(tunable_params, class_name=spec.class_name, theta0=theta0, all_theta=all_theta,
+                                 n_dist=nd if is_fl else 0, horizon=extension.horizon_hint(tunable_params) or horizon,
+                                 persistent=bool(persistent_params))
+    for j, (name, fn) in enumerate(tunable_params.items()):
         pc = cfg.params[j]
         pc.theta_slot = et.theta_names.index(name)
         pc.rng_child = last_fn[id(fn)]
@@ -128,10 +169,22 @@ def compile_config(env, tunable_params: dict, *, change_notification=False, delt
         pc.sched_slot = first_sched[id(fn.scheduler)]
         pc.sched_end = float("inf")
         fields = {}
-        # `table_horizon`: how far sampled (Custom) schedulers must reach when the caller knows the t it will ask about
-        # (host-side `scheduler(t)` / `fn(param, t)` calls); a batch derives it from its TimeLimit
-        fields.update(fn.scheduler._compile(tables, table_horizon or (2 * cfg.max_episode_steps if cfg.max_episode_steps > 0 else None)))
-        fields.update(fn._compile(tables))
+        tab = sampled.get(name)
+        if tab is None:
+            fields.update(fn.scheduler._compile(tables, horizon))
+            fields.update(fn._compile(tables))
+        else:
+            # the sampled fire pattern: a bit table whose answer beyond its end is "unknown" (counted, raised by the host)
+            off, ln = tables.add_bits(tab.fired)
+            fields.update(sched_kind=A.SCHED_TABLE, sched_tab_off=off, sched_tab_len=ln, sched_i0=2, **fn.scheduler._range())
+            pc.sched_slot = j          # a table has no state to share
+            if tab.values is None:     # built-in update function behind a user-defined scheduler
+                fields.update(fn._compile(tables))
+            else:                      # the sampled proposals, consumed in fire order (its own cursor: a shared object gets one list per name)
+                pc.fn_slot = pc.rng_child = j
+                flat = [x for row in tab.values for x in row] if is_fl else list(tab.values)
+                off, _ = tables.add_values(flat or [0.0] * 4)
+                fields.update(upd_kind=A.UPD_D_STEPWISE if is_fl else A.UPD_STEPWISE, val_tab_off=off, val_tab_len=len(tab.values))
         for key, val in fields.items():
             if key == "u":
                 for q, x in enumerate(val):

@@ -50,7 +50,7 @@ class VecNSEnv:
     def __init__(self, env, tunable_params: dict, num_envs: int, change_notification: bool = False,
                  delta_change_notification: bool = False, in_sim_change: bool = False, scalar_reward: bool = True,
                  persistent_params: bool = False, track_returns: bool = False, device=None, is_sim_env: bool = False,
-                 violation_mask: bool = False, specialize: bool | None = None,
+                 violation_mask: bool = False, specialize: bool | None = None, _compiled=None,
                  **kwargs):
         """`specialize=True` compiles config-specialised step / rollout kernels for this batch (hiprtc, once per
         distinct configuration, ~0.6 s; the code objects persist in `NSG_SPEC_CACHE=<dir>`, default the user's cache directory): same results bit
@@ -64,11 +64,23 @@ class VecNSEnv:
         if self.device.index is None:
             self.device = torch.device(f"cuda:{torch.cuda.current_device()}")
         self._dev_index = self.device.index
-        self.cfg, self.tables, self.spec, self.param_names = compile_config(
-            env, tunable_params, change_notification=change_notification,
-            delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
-            scalar_reward=scalar_reward, persistent_params=persistent_params, track_returns=track_returns,
-            is_sim_env=is_sim_env, violation_mask=violation_mask, **kwargs)
+        if _compiled is None:
+            self.cfg, self.tables, self.spec, self.param_names = compile_config(
+                env, tunable_params, change_notification=change_notification,
+                delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
+                scalar_reward=scalar_reward, persistent_params=persistent_params, track_returns=track_returns,
+                is_sim_env=is_sim_env, violation_mask=violation_mask, **kwargs)
+        else:
+            # a planning copy (fork): the SOURCE's compiled configuration with the copy's own flags and TimeLimit.  Nothing is
+            # compiled again - sampled schedules (CustomScheduler, user-defined subclasses: ns_gym_amd.extension) must be the very
+            # tables the source steps with, whatever has happened to the user's Python objects since the source was built
+            from .envs import from_gym_env
+
+            src_cfg, self.tables, _, self.param_names = _compiled
+            self.spec = from_gym_env(env)
+            self.cfg = A.Config.from_buffer_copy(bytes(src_cfg))
+            self.cfg.flags = (src_cfg.flags & ~(A.F_SIM_ENV | A.F_IN_SIM_CHANGE)) | (A.F_SIM_ENV if is_sim_env else 0) | (A.F_IN_SIM_CHANGE if in_sim_change else 0)
+            self.cfg.max_episode_steps = int(self.spec.max_episode_steps) if self.spec.max_episode_steps else 0
         self._ctor = dict(env=env, tunable_params=tunable_params, num_envs=num_envs, change_notification=change_notification,
                           delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
                           scalar_reward=scalar_reward, persistent_params=persistent_params, track_returns=track_returns,
@@ -138,6 +150,13 @@ class VecNSEnv:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.nsg_specialize(self._h), "nsg_specialize")
         return self
+
+    @property
+    def has_user_defined_updates(self) -> bool:
+        """Some tunable parameter is driven by a user-defined `UpdateFn` subclass (its chain is a sampled table: ns_gym_amd.extension)."""
+        from . import extension
+
+        return any(extension.is_user_update_fn(fn) for fn in self.tunable_params.values())
 
     @property
     def specialized(self) -> bool:
@@ -463,6 +482,12 @@ class VecNSEnv:
 
         if entropy is None:
             entropy = int.from_bytes(os.urandom(8), "little")
+        if int(theta_mode) == 1 and self.in_sim_change and self.has_user_defined_updates:
+            # get_planning_env() without delta notification hands the copy the INITIAL θ at the source's t, and with in_sim_change
+            # the copy keeps calling `_update` from there: a chain that starts somewhere the sampled one never was
+            raise _lib.NsgError("a planning copy that restarts from the initial θ (get_planning_env without delta_change_notification) and keeps "
+                                "evolving (in_sim_change=True) leaves the θ chain a user-defined update function was sampled over: use "
+                                "delta_change_notification=True (the copy continues the source's chain) or in_sim_change=False (frozen copy)")
         if into is not None:
             assert into.is_sim_env and into.N % self.N == 0 and getattr(into, "_fork_parent", None) is self._fork_root(), \
                 "`into` must be a planning copy previously forked from this env"
@@ -480,7 +505,7 @@ class VecNSEnv:
             import dataclasses
 
             kw["env"] = dataclasses.replace(self.spec, max_episode_steps=1000)
-        dst = VecNSEnv(**kw)
+        dst = VecNSEnv(**kw, _compiled=(self.cfg, self.tables, self.spec, self.param_names))
         with torch.cuda.device(self.device):
             _lib.check(self.lib.nsg_fork(self._h, dst._h, C.c_uint64(entropy & (2**64 - 1)), int(theta_mode), self._stream),
                        "nsg_fork")

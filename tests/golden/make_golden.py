@@ -184,7 +184,13 @@ DIST_UPDATE_SPECS = {
 
 
 def build_params(S, U, params_spec):
-    """tunable_params dict of REFERENCE objects; `same_as` / `scheduler_of` share one object between entries."""
+    """tunable_params dict of REFERENCE objects; `same_as` / `scheduler_of` share one object between entries.
+    Specs that name "user:" classes build them on the REFERENCE's base classes (tests/golden/user_plugins.py)."""
+    if any(str(fs.get(k, [""])[0]).startswith("user:") for fs in params_spec.values() for k in ("scheduler", "update")):
+        import ns_gym.base as ref_base
+        from tests.golden import user_plugins
+
+        return user_plugins.build_params(ref_base, S, U, params_spec)
     out = {}
     for name, fs in params_spec.items():
         if "same_as" in fs:
@@ -428,6 +434,45 @@ TRAJ_SPECS = {
         "wrapper_kwargs": {"initial_prob_dist": [0.8, 0.1, 0.1],
                            "modified_rewards": {"H": -1, "G": 1, "F": 0, "S": 0}},
         "flags": {"change_notification": True, "delta_change_notification": False},
+    },
+}
+
+
+# User-defined Scheduler / UpdateFn subclasses - the reference's extension idiom (base.py:50-203, tutorial.ipynb cells 38-44) -
+# driven by the REFERENCE wrappers.  The classes live in tests/golden/user_plugins.py (one definition, built on ns_gym.base here
+# and on ns_gym_amd.base in the tests).
+USER_SPECS = {
+    # an Every-5 `_check` with a custom scalar `_update` that runs into the constraint checker; ONE stateful scheduler object shared
+    # by a built-in update fn and a user-defined one (called twice per step, in dict order); prev_param bookkeeping
+    "user_cartpole_every5_custom": {
+        "env_id": "CartPole-v1", "T": 400, "seeds": [0, 1, 2, 3],
+        "params": {
+            "masscart": {"scheduler": ["user:Every", {"every": 5}], "update": ["user:Sawtooth", {"up": 0.25, "down": 0.6, "block": 5}]},
+            "force_mag": {"scheduler": ["user:EveryNthCall", {"n": 3}], "update": ["IncrementUpdate", {"k": 0.5}]},
+            "length": {"scheduler_of": "force_mag", "update": ["user:Momentum", {"k": 0.002, "beta": 0.5}]},
+            "gravity": {"scheduler": ["user:SeededCoin", {"p": 0.3, "seed": 11, "start": 2}], "update": ["RandomWalk", {"sigma": 0.2}]},
+        },
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    # the tutorial's oscillating slip updater on FrozenLake, made deterministic (its scheduler there draws from the global RNG)
+    "user_frozenlake_oscillating": {
+        "env_id": "FrozenLake-v1", "make_kwargs": {"map_name": "4x4", "is_slippery": False, "max_episode_steps": 50}, "T": 260,
+        "seeds": list(range(8)),
+        "params": {"P": {"scheduler": ["user:EveryNthCall", {"n": 7}], "update": ["user:OscillatingSlip", {"head": 0.4}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [1, 0, 0]},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "user_frozenlake_sharpen": {
+        "env_id": "FrozenLake-v1", "make_kwargs": {"map_name": "8x8", "is_slippery": False}, "T": 260, "seeds": [20, 21, 22, 23],
+        "params": {"P": {"scheduler": ["PeriodicScheduler", {"period": 4}], "update": ["user:Sharpen", {"floor": 0.05}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [0.5, 0.3, 0.2]},
+        "flags": {"change_notification": True, "delta_change_notification": False},
+    },
+    "user_pendulum_momentum": {
+        "env_id": "Pendulum-v1", "T": 450, "seeds": [5, 6, 7],
+        "params": {"l": {"scheduler": ["ContinuousScheduler", {"start": 3, "end": 150}], "update": ["user:Momentum", {"k": -0.004, "beta": 0.9}]},
+                   "g": {"scheduler": ["user:Every", {"every": 7}], "update": ["DecrementUpdate", {"k": 0.4}]}},
+        "flags": {"change_notification": True, "delta_change_notification": True},
     },
 }
 
@@ -876,13 +921,17 @@ def main():
     warnings.simplefilter("ignore")
     gym, S, U, CC, FL = _bind_reference()
     only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only-traj=")]
+    if "--only-user" in sys.argv:
+        only = list(USER_SPECS)
     if only:   # add trajectory fixtures without touching the others (the manifest is rewritten: it lists every spec)
         for name in only:
-            rec = gen_trajectory(gym, S, U, CC, FL, TRAJ_SPECS[name])
+            rec = gen_trajectory(gym, S, U, CC, FL, {**TRAJ_SPECS, **USER_SPECS}[name])
             np.savez_compressed(os.path.join(HERE, f"traj_{name}.npz"), **rec)
-            print(name, "episodes:", int(rec["was_reset"].sum()), "fired:", int(rec["gt_env_change"].sum()))
+            print(name, "episodes:", int(rec["was_reset"].sum()), "fired:", int(rec["gt_env_change"].sum()),
+                  "rejected-or-silent steps:", int((rec["gt_env_change"] == 0).sum()))
         man = json.load(open(os.path.join(HERE, "manifest.json")))
         man["traj_specs"] = TRAJ_SPECS
+        man["user_specs"] = USER_SPECS
         with open(os.path.join(HERE, "manifest.json"), "w") as f:
             json.dump(man, f, indent=1)
         return
@@ -899,6 +948,7 @@ def main():
         "scalar_update_specs": SCALAR_UPDATE_SPECS,
         "dist_update_specs": DIST_UPDATE_SPECS,
         "traj_specs": TRAJ_SPECS,
+        "user_specs": USER_SPECS,
         "planning_specs": PLANNING_SPECS,
         "grid_specs": GRID_SPECS,
     }
@@ -906,6 +956,10 @@ def main():
     np.savez_compressed(os.path.join(HERE, "schedulers.npz"), **gen_schedulers(S))
     np.savez_compressed(os.path.join(HERE, "update_traces.npz"), **gen_update_traces(S, U))
     for name, spec in TRAJ_SPECS.items():
+        rec = gen_trajectory(gym, S, U, CC, FL, spec)
+        np.savez_compressed(os.path.join(HERE, f"traj_{name}.npz"), **rec)
+        print(name, "episodes:", int(rec["was_reset"].sum()), "fired:", int(rec["gt_env_change"].sum()))
+    for name, spec in USER_SPECS.items():
         rec = gen_trajectory(gym, S, U, CC, FL, spec)
         np.savez_compressed(os.path.join(HERE, f"traj_{name}.npz"), **rec)
         print(name, "episodes:", int(rec["was_reset"].sum()), "fired:", int(rec["gt_env_change"].sum()))

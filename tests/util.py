@@ -21,12 +21,30 @@ def load(name):
     return np.load(os.path.join(GOLDEN, name))
 
 
+USER_SPECS = MANIFEST.get("user_specs", {})
+
+
+def build_params(params_spec):
+    """tunable_params of THIS package's classes from a neutral spec; "user:" class names are the user-defined subclasses of
+    tests/golden/user_plugins.py built on ns_gym_amd.base (the reference-side fixtures built the same classes on ns_gym.base)."""
+    from ns_gym_amd.spec import build_tunable_params
+
+    if any(str(fs.get(k, [""])[0]).startswith("user:") for fs in params_spec.values() for k in ("scheduler", "update")):
+        import ns_gym_amd.base as base
+        import ns_gym_amd.schedulers as S
+        import ns_gym_amd.update_functions as U
+        from tests.golden import user_plugins
+
+        return user_plugins.build_params(base, S, U, params_spec)
+    return build_tunable_params(params_spec)
+
+
 def make_env_from_spec(factory, spec, n=None, seeds=None, **extra):
     from ns_gym_amd.envs import make
     from ns_gym_amd.spec import build_tunable_params
 
     env = make(spec["env_id"], **spec.get("make_kwargs", {}))
-    tp = build_tunable_params(spec["params"])
+    tp = build_params(spec["params"])
     n = n if n is not None else len(spec["seeds"])
     kw = {**spec["flags"], **spec.get("wrapper_kwargs", {}), **extra}
     return factory(env, tp, n, **kw)
