@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define NSG_ABI_VERSION 3
+#define NSG_ABI_VERSION 4 /* 4: NSG_F_NO_AUTORESET; the grid status byte carries a table hint (NSG_ST_TABLE_*), Pendulum's episode
+                             word no needs-reset bit (round 3, not re-versioned then); nsg_table_prob_dirty */
 #define NSG_MAX_PARAMS 8 /* tunable params per env (Acrobot has 8: ns_gym/base.py:622-631) */
 #define NSG_MAX_THETA 8
 #define NSG_MAX_SEGMENTS 8 /* env-type segments of one heterogeneous launch */
@@ -115,6 +116,13 @@ enum {
 #define NSG_F_TERMINAL_CLIFF 0x100u /* CliffWalking terminal_cliff (toy_text.py:39,126-128)              */
 #define NSG_F_SIM_ENV 0x40u        /* planning copy: is_sim_env (base.py:270, classic_control.py:184)   */
 #define NSG_F_IN_SIM_CHANGE 0x80u  /* in_sim_change: θ keeps evolving inside planning copies            */
+#define NSG_F_NO_AUTORESET 0x400u  /* a finished env is NOT reset by the next step: it keeps stepping exactly like the reference's single
+                                      wrappers, which forward to gymnasium whatever `done` said (base.py:313): CartPole integrates on and pays
+                                      0.0 from the second terminated step (steps_beyond_terminated), TimeLimit keeps reporting truncated,
+                                      FrozenLake's terminal cell self-loops and still consumes its draw (toy_text.py:435-436), θ-engine and t
+                                      run on.  Bit 0 of the episode word then means "terminated at an earlier step of this episode".  Only
+                                      nsg_reset / nsg_reset_seeded start a new episode.  Not combinable with NSG_F_TRACK_RETURNS (episode
+                                      accounting is defined by the autoreset) */
 
 /* per-env status: grid envs keep a byte (buffers.status); classic-control envs keep an episode WORD (buffers.episode):
  * bit 0 = NSG_ST_NEEDS_RESET, bits 1-31 = how many resets the env has drawn from its np_random stream so far (= the index of
@@ -416,6 +424,10 @@ int nsg_theta_trace_stateful(nsg_handle* h, int32_t p, int32_t n, int32_t t0, in
  * out [count][n].  state_out [n][4] records, may be NULL. */
 int nsg_rng_fill(int32_t kind, const uint64_t* seeds_dev, int32_t n, int32_t spawn_key, int32_t count,
                  void* out_dev, uint64_t* state_out_dev, void* stream);
+
+/* A caller that writes buffers.table_prob itself (grid envs) calls this afterwards: it clears the table hint of every env's status
+ * byte (NSG_ST_TABLE_ROWS), so that the next step reads the rows instead of the distribution the byte still named. */
+int nsg_table_prob_dirty(nsg_handle* h, void* stream);
 
 /* Done-mask compaction: expands the ballot words of the last step into a dense list of env
  * indices (order unspecified).  idx_out_dev: int32[N], count_out_dev: uint64[1] (zeroed here). */

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-NSG_ABI_VERSION = 3
+NSG_ABI_VERSION = 4
 NSG_MAX_PARAMS = 8
 NSG_MAX_THETA = 8
 NSG_MAX_SEGMENTS = 8
@@ -36,6 +36,7 @@ F_VIOLATION_MASK = 0x200
 F_TERMINAL_CLIFF = 0x100
 F_SIM_ENV = 0x40
 F_IN_SIM_CHANGE = 0x80
+F_NO_AUTORESET = 0x400
 
 ST_NEEDS_RESET = 0x1
 EP_COUNT_SHIFT = 1          # episode word of the classic-control envs: resets drawn so far << 1 | needs-reset

@@ -375,7 +375,10 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   // its word carries the count only, a single step reads it in the lanes that reset (all of them on the same launch when the
   // batch was started together, none on the other 199) and rewrites it there - 8 B per env-step less in dense rows.  Planning
   // copies (TimeLimit counted from the fork; a copy of a finished env must still reset first) keep the stored bit.
-  const bool reset_from_t = T::NEVER_TERMINATES && !sim;
+  // NSG_F_NO_AUTORESET (gymnasium after `done`, what the reference's single wrappers do: base.py:313): nothing resets inside a step;
+  // bit 0 of the episode word then means "terminated at an earlier step of this episode" (CartPole's steps_beyond_terminated)
+  const bool noauto = (cfg.flags & NSG_F_NO_AUTORESET) != 0;
+  const bool reset_from_t = T::NEVER_TERMINATES && !sim && !noauto;
   unsigned st;
   bool do_reset;
   if (reset_from_t) {
@@ -384,7 +387,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     st = !active ? 0u : !io.load ? ls.st : (do_reset || io.lds_rng) ? (unsigned)ldg(b.episode, o4) & ~NSG_ST_NEEDS_RESET : 0u;
   } else {
     st = !active ? 0u : io.load ? (unsigned)ldg(b.episode, o4) : ls.st;
-    do_reset = active && (st & NSG_ST_NEEDS_RESET);
+    do_reset = active && (st & NSG_ST_NEEDS_RESET) && !noauto;
   }
   const bool do_step = active && !do_reset;
   const bool ld_state = NSG_UNCOND_LOADS ? active : do_step;
@@ -540,6 +543,10 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   }
   if (do_step) {
     term = env_step<ENV>(th, s, ai, af, reward);
+    if constexpr (ENV == NSG_ENV_CARTPOLE) {
+      // CartPoleEnv.step [UPSTREAM]: a step that finds the pole down AGAIN (steps_beyond_terminated is not None) pays 0.0
+      if (noauto && term && (st & NSG_ST_NEEDS_RESET)) reward = 0.0;
+    }
     tnew = t + 1;  // base.py:314
     // TimeLimit [UPSTREAM] counts the steps of ITS env: a planning copy restarts at the fork
     const int elapsed = tnew - (sim ? ls.tf : 0);
@@ -637,7 +644,8 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   }
 
   // a reset consumed one more episode of the env's stream
-  const unsigned stw = (done && !reset_from_t ? NSG_ST_NEEDS_RESET : 0u) | (((st >> NSG_EP_COUNT_SHIFT) + (do_reset ? 1u : 0u)) << NSG_EP_COUNT_SHIFT);
+  const unsigned bit0 = noauto ? ((st & NSG_ST_NEEDS_RESET) | (term ? NSG_ST_NEEDS_RESET : 0u)) : (done && !reset_from_t ? NSG_ST_NEEDS_RESET : 0u);
+  const unsigned stw = bit0 | (((st >> NSG_EP_COUNT_SHIFT) + (do_reset ? 1u : 0u)) << NSG_EP_COUNT_SHIFT);
 #pragma unroll
   for (int k = 0; k < T::PHYS; k++) ls.s[k] = s[k];
   ls.t = tnew;
@@ -765,7 +773,9 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
   const unsigned st = active ? gl.st : 0u;
   unsigned table_hint = st >> NSG_ST_TABLE_SHIFT;
   const int t = active ? gl.t : 0;
-  const bool do_reset = active && (st & NSG_ST_NEEDS_RESET);
+  // NSG_F_NO_AUTORESET: a finished env keeps stepping like gymnasium's (FrozenLake: the terminal cell's one-entry self-loop row,
+  // which still consumes its draw - toy_text.py:435-436; CliffWalking / Bridge: an ordinary move from the terminal cell)
+  const bool do_reset = active && (st & NSG_ST_NEEDS_RESET) && !(cfg.flags & NSG_F_NO_AUTORESET);
   const bool do_step = active && !do_reset;
 
   int cell = do_step ? gl.cell : 0;
@@ -1366,8 +1376,10 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
     const bool src_from_t = env == NSG_ENV_PENDULUM && !(cfg.flags & NSG_F_SIM_ENV);
     const int src_needs_reset = fl ? 0 : src_from_t ? (cfg.max_episode_steps > 0 && t >= cfg.max_episode_steps ? 1 : 0)
                                                     : (sb.episode[is] & (int32_t)NSG_ST_NEEDS_RESET);
-    if (fl) db.status[i] = sb.status[is];  // (its table hint is settled with the table, below)
-    else db.episode[i] = src_needs_reset;   // the copy's own stream starts at its first episode
+    // NSG_F_NO_AUTORESET: the copy is a NEW base env that was reset (classic_control.py:168-178): it has not terminated yet
+    const bool noauto = (ds.cfg.flags & NSG_F_NO_AUTORESET) != 0;
+    if (fl) db.status[i] = noauto ? (uint8_t)(sb.status[is] & ~NSG_ST_NEEDS_RESET) : sb.status[is];  // (its table hint is settled with the table, below)
+    else db.episode[i] = noauto ? 0 : src_needs_reset;   // the copy's own stream starts at its first episode
     for (int r = 0; r < (fl ? nd * P : P); r++) {
       const double cur = sb.theta[(int64_t)r * Ns + is];
       const double init = fl ? grid_initial(cfg, r / nd)[r % nd] : cfg.base_theta[cfg.params[r].theta_slot];

@@ -61,6 +61,8 @@ int validate(const nsg_config* cfg, size_t table_bytes) {
   if (cfg->env_type < 0 || cfg->env_type >= NSG_ENV_COUNT) return fail(NSG_EINVAL, "bad env_type %d", cfg->env_type);
   if (cfg->n_params < 0 || cfg->n_params > NSG_MAX_PARAMS) return fail(NSG_EINVAL, "bad n_params %d", cfg->n_params);
   if (table_bytes > (size_t)kMaxTableBytes) return fail(NSG_EINVAL, "constant tables are %zu bytes, limit %d", table_bytes, kMaxTableBytes);
+  if ((cfg->flags & NSG_F_NO_AUTORESET) && (cfg->flags & NSG_F_TRACK_RETURNS))
+    return fail(NSG_EINVAL, "NSG_F_TRACK_RETURNS needs the autoreset (an episode's return is closed by the step that resets it); not combinable with NSG_F_NO_AUTORESET");
   const bool fl = is_grid_env(cfg->env_type);
   if (fl) {
     if (cfg->env_type != NSG_ENV_BRIDGE && cfg->n_params != 1) return fail(NSG_EINVAL, "FrozenLake / CliffWalking take exactly one tunable parameter (P)");
@@ -137,7 +139,7 @@ struct nsg_handle {
   // process (a new handle at a recycled address is a different member), `generation` counts the launch-relevant changes of
   // THIS handle (nsg_bind, nsg_specialize) - other handles coming and going (planning copies) leave a group's plan alone.
   uint64_t id = 0;
-  uint64_t generation = 0;
+  std::atomic<uint64_t> generation{0};   // written by nsg_bind / nsg_specialize of this handle, read by group planning under its mutex
 };
 
 namespace {
@@ -398,9 +400,8 @@ int nsg_create(const nsg_config* cfg, const void* tables, size_t table_bytes, in
   if (table_bytes && !tables) return fail(NSG_EINVAL, "tables is NULL");
   int rc = validate(cfg, table_bytes);
   if (rc) return rc;
-  nsg_handle* h = new (std::nothrow) nsg_handle();
+  nsg_handle* h = new (std::nothrow) nsg_handle();   // value-initialised: every member starts at zero / null
   if (!h) return fail(NSG_ENOMEM, "out of host memory");
-  memset(h, 0, sizeof(*h));
   h->n = n;
   h->id = g_next_handle_id++;
   // any failure below releases what was allocated so far (nsg_destroy frees the three device blocks and the handle)
@@ -934,6 +935,21 @@ int nsg_seed_streams(nsg_handle* h, const uint64_t* seeds_dev, int32_t which, vo
     hipLaunchKernelGGL(stream_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, h->dev, 0ULL, 0ULL);
   }
   hipLaunchKernelGGL(seed_streams_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, (hipStream_t)stream, h->dev, seeds_dev, which);
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
+// The caller wrote buffers.table_prob itself: no status byte may go on naming a config-held distribution
+__global__ void table_hint_clear_kernel(uint8_t* status, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    status[i] &= (uint8_t)NSG_ST_NEEDS_RESET;   // NSG_ST_TABLE_ROWS: read the rows
+}
+
+int nsg_table_prob_dirty(nsg_handle* h, void* stream) {
+  if (!h) return fail(NSG_EINVAL, "handle is NULL");
+  if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
+  if (!h->host.buf.table_prob || !h->host.buf.status) return NSG_OK;   // this env type keeps no P-table rows
+  hipLaunchKernelGGL(table_hint_clear_kernel, dim3(grid_for(h->n)), dim3(kBlock), 0, (hipStream_t)stream, h->host.buf.status, h->n);
   HIP_TRY(hipGetLastError());
   return NSG_OK;
 }

@@ -43,7 +43,7 @@ def compile_config(env, tunable_params: dict, **kwargs):
 
 def _compile_once(env, tunable_params: dict, *, change_notification=False, delta_change_notification=False,
                   in_sim_change=False, scalar_reward=True, persistent_params=False, track_returns=False, initial_prob_dist=None, modified_rewards=None, is_sim_env=False, terminal_cliff=False, violation_mask=False,
-                  table_horizon=None, horizon_factor=2):
+                  table_horizon=None, horizon_factor=2, autoreset=True):
     from . import extension
 
     spec: BaseEnvSpec = from_gym_env(env)
@@ -81,6 +81,8 @@ def _compile_once(env, tunable_params: dict, *, change_notification=False, delta
         flags |= A.F_SIM_ENV
     if violation_mask:
         flags |= A.F_VIOLATION_MASK
+    if not autoreset:
+        flags |= A.F_NO_AUTORESET
     tables = TableBuilder()
     tables.nd = nd
     if is_fl:

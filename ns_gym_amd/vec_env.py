@@ -50,12 +50,18 @@ class VecNSEnv:
     def __init__(self, env, tunable_params: dict, num_envs: int, change_notification: bool = False,
                  delta_change_notification: bool = False, in_sim_change: bool = False, scalar_reward: bool = True,
                  persistent_params: bool = False, track_returns: bool = False, device=None, is_sim_env: bool = False,
-                 violation_mask: bool = False, specialize: bool | None = None, _compiled=None,
+                 violation_mask: bool = False, specialize: bool | None = None, autoreset: bool = True, _compiled=None,
                  **kwargs):
         """`specialize=True` compiles config-specialised step / rollout kernels for this batch (hiprtc, once per
         distinct configuration, ~0.6 s; the code objects persist in `NSG_SPEC_CACHE=<dir>`, default the user's cache directory): same results bit
         for bit, 10-35 % less time per step.  `False`: the precompiled generic kernels.  `None` (default): specialise
-        batches of >= 65 536 envs when the runtime compiler is available, silently stay generic otherwise."""
+        batches of >= 65 536 envs when the runtime compiler is available, silently stay generic otherwise.
+
+        `autoreset=True` (default): gymnasium's next-step vector autoreset - the step after an episode ended resets that env
+        (reward 0, flags clear, relative_time 0, streams continue).  `autoreset=False`: nothing resets inside `step()`; a finished
+        env keeps stepping exactly like the reference's single wrappers, which forward to gymnasium whatever `done` said
+        (ns_gym/base.py:313): CartPole integrates on and pays 0.0 from its second terminated step, TimeLimit keeps reporting
+        `truncated`, FrozenLake's terminal cell self-loops, θ and `relative_time` keep evolving - until `reset()` is called."""
         self.lib = _lib.load()
         self._row_cache = {}
         if not torch.cuda.is_available():
@@ -69,7 +75,7 @@ class VecNSEnv:
                 env, tunable_params, change_notification=change_notification,
                 delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
                 scalar_reward=scalar_reward, persistent_params=persistent_params, track_returns=track_returns,
-                is_sim_env=is_sim_env, violation_mask=violation_mask, **kwargs)
+                is_sim_env=is_sim_env, violation_mask=violation_mask, autoreset=autoreset, **kwargs)
         else:
             # a planning copy (fork): the SOURCE's compiled configuration with the copy's own flags and TimeLimit.  Nothing is
             # compiled again - sampled schedules (CustomScheduler, user-defined subclasses: ns_gym_amd.extension) must be the very
@@ -84,13 +90,14 @@ class VecNSEnv:
         self._ctor = dict(env=env, tunable_params=tunable_params, num_envs=num_envs, change_notification=change_notification,
                           delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
                           scalar_reward=scalar_reward, persistent_params=persistent_params, track_returns=track_returns,
-                          device=device, violation_mask=violation_mask, specialize=specialize, **kwargs)
+                          device=device, violation_mask=violation_mask, specialize=specialize, autoreset=autoreset, **kwargs)
         self.tunable_params = tunable_params
         self.change_notification = change_notification
         self.delta_change_notification = delta_change_notification
         self.in_sim_change = in_sim_change
         self.scalar_reward = scalar_reward
         self.persistent_params = persistent_params
+        self.autoreset = bool(autoreset)
         self.frozen = False
         self.is_sim_env = bool(is_sim_env)
         self.has_reset = False

@@ -88,6 +88,9 @@ class _NSSingle:
         self._act = None
         self._host = None
         kwargs.setdefault("violation_mask", True)   # the per-step rejected-update row feeds the ConstraintViolationWarning
+        # a single wrapper never resets on its own: step() after `done` goes on exactly like the reference's, which forwards to
+        # gymnasium (base.py:313) - the reference's own tests step without looking at `done` (tests/test_step_reset.py:570-577)
+        kwargs.setdefault("autoreset", False)
         self._vec = _vec if _vec is not None else VecNSEnv(
             self.spec, tunable_params, 1, change_notification=change_notification,
             delta_change_notification=delta_change_notification, in_sim_change=in_sim_change, **kwargs)
@@ -107,7 +110,6 @@ class _NSSingle:
             self.observation_space = self.observation_space.to_gymnasium()
         except ImportError:
             pass
-        self._done = False
 
     # state mirrored from the vector env
     t = property(lambda self: int(self._vec.t[0].item()))
@@ -137,7 +139,6 @@ class _NSSingle:
 
     def reset(self, *, seed: int | None = None, options: dict | None = None):
         self._vec.reset(seed=None if seed is None else [int(seed)], options=options)
-        self._done = False
         o, inf = self._scalars()
         # the reference's reset info carries the zero dicts (base.py:397-408)
         return o, inf
@@ -150,13 +151,6 @@ class _NSSingle:
             self._act = torch.zeros(1, dtype=torch.float32 if v.action_is_float else torch.int32).pin_memory()
             self._act_np = self._act.numpy()
         self._act_np[0] = float(np.asarray(action, dtype=np.float64).reshape(-1)[0]) if v.action_is_float else int(action)
-        if self._done:
-            # The reference leaves a step() after the episode has ended to gymnasium (undefined there: CartPole warns and keeps
-            # integrating, a TimeLimit keeps reporting truncated).  Here the env is a 1-env batch with next-step autoreset, so this
-            # call RESETS it (reward 0, flags clear, relative_time 0, streams continue) - a stated deviation, not a silent one.
-            warnings.warn("step() was called although this environment had already returned terminated or truncated = True: "
-                          "ns_gym_amd resets it on this call (gymnasium's next-step autoreset); call reset() to control the seed",
-                          UserWarning, stacklevel=3)
         v._step_raw(self._act.data_ptr())
         o, inf = self._scalars()
         if v.may_raise:      # what the reference raises inside step() (LCBounded exhaustion, see VecNSEnv.check_errors)
@@ -164,7 +158,6 @@ class _NSSingle:
         h = self._host
         r = float(h["reward"][0])
         terminated, truncated = bool(h["terminated"][0]), bool(h["truncated"][0])
-        self._done = terminated or truncated
         if not v.is_grid:
             if "violation" not in h:
                 v.check_constraints()

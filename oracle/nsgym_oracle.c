@@ -769,7 +769,10 @@ static void frozenlake_move(const nsg_config* cfg, int row, int col, int a, int*
 static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N, int64_t i,
                      const void* actions, uint64_t* cnt) {
   int env = cfg->env_type, P = cfg->n_params;
-  if (b->status[i] & NSG_ST_NEEDS_RESET) { /* next-step autoreset == env.reset() with no seed */
+  /* NSG_F_NO_AUTORESET: the reference's single wrappers forward every step() to gymnasium whatever `done` said (base.py:313);
+     status bit 0 then means "terminated at an earlier step of this episode" (CartPole's steps_beyond_terminated [UPSTREAM]) */
+  const int noauto = (cfg->flags & NSG_F_NO_AUTORESET) != 0;
+  if (!noauto && (b->status[i] & NSG_ST_NEEDS_RESET)) { /* next-step autoreset == env.reset() with no seed */
     reset_one(cfg, tables, b, N, i, 0, 0);
     if (b->done_bits) b->done_bits[i >> 6] &= ~(1ULL << (i & 63));
     return;
@@ -935,6 +938,8 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
     if (env == NSG_ENV_PENDULUM || env == NSG_ENV_MOUNTAINCAR_CONT) af = ((const float*)actions)[i];
     else ai = ((const int32_t*)actions)[i];
     term = env_step(env, th, s, ai, af, &reward);
+    /* CartPoleEnv.step [UPSTREAM]: `elif self.steps_beyond_terminated is None: ... reward = 1.0  else: ... reward = 0.0` */
+    if (noauto && env == NSG_ENV_CARTPOLE && term && (b->status[i] & NSG_ST_NEEDS_RESET)) reward = 0.0;
     for (int k = 0; k < PHYS_DIM[env]; k++) b->phys[k * N + i] = s[k];
     env_obs(env, s, b->obs + i * OBS_DIM[env]);
   }
@@ -947,7 +952,7 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
   b->terminated[i] = (uint8_t)term;
   b->truncated[i] = (uint8_t)trunc;
   int done = term || trunc;
-  b->status[i] = done ? NSG_ST_NEEDS_RESET : 0;
+  b->status[i] = noauto ? (uint8_t)((b->status[i] & NSG_ST_NEEDS_RESET) | (term ? NSG_ST_NEEDS_RESET : 0)) : (done ? NSG_ST_NEEDS_RESET : 0);
   if (cfg->flags & NSG_F_TRACK_RETURNS) {
     float er = b->ep_return[i] + (float)reward;
     int el = b->ep_length[i] + 1;
@@ -987,7 +992,8 @@ int orc_fork(const nsg_config* scfg, const nsg_buffers* sb, const nsg_config* dc
     if (fl) db->cell[i] = sb->cell[i];
     db->t[i] = sb->t[i];
     db->t_fork[i] = sb->t[i];
-    db->status[i] = sb->status[i];
+    /* NSG_F_NO_AUTORESET: the copy wraps a NEW base env that was reset (classic_control.py:168-178): not terminated yet */
+    db->status[i] = (dcfg->flags & NSG_F_NO_AUTORESET) ? 0 : sb->status[i];
     for (int r = 0; r < (fl ? nd * P : P); r++) {
       double cur = sb->theta[r * N + i];
       double init = fl ? grid_initial(scfg, r / nd)[r % nd] : scfg->base_theta[scfg->params[r].theta_slot];

@@ -477,6 +477,67 @@ USER_SPECS = {
 }
 
 
+# The reference's single wrappers never reset on their own: step() after `done` is forwarded to gymnasium like any other
+# (base.py:313), and the reference's own tests step without looking at `done` (tests/test_step_reset.py:570-577, 722-752).
+# These fixtures run well past the first `done` ("autoreset": False = the driver never calls reset()).
+NORESET_SPECS = {
+    "noreset_cartpole": {   # terminates after ~10-40 steps, then integrates on: reward 1.0 on the terminating step, 0.0 afterwards
+        "env_id": "CartPole-v1", "T": 110, "seeds": [0, 1, 2, 3, 4, 5], "autoreset": False,
+        "params": {"masspole": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["IncrementUpdate", {"k": 0.1}]},
+                   "gravity": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["RandomWalk", {}]}},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "noreset_cartpole_timelimit": {   # a short TimeLimit: truncated stays True on every later step, t and θ run on
+        "env_id": "CartPole-v1", "make_kwargs": {"max_episode_steps": 12}, "T": 60, "seeds": [7, 8, 9], "autoreset": False,
+        "params": {"force_mag": {"scheduler": SCHEDULER_SPECS["burst_3_2"], "update": ["IncrementUpdate", {"k": 0.25}]}},
+        "flags": {"change_notification": True, "delta_change_notification": False},
+    },
+    "noreset_pendulum": {   # never terminates; truncated from step 200 on
+        "env_id": "Pendulum-v1", "T": 240, "seeds": [0, 1, 2], "autoreset": False,
+        "params": {"m": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["IncrementUpdate", {"k": 0.01}]}},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "noreset_acrobot": {
+        "env_id": "Acrobot-v1", "make_kwargs": {"max_episode_steps": 60}, "T": 100, "seeds": [0, 1, 2, 3], "autoreset": False,
+        "params": {"LINK_MASS_2": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["IncrementUpdate", {"k": 0.05}]}},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "noreset_mountaincar": {
+        "env_id": "MountainCar-v0", "T": 240, "seeds": [0, 1], "autoreset": False,
+        "params": {"force": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["IncrementUpdate", {"k": 0.0001}]}},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "noreset_mountaincar_continuous": {
+        "env_id": "MountainCarContinuous-v0", "make_kwargs": {"max_episode_steps": 150}, "T": 400, "seeds": [0, 1, 2, 3], "autoreset": False,
+        "params": {"power": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["IncrementUpdate", {"k": 0.00005}]}},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "noreset_frozenlake_4x4": {   # holes / goal: the terminal cell's one-entry row self-loops (and still consumes its draw)
+        "env_id": "FrozenLake-v1", "make_kwargs": {"map_name": "4x4", "is_slippery": False}, "T": 140, "seeds": list(range(30, 42)),
+        "autoreset": False,
+        "params": {"P": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["DistributionDecrementUpdate", {"k": 0.05}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [1.0, 0.0, 0.0]},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+}
+
+NORESET_GRID_SPECS = {
+    "noreset_cliff": {   # terminal cliff / goal: the next step is an ordinary move from that cell
+        "env_id": "CliffWalking-v1", "make_kwargs": {"max_episode_steps": 40}, "T": 90, "seeds": list(range(8)), "autoreset": False,
+        "params": {"P": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["DistributionDecrementUpdate", {"k": 0.06}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [1.0, 0.0, 0.0, 0.0], "terminal_cliff": True},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+    "noreset_bridge_onehot": {
+        "env_id": "ns_gym/Bridge-v0", "T": 130, "seeds": [0, 1, 2, 3], "autoreset": False,
+        "params": {"P": {"scheduler": SCHEDULER_SPECS["burst_3_2"], "update": ["DistributionCyclicUpdate",
+                   {"dist_list": [[0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0]]}]}},
+        "wrapper_kwargs": {"initial_prob_dist": [1.0, 0.0, 0.0]},
+        "flags": {"change_notification": True, "delta_change_notification": True},
+    },
+}
+
+
 GRID_SPECS = {
     # CliffWalking: 4-way slip [a, a+1, a-1, a+2] (toy_text.py:96), cliff teleport, env-stream categorical draw
     "cliff_decrement": {
@@ -595,7 +656,7 @@ def gen_grid_trajectory(gym, S, U, spec):
             rec["reward"][k, i] = r
             rec["terminated"][k, i] = term
             rec["truncated"][k, i] = trunc
-            need_reset = bool(term or trunc)
+            need_reset = bool(term or trunc) and spec.get("autoreset", True)
     return rec
 
 
@@ -686,7 +747,7 @@ def gen_trajectory(gym, S, U, CC, FL, spec):
             rec["reward"][k, i] = r
             rec["terminated"][k, i] = term
             rec["truncated"][k, i] = trunc
-            need_reset = bool(term or trunc)
+            need_reset = bool(term or trunc) and spec.get("autoreset", True)
     return rec
 
 
@@ -923,15 +984,23 @@ def main():
     only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only-traj=")]
     if "--only-user" in sys.argv:
         only = list(USER_SPECS)
+    if "--only-noreset" in sys.argv:
+        only = list(NORESET_SPECS)
+        for name, spec in NORESET_GRID_SPECS.items():
+            rec = gen_grid_trajectory(gym, S, U, spec)
+            np.savez_compressed(os.path.join(HERE, f"grid_{name}.npz"), **rec)
+            print(name, "terminated:", int(rec["terminated"].sum()), "truncated:", int(rec["truncated"].sum()))
     if only:   # add trajectory fixtures without touching the others (the manifest is rewritten: it lists every spec)
         for name in only:
-            rec = gen_trajectory(gym, S, U, CC, FL, {**TRAJ_SPECS, **USER_SPECS}[name])
+            rec = gen_trajectory(gym, S, U, CC, FL, {**TRAJ_SPECS, **USER_SPECS, **NORESET_SPECS}[name])
             np.savez_compressed(os.path.join(HERE, f"traj_{name}.npz"), **rec)
             print(name, "episodes:", int(rec["was_reset"].sum()), "fired:", int(rec["gt_env_change"].sum()),
                   "rejected-or-silent steps:", int((rec["gt_env_change"] == 0).sum()))
         man = json.load(open(os.path.join(HERE, "manifest.json")))
         man["traj_specs"] = TRAJ_SPECS
         man["user_specs"] = USER_SPECS
+        man["noreset_specs"] = NORESET_SPECS
+        man["noreset_grid_specs"] = NORESET_GRID_SPECS
         with open(os.path.join(HERE, "manifest.json"), "w") as f:
             json.dump(man, f, indent=1)
         return
@@ -949,6 +1018,8 @@ def main():
         "dist_update_specs": DIST_UPDATE_SPECS,
         "traj_specs": TRAJ_SPECS,
         "user_specs": USER_SPECS,
+        "noreset_specs": NORESET_SPECS,
+        "noreset_grid_specs": NORESET_GRID_SPECS,
         "planning_specs": PLANNING_SPECS,
         "grid_specs": GRID_SPECS,
     }
@@ -963,6 +1034,14 @@ def main():
         rec = gen_trajectory(gym, S, U, CC, FL, spec)
         np.savez_compressed(os.path.join(HERE, f"traj_{name}.npz"), **rec)
         print(name, "episodes:", int(rec["was_reset"].sum()), "fired:", int(rec["gt_env_change"].sum()))
+    for name, spec in NORESET_SPECS.items():
+        rec = gen_trajectory(gym, S, U, CC, FL, spec)
+        np.savez_compressed(os.path.join(HERE, f"traj_{name}.npz"), **rec)
+        print(name, "terminated:", int(rec["terminated"].sum()), "truncated:", int(rec["truncated"].sum()))
+    for name, spec in NORESET_GRID_SPECS.items():
+        rec = gen_grid_trajectory(gym, S, U, spec)
+        np.savez_compressed(os.path.join(HERE, f"grid_{name}.npz"), **rec)
+        print(name, "terminated:", int(rec["terminated"].sum()), "truncated:", int(rec["truncated"].sum()))
     np.savez_compressed(os.path.join(HERE, "reset_semantics.npz"), **gen_reset_semantics(gym, S, U, CC))
     np.savez_compressed(os.path.join(HERE, "p_tables.npz"), **gen_p_tables(gym, S, U, FL))
     for name, spec in GRID_SPECS.items():

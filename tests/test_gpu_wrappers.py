@@ -180,10 +180,10 @@ def test_episode_harness_rows_match_step_by_step_accounting(tmp_path):
     assert obs == 3 and rew == 1.0
 
 
-def test_step_after_done_resets_and_says_so():
-    """Stated deviation: the N = 1 adaptors inherit the batch's next-step autoreset, so a step() on a finished
-    env performs the reset where the reference would keep stepping gymnasium's finished env (undefined there).  It must not
-    be silent: the call warns, returns the reset observation (relative_time 0, reward 0, flags clear) and the episode goes on."""
+def test_step_after_done_goes_on_like_the_references_and_an_autoreset_adaptor_can_be_asked_for():
+    """A single wrapper never resets on its own: step() after `done` is forwarded like any other (ns_gym/base.py:313) - CartPole
+    integrates on (reward 0.0 from the second terminated step), relative_time and θ keep counting.  `autoreset=True` gives the
+    batch behaviour (the step after `done` is the reset) to callers that want it."""
     import warnings
 
     from ns_gym_amd import make
@@ -191,24 +191,33 @@ def test_step_after_done_resets_and_says_so():
     from ns_gym_amd.update_functions import IncrementUpdate
     from ns_gym_amd.wrappers import NSClassicControlWrapper
 
-    env = NSClassicControlWrapper(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)},
-                                  change_notification=True)
+    def build(**kw):
+        return NSClassicControlWrapper(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)},
+                                       change_notification=True, **kw)
+
+    env = build()
     env.reset(seed=3)
-    done = False
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")            # no warning while the episode runs
-        for _ in range(500):
-            obs, r, term, trunc, info = env.step(1)
-            if term or trunc:
-                done = True
-                break
-    assert done
-    with pytest.warns(UserWarning, match="already returned terminated or truncated"):
-        obs, r, term, trunc, info = env.step(1)
-    assert obs["relative_time"] == 0 and r == 0.0 and not term and not trunc
     with warnings.catch_warnings():
         warnings.simplefilter("error")
-        obs, r, term, trunc, info = env.step(1)   # the new episode runs on without a warning
-    assert obs["relative_time"] == 1 and r == 1.0
-    env.reset(seed=4)                             # an explicit reset after done is the silent, reference way
+        for k in range(500):
+            obs, r, term, trunc, info = env.step(1)
+            if term or trunc:
+                break
+        assert term and r == 1.0
+        t_done, m_done = obs["relative_time"], env.unwrapped.masspole
+        obs, r, term, trunc, info = env.step(1)          # no reset, no warning
+    assert obs["relative_time"] == t_done + 1 and r == 0.0 and term and not trunc
+    assert env.unwrapped.masspole == pytest.approx(m_done + 0.1) and obs["env_change"]["masspole"] == 1
+    env.reset(seed=4)
+    assert env.t == 0 and env.unwrapped.masspole == pytest.approx(0.1)
     env.close()
+
+    auto = build(autoreset=True)
+    auto.reset(seed=3)
+    for k in range(500):
+        obs, r, term, trunc, info = auto.step(1)
+        if term or trunc:
+            break
+    obs, r, term, trunc, info = auto.step(1)
+    assert obs["relative_time"] == 0 and r == 0.0 and not term and not trunc and auto.unwrapped.masspole == pytest.approx(0.1)
+    auto.close()
