@@ -313,6 +313,7 @@ def main():
     for k in range(args.steps):
         env.step(pool[k % 8])
     e1.record()
+    dt_enqueue = time.perf_counter() - t0   # the host loop alone: how fast THIS rank's Python issues launches (a rank starved of host cores shows here)
     while not e1.query():
         pass
     dt = time.perf_counter() - t0      # this rank's K steps, device drained; the MAX over ranks below is the job's time
@@ -325,11 +326,32 @@ def main():
     # The job's ONE exchange: every rank's episode returns gathered at the END of a rollout (per rollout, not per step - a
     # rollout is thousands of steps; inside the driver's 20-step window it would be a third of the time at N = 8).  Timed on
     # its own and reported as config.returns_gather_ms, with barriers on both sides like the steps.
-    tg = time.perf_counter()
-    gathered = all_gather_returns(env, sizes=[n] * world) if dist is not None else env.episode_returns()[0]
-    torch.cuda.synchronize()
-    barrier()
-    gather_ms = (time.perf_counter() - tg) * 1e3
+    # Two schedules of the same exchange, both timed: RCCL's all-gather (its own choice of algorithm) and the direct one - every
+    # shard sent to each peer over that peer's own xGMI link (ns_gym_amd.distributed.all_gather_returns_direct).  NSG_BENCH_ALLGATHER
+    # = "rccl" (default) | "direct" picks the one whose time is charged as returns_gather_ms / value_incl_gather.
+    from ns_gym_amd.distributed import all_gather_returns_direct, verify_gather
+
+    def timed_gather(fn):
+        barrier()
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        out = fn(env, sizes=[n] * world) if dist is not None else env.episode_returns()[0]
+        torch.cuda.synchronize()
+        barrier()
+        return out, (time.perf_counter() - tg) * 1e3
+
+    which = os.environ.get("NSG_BENCH_ALLGATHER", "rccl")
+    if which not in ("rccl", "direct"):
+        raise SystemExit("bench.py: NSG_BENCH_ALLGATHER must be 'rccl' or 'direct'")
+    gathered, gather_ms_rccl = timed_gather(all_gather_returns)
+    gather_ms_direct, direct_equal = None, None
+    if dist is not None:
+        all_gather_returns_direct(env, sizes=[n] * world)          # first use: connection set-up of the point-to-point channels
+        g2, gather_ms_direct = timed_gather(all_gather_returns_direct)
+        direct_equal = bool(torch.equal(g2, gathered))
+    gather_ms = gather_ms_direct if (which == "direct" and gather_ms_direct is not None) else gather_ms_rccl
+    # the gathered CONTENT, not just its length: this rank's slice is its local tensor, and the checksums agree across ranks
+    gather_verified = verify_gather(gathered, env.episode_returns()[0], rank * n) and (direct_equal is not False)
 
     if args.dump_shards:   # every row a sharded job must reproduce whatever its world size
         import numpy as np
@@ -399,16 +421,16 @@ def main():
             big.close()
             ach = BYTES_PER_ENV_STEP * N_HBM_RESIDENT / (big_us * 1e-6) / 1e9
             hbm = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                   "envs": N_HBM_RESIDENT, "avg_launch_us": big_us, "launches": 300, "repetitions_us": reps_us,
+                   "envs": N_HBM_RESIDENT, "avg_launch_us": big_us, "launches": 100, "repetitions": 3, "repetitions_us": reps_us,
                    "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP, "traffic": None,
                    "note": "same kernel and config as `roofline`, 2^24 envs: every row streams from HBM each step"}
         except Exception as e:     # e.g. not enough device memory next to another tenant; never fatal for the headline line
             hbm = {"error": f"{type(e).__name__}: {e}"[:200]}
 
-    t = torch.tensor([dt, gather_ms, kern_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, gather_ms, kern_ms, gather_ms_rccl, gather_ms_direct or 0.0, dt_enqueue], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max, gather_ms_max, kern_ms_max = (float(x) for x in t.tolist())
+    dt_max, gather_ms_max, kern_ms_max, gather_ms_rccl_max, gather_ms_direct_max, dt_enqueue_max = (float(x) for x in t.tolist())
     total_env_steps = float(n) * world * args.steps
     value = total_env_steps / dt_max
     # the same job with its one exchange charged to it: this window's K steps + the gather, and a T = 1000 rollout + the gather
@@ -438,6 +460,12 @@ def main():
                                if world > 1 else "single GPU",
                 "episodes_finished_rank0": episodes_rank0,
                 "gathered_returns": int(gathered.numel()), "returns_gather_ms": gather_ms_max,
+                "gather_verified": bool(gather_verified), "returns_gather_schedule": which if dist is not None else "local read-out",
+                "returns_gather_ms_rccl_allgather": gather_ms_rccl_max,
+                "returns_gather_ms_direct_p2p": gather_ms_direct_max if dist is not None else None,
+                # the host side of the K timed steps, per rank: Python launch loop only (before the drain)
+                "rank0_host_loop_steps_per_s": args.steps / dt_enqueue, "slowest_rank_host_loop_steps_per_s": args.steps / dt_enqueue_max,
+                "rank0_avg_launch_us": kern_ms * 1e3, "slowest_rank_avg_launch_us": kern_ms_max * 1e3,
                 "collectives": (f"torch.distributed backend {dist.get_backend()}, {world} rank(s)" if dist is not None else "none (single process)"),
                 "value_incl_gather": value_incl_gather, "value_incl_gather_T1000": value_incl_gather_t1000,
                 "ms_per_step_clock_after_synchronize": dt_after_sync / args.steps * 1e3,
@@ -451,6 +479,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                 "frac": achieved / peak, "traffic": _pmc_traffic(n),
+                # `frac` prices the kernel: bytes per launch over the HIP-event average launch duration (`avg_launch_us`).  The same
+                # bytes over the line's own `ms_per_step` (host clock around the K steps, max over ranks):
+                "frac_from_ms_per_step": BYTES_PER_ENV_STEP * value / 1e9 / (HBM_PEAK_GBS * world),
                 "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of an "
                                   "earlier run of this kernel, scaled per env; not measured in this run)",
                 "residency": f"{n} envs = {n * 150 / 1e6:.0f} MB of rows: "
@@ -488,6 +519,8 @@ def main():
                 "python_object_loop": _safe(_python_object_loop),
                 # the same loop in one worker PROCESS per host core of this GPU's share, rates summed
                 "python_object_loop_all_cores": _safe(_python_object_loop_all_cores, threads),
+                # what a NumPy user would write: the same config as arrays over envs, one core
+                "numpy_vectorised": _safe(_numpy_vectorised),
             }
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -518,6 +551,17 @@ def _python_object_loop():
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "env-steps/s", "cores": 1,
             "sample": f"64 wrapper objects x 600 steps of the same config in {dt:.1f} s"}
+
+
+def _numpy_vectorised():
+    from oracle import numpy_vec as NV
+
+    n = 1 << 16
+    rate, _ = NV.time_c1(n, 10)
+    steps = int(min(max(3.0 * rate / n, 10), 2000))     # ~3 s of wall time
+    v, secs = NV.time_c1(n, steps)
+    return {"value": v, "unit": "env-steps/s", "cores": 1,
+            "sample": f"oracle/numpy_vec.py, {n} envs x {steps} steps of the same config in {secs:.1f} s"}
 
 
 def _python_object_loop_all_cores(workers):

@@ -80,3 +80,59 @@ def all_gather_returns(env, group=None, sizes=None) -> torch.Tensor:
     else:
         dist.all_gather_into_tensor(out, padded, group=group)
     return torch.cat([out[r * m: r * m + sizes[r]] for r in range(world)])
+
+
+def all_gather_returns_direct(env, group=None, sizes=None) -> torch.Tensor:
+    """The same exchange with an explicit DIRECT schedule: every rank sends its shard to each of the other ranks and receives
+    theirs, all 2 x (world - 1) transfers posted as one batch of point-to-point operations (RCCL groups them into one launch).
+    On MI355X the 8 GPUs of a node are a full xGMI mesh - 7 links per GPU, each to one peer - so this moves every shard over its
+    own link once (4 MiB per link at 2^20 envs per GPU), where a ring all-gather forwards every shard through 7 hops of single
+    links.  Whether it beats RCCL's own choice is a measurement (bench.py times both)."""
+    import torch.distributed as dist
+
+    local = env.episode_returns()[0].contiguous()
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if sizes is None:
+        n_local = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+        all_n = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(all_n, n_local, group=group)
+        sizes = [int(x.item()) for x in all_n]
+    assert len(sizes) == world and sizes[rank] == local.numel()
+    offs = [0]
+    for s in sizes:
+        offs.append(offs[-1] + s)
+    out = torch.empty(offs[-1], dtype=local.dtype, device=local.device)
+    out[offs[rank]:offs[rank + 1]] = local
+    host = dist.get_backend(group) == "gloo"     # the CPU rehearsal backend moves host memory
+    src = local.cpu() if host else local
+    parts = {r: (torch.empty(sizes[r], dtype=local.dtype) if host else out[offs[r]:offs[r + 1]]) for r in range(world) if r != rank}
+    ops = []
+    for d in range(1, world):                     # peer order staggered by rank: at any moment every link carries one transfer
+        to, frm = (rank + d) % world, (rank - d) % world
+        ops.append(dist.P2POp(dist.isend, src, to, group=group))
+        ops.append(dist.P2POp(dist.irecv, parts[frm], frm, group=group))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    if host:
+        for r, p in parts.items():
+            out[offs[r]:offs[r + 1]] = p.to(out.device)
+    return out
+
+
+def verify_gather(gathered: torch.Tensor, local: torch.Tensor, lo: int, group=None) -> bool:
+    """What an all-gather of returns must satisfy, checked on every rank: this rank's slice of the gathered tensor IS its local
+    tensor, and the sum over ranks of each rank's local checksum equals the checksum of the gathered tensor (bit patterns summed as
+    integers: exact, order-independent).  Returns the AND over ranks."""
+    import torch.distributed as dist
+
+    ok = bool(torch.equal(gathered[lo:lo + local.numel()], local))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        bits = lambda t: t.contiguous().view(torch.int32).to(torch.int64).sum()   # noqa: E731
+        v = torch.stack([bits(local), torch.tensor(0 if ok else 1, dtype=torch.int64, device=local.device)])
+        if dist.get_backend(group) == "gloo":
+            v = v.cpu()
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+        ok = int(v[1]) == 0 and int(v[0]) == int(bits(gathered))
+    return ok

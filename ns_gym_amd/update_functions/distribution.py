@@ -123,11 +123,6 @@ class DistributionLinearInterpolation(UpdateDistributionFn):
         return {"upd_kind": A.UPD_D_LERP, "u": _u(*s, *e, self.T)}
 
 
-class _NotFusedYet(UpdateDistributionFn):
-    def _compile(self, tables):
-        raise NotImplementedError(f"{type(self).__name__} is not fused into the kernel yet (SURVEY §8(f) rank 3)")
-
-
 class RandomCategorical(UpdateDistributionFn):
     """A fresh Dirichlet(1,…,1) sample on every fire: `list(rng.dirichlet(np.ones(n)))`
     (distribution.py:11-38); owns a PCG64 stream like the reference's `self.rng`."""
@@ -173,7 +168,11 @@ class LCBoundedDistrubutionUpdate(UpdateDistributionFn):
         elif isinstance(self.update_fn, DistributionNoUpdate):
             inner = 1
         else:
-            raise NotImplementedError(f"LCBounded over {type(self.update_fn).__name__} is not fused into the kernel")
+            from .._lib import NsgError
+
+            raise NsgError(f"LCBoundedDistrubutionUpdate over {type(self.update_fn).__name__}: the kernels' rejection loop draws its candidates "
+                           f"from RandomCategorical (or accepts DistributionNoUpdate at once); another inner update function would have to "
+                           f"run as Python inside a per-env loop of up to 1e5 tries (distribution.py:167-183)")
         d = {"upd_kind": A.UPD_D_LCBOUNDED, "u": _u(self.L, inner), "uses_rng": 1 if inner == 0 else 0}
         if self.inner_seed is not None:
             d.update(has_fn_seed=1, fn_seed=int(self.inner_seed))

@@ -328,6 +328,9 @@ class PendulumEnv(Env):
         g, m, l, dt = self.g, self.m, self.l, self.dt
         u = float(np.clip(np.asarray(u, dtype=np.float64).reshape(-1), -self.max_torque, self.max_torque)[0])
         self.last_u = u
+        # (one line that is NOT the NumPy-1.26 reading the class docstring fixes: upstream `u` is still a float32 scalar here, so
+        # `u**2` rounds to float32 before the `0.001 *`; this file squares in float64.  |difference| <= 2.4e-10 on the cost, three
+        # orders below the float32 reward's resolution - the reward the wrappers return is float(...) of it, compared at 1e-5)
         costs = angle_normalize(th) ** 2 + 0.1 * thdot**2 + 0.001 * (u**2)
         newthdot = thdot + (3 * g / (2 * l) * np.sin(th) + 3.0 / (m * l**2) * u) * dt
         newthdot = np.clip(newthdot, -self.max_speed, self.max_speed)

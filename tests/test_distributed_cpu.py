@@ -39,13 +39,22 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from ns_gym_amd.distributed import all_gather_returns, shard_range
+    from ns_gym_amd.distributed import all_gather_returns, all_gather_returns_direct, shard_range, verify_gather
 
     res = {}
     for total in (12, 11):   # even and ragged shards
         lo, hi = shard_range(total, rank, world)
         local = torch.arange(lo, hi, dtype=torch.float32) * 0.5
-        res[total] = all_gather_returns(_FakeEnv(local)).tolist()
+        got = all_gather_returns(_FakeEnv(local))
+        res[total] = got.tolist()
+        # the direct schedule (every shard sent to each peer) gathers the same tensor; the content check passes on it ...
+        res[("direct", total)] = all_gather_returns_direct(_FakeEnv(local)).tolist()
+        res[("verified", total)] = verify_gather(got, local, lo)
+        # ... and FAILS, on every rank, when one rank's slice is not what that rank holds
+        bad = got.clone()
+        if rank == 1:
+            bad[lo] += 1.0
+        res[("verified_bad", total)] = verify_gather(bad, local, lo)
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -67,6 +76,9 @@ def test_all_gather_returns_gloo_world2():
     for total in (12, 11):
         want = [i * 0.5 for i in range(total)]
         assert res[0][total] == want and res[1][total] == want
+        assert res[0][("direct", total)] == want and res[1][("direct", total)] == want
+        assert res[0][("verified", total)] is True and res[1][("verified", total)] is True
+        assert res[0][("verified_bad", total)] is False and res[1][("verified_bad", total)] is False
 
 
 def _job_worker(rank, world, port, total, steps, q):

@@ -34,9 +34,12 @@ def test_single_process_line():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert abs(r["achieved"] - 120 * 65536 / (r["avg_launch_us"] * 1e-6) / 1e9) / r["achieved"] < 1e-6
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and "workload" in d["config"]
+    assert d["cpu_baseline"]["numpy_vectorised"]["value"] > 0 and d["cpu_baseline"]["numpy_vectorised"]["cores"] == 1
+    assert abs(r["frac_from_ms_per_step"] - 120 * d["value"] / 8e12) < 1e-9 and d["config"]["gather_verified"] is True
     assert "static" in r["traffic_source"] and "Infinity Cache" in r["residency"]
     h = d["roofline_hbm_resident"]                      # the same kernel on 2^24 envs: rows stream from HBM
     assert h["envs"] == 1 << 24 and h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / 8000.0) < 1e-9
+    assert h["launches"] == 100 and h["repetitions"] == 3 and len(h["repetitions_us"]) == 3
     assert abs(h["achieved"] - 120 * (1 << 24) / (h["avg_launch_us"] * 1e-6) / 1e9) / h["achieved"] < 1e-6
     # every BASELINE configuration at the size BASELINE quotes it at, each priced with its own bytes
     own = d["config"]["baseline_configs_at_own_size"]
@@ -61,6 +64,14 @@ def test_two_ranks_aggregate_line():
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 2 * 65536 and d["config"]["gathered_returns"] == 2 * 65536
     assert abs(d["value"] - 2 * 65536 * 60 / (d["ms_per_step"] * 60 / 1e3)) / d["value"] < 1e-6   # whole-job aggregate
     assert d["config"]["returns_gather_ms"] > 0.0       # the end-of-rollout exchange, timed on its own
+    # first-contact diagnostics of an N > 1 run: the gathered CONTENT was checked, both gather schedules were timed, and a rank
+    # whose host loop or kernel lags shows in the line
+    c = d["config"]
+    assert c["gather_verified"] is True and c["returns_gather_schedule"] == "rccl"
+    assert c["returns_gather_ms_rccl_allgather"] > 0.0 and c["returns_gather_ms_direct_p2p"] > 0.0
+    assert c["slowest_rank_host_loop_steps_per_s"] <= c["rank0_host_loop_steps_per_s"] * 1.0000001 and c["slowest_rank_host_loop_steps_per_s"] > 0
+    assert c["slowest_rank_avg_launch_us"] >= c["rank0_avg_launch_us"] * 0.9999999 > 0
+    assert abs(d["roofline"]["frac_from_ms_per_step"] - 120 * d["value"] / 1e9 / 16000.0) < 1e-9
 
 
 def test_single_rank_through_rccl():
@@ -79,7 +90,7 @@ def test_single_rank_through_rccl():
     assert p.returncode == 0, p.stderr[-2000:]
     d = _line(p.stdout)
     assert d["n_gpus"] == 1 and d["config"]["collectives"] == "torch.distributed backend nccl, 1 rank(s)"
-    assert d["config"]["gathered_returns"] == 65536 and d["config"]["returns_gather_ms"] > 0.0
+    assert d["config"]["gathered_returns"] == 65536 and d["config"]["returns_gather_ms"] > 0.0 and d["config"]["gather_verified"] is True
 
 
 def test_gpus_flag_launches_its_own_ranks():
