@@ -97,7 +97,7 @@ def baseline_configs_at_own_size(dev, c1_step_us, c1_rollout_rate, n_c1):
             env.step(a)
         us = min(env.time_steps(a, 300) for _ in range(2)) * 1e3
         ru = rollout_us(env)
-        rows[tag] = {"envs": env.N, "step_us": us, "bytes_per_env_step": w["bytes_per_env_step"],
+        rows[tag] = {"envs": env.N, "kernels": env.kernels, "step_us": us, "bytes_per_env_step": w["bytes_per_env_step"],
                      "frac_of_hbm_peak": frac(w["bytes_per_env_step"], env.N, us), "env_steps_per_sec": env.N / (us * 1e-6),
                      "rollout_k64_us_per_step": ru, "rollout_k64_env_steps_per_sec": env.N / (ru * 1e-6)}
         if env.N <= 1 << 16:
@@ -253,6 +253,7 @@ def main():
         print(f"bench.py: {e}; timing the generic kernels", file=sys.stderr)
         args.generic = True
         env = make_env(False)
+    kernels_used = env.kernels
     # env i of the whole job is seeded base_seed + global index: results do not depend on the sharding
     env.reset(seed=torch.arange(rank * n, (rank + 1) * n, dtype=torch.int64).numpy().astype("uint64"))
     g = torch.Generator(device=dev)
@@ -411,6 +412,7 @@ def main():
             big = VecNSEnv(make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)}, N_HBM_RESIDENT,
                            change_notification=True, delta_change_notification=True, track_returns=True, device=dev, specialize=True)
             big.reset(seed=0)
+            big_kernels = big.kernels
             ab = torch.randint(0, 2, (N_HBM_RESIDENT,), dtype=torch.int32, device=dev, generator=g)
             for _ in range(20):
                 big.step(ab)
@@ -423,6 +425,7 @@ def main():
             hbm = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                    "envs": N_HBM_RESIDENT, "avg_launch_us": big_us, "launches": 100, "repetitions": 3, "repetitions_us": reps_us,
                    "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP, "traffic": None,
+                   "kernels": big_kernels,
                    "note": "same kernel and config as `roofline`, 2^24 envs: every row streams from HBM each step"}
         except Exception as e:     # e.g. not enough device memory next to another tenant; never fatal for the headline line
             hbm = {"error": f"{type(e).__name__}: {e}"[:200]}
@@ -473,7 +476,9 @@ def main():
                                 "(device drained); the closing synchronize() + barrier follow immediately",
                 "actions": "counter-based uniform draws per (pool slot, global env index): independent of the sharding",
                 "rollout_k64_env_steps_per_sec_per_gpu": rollout_rate,
-                "kernels": "generic (precompiled)" if args.generic else "config-specialised (nsg_specialize, hiprtc)",
+                # which code object ran: "config-specialised (prebuilt)" = the unit shipped with the library, built and inspected at
+                # library build time (ns_gym_amd/prebuilt/resource_usage.txt); "(hiprtc)" = compiled on this box by the runtime compiler
+                "kernels": kernels_used,
                 ("specialised_kernel_avg_launch_us" if args.generic else "generic_kernel_avg_launch_us"): other_us,
             },
             "roofline": {

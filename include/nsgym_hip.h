@@ -390,6 +390,7 @@ int nsg_rollout_group(nsg_handle* const* hs, int32_t n_handles, const void* cons
 #define NSG_GROUP_GENERIC_SIMPLE 1   /* precompiled kernel, plain-arithmetic theta engine */
 #define NSG_GROUP_GENERIC_FULL 2     /* precompiled kernel, full theta engine */
 #define NSG_GROUP_SPECIALISED 3      /* the unit compiled for the ordered tuple of the members' configs (nsg_spec_group) */
+#define NSG_GROUP_SPECIALISED_PREBUILT 4 /* the same, shipped with the library (NSG_SPEC_ORIGIN_PREBUILT) */
 int nsg_step_group_kind(nsg_handle* const* hs, int32_t n_handles);
 
 /* θ-schedule engine alone (Scheduler.__call__ + UpdateFn.__call__, base.py:67-81,124-149)
@@ -466,6 +467,20 @@ int nsg_read_back(const void* src_dev, void* dst_host_mapped, int64_t bytes, uin
  * object to be released with nsg_spec_free. */
 int nsg_specialize(nsg_handle* h);
 int nsg_is_specialized(const nsg_handle* h);
+/* Where the handle's specialised unit came from (0 = not specialised). */
+#define NSG_SPEC_ORIGIN_NONE 0
+#define NSG_SPEC_ORIGIN_HIPRTC 1    /* compiled by hiprtc in this process                                        */
+#define NSG_SPEC_ORIGIN_CACHE 2     /* read from the user's disk cache (NSG_SPEC_CACHE), compiled by an earlier process */
+#define NSG_SPEC_ORIGIN_PREBUILT 3  /* shipped with the library: <directory of libnsgym_hip.so>/prebuilt (or NSG_PREBUILT_DIR), built and
+                                       inspected at library build time (nsg_spec_prebuild; csrc/prebuilt_resource_usage.txt)  */
+int nsg_spec_origin(const nsg_handle* h);
+/* Build-time side of NSG_SPEC_ORIGIN_PREBUILT (no GPU needed): compiles the unit nsg_specialize() would compile for a handle of
+ * (cfg, n envs) on a device whose gcnArchName is `arch` (e.g. "gfx950:sramecc+:xnack-": the name is part of the key, and so is n where
+ * the launch policy depends on it) and writes it to <dir>/nsg_<key>.hsaco, the file name nsg_specialize looks for.  The same spill
+ * rule applies: a unit that spills is not written.  nsg_spec_prebuild_group: the unit of nsg_step_group / nsg_rollout_group for
+ * the ordered member list (cfgs[k], ns[k]). */
+int nsg_spec_prebuild(const nsg_config* cfg, int64_t n, const char* arch, const char* dir);
+int nsg_spec_prebuild_group(const nsg_config* const* cfgs, const int64_t* ns, int32_t count, const char* arch, const char* dir);
 int nsg_spec_build(const nsg_config* cfg, const char* arch, void** code_out, size_t* size_out);
 /* the same for the unit nsg_step_group uses when every member is specialised: one kernel (nsg_spec_group) for the ordered tuple
  * of the members' configs */

@@ -153,7 +153,7 @@ inline void emit_cfg_words(std::string& s, const nsg_config& cfg, int index) {
 
 // Heterogeneous launch (nsg_step_group) specialised for the ordered tuple of its members' configs:
 // one kernel, the segment a workgroup belongs to selects the member's folded step_body.
-inline std::string group_source(const nsg_config* const* cfgs, const bool* full, int n) {
+inline std::string group_source(const nsg_config* const* cfgs, const bool* full, int n, bool with_rollout = true) {
   std::string s;
   s.reserve(16384 * n);
   s +=
@@ -189,8 +189,9 @@ inline std::string group_source(const nsg_config* const* cfgs, const bool* full,
              k, (int)cfgs[k]->env_type, full[k] ? "true" : "false", k, k);
     s += buf;
   }
-  s += "    default: break;\n  }\n}\n"
-       "extern \"C\" __global__ __launch_bounds__(NSG_BLOCK) void nsg_spec_group_rollout(const nsg::Segment* __restrict__ segs, int nseg,\n"
+  s += "    default: break;\n  }\n}\n";
+  if (!with_rollout) return s;
+  s += "extern \"C\" __global__ __launch_bounds__(NSG_BLOCK) void nsg_spec_group_rollout(const nsg::Segment* __restrict__ segs, int nseg,\n"
        "                                                                 nsg::ActionPtrs acts, int k_steps, nsg::RolloutOuts outs) {\n"
        "  const int sidx = nsg::group_segment_of_block(segs, nseg);\n"
        "  const nsg::Segment& sg = segs[sidx];\n"
@@ -262,8 +263,13 @@ inline std::vector<char> spec_compile(const nsg_config& cfg, bool full, const ch
 }
 // The heterogeneous launch's unit is held to the same rule: a group kernel that spills is refused (the generic group kernel
 // stays in force, nsg_step_group).
+// The two kernels of the unit are judged separately: when the unit with both spills, the single-step kernel is built on its own -
+// if IT is clean the unit ships without nsg_spec_group_rollout (fused group rollouts of this member list run the generic kernel),
+// so a spilling rollout never costs nsg_step_group its specialised kernel.
 inline std::vector<char> group_compile(const nsg_config* const* cfgs, const bool* full, int n, const char* arch, std::string& err) {
   std::vector<char> code = compile_source(group_source(cfgs, full, n), arch, err);
+  if (!code.empty() && unit_uses_scratch(code) && !allow_spill())
+    code = compile_source(group_source(cfgs, full, n, false), arch, err);
   if (!code.empty() && unit_uses_scratch(code) && !allow_spill()) {
     err = "the specialised group kernel spills vector registers (scratch memory); such builds are not used (see spec_compile)";
     code.clear();
@@ -354,6 +360,7 @@ struct Module {
   hipFunction_t group = nullptr, group_rollout = nullptr;   // heterogeneous-launch unit (single step, fused rollout)
   uint64_t h0 = 0;                                    // config key (group keys are built from their members')
   int step_waves = 0;                                 // wavefronts per SIMD the step kernel's registers allow (0 = unknown)
+  int origin = 0;                                     // NSG_SPEC_ORIGIN_*: where this code object came from
 };
 
 struct Key {
@@ -370,6 +377,12 @@ inline std::map<Key, Module>& cache() {
 }
 inline std::mutex& cache_mutex() {
   static std::mutex m;
+  return m;
+}
+// keys whose compilation failed in this process (refused unit, compiler error): asked again they fail at once instead of
+// compiling for seconds every time - a re-plan of a group holds the plan mutex while it asks
+inline std::map<Key, std::string>& failed() {
+  static std::map<Key, std::string> m;
   return m;
 }
 

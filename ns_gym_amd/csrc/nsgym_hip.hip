@@ -214,7 +214,40 @@ void spec_cache_evict(const std::string& dir) {
   for (size_t k = 0; k + kSpecCacheMaxFiles < files.size(); k++) (void)remove(files[k].second.c_str());
 }
 
-// Look a code object up in the process cache, then in the disk cache (spec_cache_dir), else compile it; load it.
+// Units shipped WITH the library, built and inspected when the library was (nsg_spec_prebuild; csrc/prebuilt_resource_usage.txt):
+// <directory of libnsgym_hip.so>/prebuilt, or NSG_PREBUILT_DIR.  Same trust as the library next to them: no ownership test.
+std::string prebuilt_dir() {
+  if (const char* e = getenv("NSG_PREBUILT_DIR")) return (*e && strcmp(e, "off") != 0) ? std::string(e) : std::string();
+  Dl_info info;
+  if (!dladdr((const void*)&nsg_abi_version, &info) || !info.dli_fname) return "";
+  std::string path = info.dli_fname;
+  const size_t slash = path.rfind('/');
+  return (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/prebuilt";
+}
+
+std::string spec_file_name(uint64_t h0, uint64_t h1) {
+  char name[64];
+  snprintf(name, sizeof(name), "/nsg_%016llx_%016llx.hsaco", (unsigned long long)h0, (unsigned long long)h1);
+  return name;
+}
+
+bool read_file(const std::string& path, std::vector<char>& code) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  code.clear();
+  if (n > 0) {
+    code.resize((size_t)n);
+    if (fread(code.data(), 1, (size_t)n, f) != (size_t)n) code.clear();
+  }
+  fclose(f);
+  return !code.empty();
+}
+
+// Look a code object up in the process cache, then among the prebuilt units, then in the disk cache (spec_cache_dir), else
+// compile it; load it.
 template <typename Compile>
 int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, const nsg_spec::Module** out) {
   const uint64_t h1 = spec_source_hash();
@@ -223,13 +256,26 @@ int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, cons
   auto& cache = nsg_spec::cache();
   auto it = cache.find(key);
   if (it == cache.end()) {
+    auto bad = nsg_spec::failed().find(key);
+    if (bad != nsg_spec::failed().end()) return fail(NSG_EUNSUPPORTED, "%s", bad->second.c_str());
     std::vector<char> code;
     std::string path;
-    const std::string dir = spec_cache_dir();
+    int origin = NSG_SPEC_ORIGIN_HIPRTC;
+    const std::string pre = prebuilt_dir();
+    if (!pre.empty() && read_file(pre + spec_file_name(h0, h1), code)) {
+      nsg_spec::Module pm;
+      pm.h0 = h0;
+      if (hipModuleLoadData(&pm.mod, code.data()) == hipSuccess) {
+        (void)hipModuleUnload(pm.mod);
+        origin = NSG_SPEC_ORIGIN_PREBUILT;
+      } else {   // built for another target: fall through to the cache / the compiler
+        (void)hipGetLastError();
+        code.clear();
+      }
+    }
+    const std::string dir = origin == NSG_SPEC_ORIGIN_PREBUILT ? std::string() : spec_cache_dir();
     if (!dir.empty()) {
-      char name[64];
-      snprintf(name, sizeof(name), "/nsg_%016llx_%016llx.hsaco", (unsigned long long)h0, (unsigned long long)h1);
-      path = dir + name;
+      path = dir + spec_file_name(h0, h1);
       if (FILE* f = spec_cache_file_ok(path.c_str()) ? fopen(path.c_str(), "rb") : nullptr) {
         fseek(f, 0, SEEK_END);
         const long n = ftell(f);
@@ -257,9 +303,14 @@ int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, cons
     if (code.empty()) {
       std::string err;
       code = compile(err);
-      if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
+      if (code.empty()) {
+        nsg_spec::failed()[key] = err;
+        return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
+      }
       compiled_now = true;
       store();
+    } else if (origin != NSG_SPEC_ORIGIN_PREBUILT) {
+      origin = NSG_SPEC_ORIGIN_CACHE;
     }
     nsg_spec::Module m;
     m.h0 = h0;
@@ -270,14 +321,24 @@ int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, cons
       remove(path.c_str());
       std::string err;
       code = compile(err);
-      if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
+      if (code.empty()) {
+        nsg_spec::failed()[key] = err;
+        return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
+      }
       store();
+      origin = NSG_SPEC_ORIGIN_HIPRTC;
       le = hipModuleLoadData(&m.mod, code.data());
     }
     if (le != hipSuccess) return fail(NSG_EHIP, "hipModuleLoadData: %s", hipGetErrorString(le));
+    m.origin = origin;
     if (group) {
       HIP_TRY(hipModuleGetFunction(&m.group, m.mod, "nsg_spec_group"));
-      HIP_TRY(hipModuleGetFunction(&m.group_rollout, m.mod, "nsg_spec_group_rollout"));
+      // a unit whose fused rollout would have spilled ships the single-step kernel alone (group_compile): rollouts of this member
+      // list then run the generic kernel
+      if (hipModuleGetFunction(&m.group_rollout, m.mod, "nsg_spec_group_rollout") != hipSuccess) {
+        (void)hipGetLastError();
+        m.group_rollout = nullptr;
+      }
     } else {
       HIP_TRY(hipModuleGetFunction(&m.step, m.mod, "nsg_spec_step"));
       HIP_TRY(hipModuleGetFunction(&m.rollout, m.mod, "nsg_spec_rollout"));
@@ -293,6 +354,58 @@ int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, cons
   return NSG_OK;
 }
 
+// What the unit of a (config, batch size) pair depends on besides the config itself, and its key.  Shared by nsg_specialize (the
+// handle's own config and size, the device's gcnArchName) and nsg_spec_prebuild (the same for a device that is not there).
+struct SpecPolicy {
+  bool full;          // full theta engine (transcendentals / ziggurat) or the plain-arithmetic one
+  bool inlane;        // CartPole batches of 2^16-2^17 envs (one wavefront per SIMD: the launch is bound by its serial chain) reset in-lane
+                      // like the rare-reset env types - no hand-over, no barriers: C1 5.84 -> 5.60 us and C2 (BASELINE's own 65 536 envs)
+                      // 7.80 -> 7.29 us at 2^16, +-0 at 2^17; smaller and larger batches lose (2^14: 5.3 -> 6.0, 2^18: 9.4 -> 10.1, 2^20: 23.7 -> 26.1)
+  bool stream_state;  // classic-control batches of 2^24 envs and more (2.5 GB of rows: nothing a launch writes is still in the 256-MiB
+                      // Infinity Cache when the next launch reads it) store their persistent rows non-temporally as well: C1 359.9 -> 348.6 us
+                      // at 2^24 envs, C2 634.9 -> 610.3, Pendulum 298.5 -> 290.7 (+-0 at 2^23 and below, and for the grid envs, whose rows
+                      // already leave through agent-scope stores)
+};
+bool cfg_simple_theta(const nsg_config& cfg) {
+  for (int p = 0; p < cfg.n_params; p++)
+    if (!upd_kind_is_simple(cfg.params[p].upd_kind) || sched_is_stochastic(cfg.params[p].sched_kind)) return false;
+  return true;
+}
+SpecPolicy spec_policy(const nsg_config& cfg, int64_t n) {
+  SpecPolicy p;
+  p.full = !cfg_simple_theta(cfg);
+  p.inlane = cfg.env_type == NSG_ENV_CARTPOLE && n >= 49152 && n <= 163840;
+  p.stream_state = !is_grid_env(cfg.env_type) && n >= (1 << 24);
+  return p;
+}
+// key: config bytes + engine variant + batch-size policy + target (+ the kernel sources this library was built from: spec_source_hash)
+uint64_t spec_key(const nsg_config& cfg, const SpecPolicy& p, const char* arch_name) {
+  uint64_t h0 = nsg_spec::fnv1a(&cfg, sizeof(nsg_config));
+  h0 = nsg_spec::fnv1a(&p.full, sizeof(p.full), h0);
+  h0 = nsg_spec::fnv1a(&p.inlane, sizeof(p.inlane), h0);
+  h0 = nsg_spec::fnv1a(&p.stream_state, sizeof(p.stream_state), h0);
+  h0 = nsg_spec::fnv1a(arch_name, strlen(arch_name), h0);
+  if (const char* e = getenv("NSG_SPEC_FLAGS")) h0 = nsg_spec::fnv1a(e, strlen(e), h0);
+  return h0;
+}
+uint64_t group_key(const uint64_t* member_keys, int n) {
+  uint64_t h0 = 0x67726f7570ull;  // "group"
+  for (int k = 0; k < n; k++) h0 = nsg_spec::fnv1a(&member_keys[k], sizeof(uint64_t), h0);
+  return h0;
+}
+int write_unit(const char* dir, uint64_t h0, const std::vector<char>& code) {
+  const std::string path = std::string(dir) + spec_file_name(h0, spec_source_hash());
+  const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return fail(NSG_EINVAL, "cannot write %s", tmp.c_str());
+  const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+  fclose(f);
+  if (!ok || rename(tmp.c_str(), path.c_str()) != 0) {
+    remove(tmp.c_str());
+    return fail(NSG_EINVAL, "cannot write %s", path.c_str());
+  }
+  return NSG_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -749,14 +862,15 @@ static int make_group_plan_locked(GroupPlan& plan, nsg_handle* const* hs, int n_
   // every member runs config-specialised kernels: so does the group (one unit for the ordered tuple of configs)
   plan.group_spec = nullptr;
   if (all_spec) {
-    uint64_t h0 = 0x67726f7570ull;  // "group"
     const nsg_config* cfgs[NSG_MAX_SEGMENTS];
     bool full[NSG_MAX_SEGMENTS];
+    uint64_t keys[NSG_MAX_SEGMENTS];
     for (int k = 0; k < n_handles; k++) {
-      h0 = nsg_spec::fnv1a(&hs[k]->spec->h0, sizeof(uint64_t), h0);
+      keys[k] = hs[k]->spec->h0;
       cfgs[k] = &hs[k]->host.cfg;
       full[k] = !hs[k]->host.simple_theta;
     }
+    const uint64_t h0 = group_key(keys, n_handles);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, hs[0]->device));
     const int rc = get_spec_module(hs[0]->device, h0, true,
@@ -870,7 +984,7 @@ int nsg_rollout_group(nsg_handle* const* hs, int32_t n_handles, const void* cons
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const Segment* ga = ps.table;
-  if (ps.group_spec) {
+  if (ps.group_spec && ps.group_spec->group_rollout) {
     void* args[] = {(void*)&ga, (void*)&n_handles, (void*)&ap, (void*)&k_steps, (void*)&ro};
     HIP_TRY(hipModuleLaunchKernel(ps.group_spec->group_rollout, ps.total_blocks, 1, 1, kBlock, 1, 1, (unsigned)ps.group_rollout_lds, s, args, nullptr));
   } else if (ps.all_simple) hipLaunchKernelGGL(rollout_group_kernel<false>, dim3(ps.total_blocks), dim3(kBlock), (size_t)ps.group_rollout_lds, s, ga, n_handles, ap, k_steps, ro);
@@ -905,7 +1019,8 @@ int nsg_step_group_kind(nsg_handle* const* hs, int32_t n_handles) {
   std::lock_guard<std::mutex> lock(g_plan_mutex);
   for (const GroupPlan& p : g_plans)
     if (same_members(p, hs, n_handles) && plan_is_current(p, hs))
-      return p.group_spec ? NSG_GROUP_SPECIALISED : p.all_simple ? NSG_GROUP_GENERIC_SIMPLE : NSG_GROUP_GENERIC_FULL;
+      return p.group_spec ? (p.group_spec->origin == NSG_SPEC_ORIGIN_PREBUILT ? NSG_GROUP_SPECIALISED_PREBUILT : NSG_GROUP_SPECIALISED)
+                          : p.all_simple ? NSG_GROUP_GENERIC_SIMPLE : NSG_GROUP_GENERIC_FULL;
   return NSG_GROUP_UNPLANNED;
 }
 
@@ -1100,30 +1215,45 @@ int nsg_specialize(nsg_handle* h) {
   if (h->spec) return NSG_OK;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, h->device));
-  const bool full = !h->host.simple_theta;
-  // key: config bytes + engine variant + target (+ the kernel sources this library was built from)
-  uint64_t h0 = nsg_spec::fnv1a(&h->host.cfg, sizeof(nsg_config));
-  h0 = nsg_spec::fnv1a(&full, sizeof(full), h0);
-  // CartPole batches of 2^16-2^17 envs (one wavefront per SIMD: the launch is bound by its serial chain) reset in-lane like the
-  // rare-reset env types - no hand-over, no barriers: C1 5.84 -> 5.60 us and C2 (BASELINE's own 65 536 envs) 7.80 -> 7.29 us at
-  // 2^16, +-0 at 2^17; smaller and larger batches lose (2^14: 5.3 -> 6.0, 2^18: 9.4 -> 10.1, 2^20: 23.7 -> 26.1)
-  const bool inlane = h->host.cfg.env_type == NSG_ENV_CARTPOLE && h->n >= 49152 && h->n <= 163840;
-  h0 = nsg_spec::fnv1a(&inlane, sizeof(inlane), h0);
-  // classic-control batches of 2^24 envs and more (2.5 GB of rows: nothing a launch writes is still in the 256-MiB Infinity Cache
-  // when the next launch reads it) store their persistent rows non-temporally as well: C1 359.9 -> 348.6 us at 2^24 envs, C2 634.9
-  // -> 610.3, Pendulum 298.5 -> 290.7 (+-0 at 2^23 and below, and for the grid envs, whose rows already leave through agent-scope
-  // stores)
-  const bool stream_state = !is_grid_env(h->host.cfg.env_type) && h->n >= (1 << 24);
-  h0 = nsg_spec::fnv1a(&stream_state, sizeof(stream_state), h0);
-  h0 = nsg_spec::fnv1a(prop.gcnArchName, strlen(prop.gcnArchName), h0);
-  if (const char* e = getenv("NSG_SPEC_FLAGS")) h0 = nsg_spec::fnv1a(e, strlen(e), h0);
+  const SpecPolicy pol = spec_policy(h->host.cfg, h->n);
+  const uint64_t h0 = spec_key(h->host.cfg, pol, prop.gcnArchName);
   const int rc = get_spec_module(h->device, h0, false,
-                                 [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, full, prop.gcnArchName, err, inlane, stream_state); }, &h->spec);
+                                 [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, pol.full, prop.gcnArchName, err, pol.inlane, pol.stream_state); }, &h->spec);
   h->generation++;   // a group that contains this handle re-plans (its specialised unit depends on every member's)
   return rc;
 }
 
 int nsg_is_specialized(const nsg_handle* h) { return h && h->spec ? 1 : 0; }
+int nsg_spec_origin(const nsg_handle* h) { return h && h->spec ? h->spec->origin : NSG_SPEC_ORIGIN_NONE; }
+
+int nsg_spec_prebuild(const nsg_config* cfg, int64_t n, const char* arch, const char* dir) {
+  if (!arch || !*arch || !dir || !*dir) return fail(NSG_EINVAL, "arch and dir are required");
+  if (n <= 0 || n > NSG_MAX_ENVS) return fail(NSG_EINVAL, "n must be in [1, 2^27]");
+  int rc = validate(cfg, (size_t)kMaxTableBytes);
+  if (rc) return rc;
+  const SpecPolicy pol = spec_policy(*cfg, n);
+  std::string err;
+  const std::vector<char> code = nsg_spec::spec_compile(*cfg, pol.full, arch, err, pol.inlane, pol.stream_state);
+  if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
+  return write_unit(dir, spec_key(*cfg, pol, arch), code);
+}
+
+int nsg_spec_prebuild_group(const nsg_config* const* cfgs, const int64_t* ns, int32_t count, const char* arch, const char* dir) {
+  if (!cfgs || !ns || count <= 0 || count > NSG_MAX_SEGMENTS || !arch || !*arch || !dir || !*dir) return fail(NSG_EINVAL, "bad arguments");
+  bool full[NSG_MAX_SEGMENTS];
+  uint64_t keys[NSG_MAX_SEGMENTS];
+  for (int k = 0; k < count; k++) {
+    int rc = validate(cfgs[k], (size_t)kMaxTableBytes);
+    if (rc) return rc;
+    const SpecPolicy pol = spec_policy(*cfgs[k], ns[k]);
+    full[k] = pol.full;
+    keys[k] = spec_key(*cfgs[k], pol, arch);
+  }
+  std::string err;
+  const std::vector<char> code = nsg_spec::group_compile(cfgs, full, count, arch, err);
+  if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
+  return write_unit(dir, group_key(keys, count), code);
+}
 
 int nsg_destroy(nsg_handle* h) {
   if (!h) return NSG_OK;

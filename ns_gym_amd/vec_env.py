@@ -169,6 +169,15 @@ class VecNSEnv:
     def specialized(self) -> bool:
         return bool(self.lib.nsg_is_specialized(self._h))
 
+    @property
+    def kernels(self) -> str:
+        """Which kernels `step()` / `rollout()` of this batch launch: "generic (precompiled)", or "config-specialised" plus where
+        that unit came from - "(prebuilt)": shipped with the library, built and inspected when the library was
+        (ns_gym_amd/prebuilt.py); "(hiprtc)": compiled by this process; "(disk cache)": compiled by an earlier process."""
+        origin = int(self.lib.nsg_spec_origin(self._h))
+        return {0: "generic (precompiled)", 1: "config-specialised (hiprtc)", 2: "config-specialised (disk cache)",
+                3: "config-specialised (prebuilt)"}[origin]
+
     # ------------------------------------------------------------------ tensor views
     def _make_views(self):
         N, P, b = self.N, max(self.cfg.n_params, 1), self.buf
@@ -649,7 +658,7 @@ def rollout_group(envs, actions, record=("obs", "reward", "terminated", "truncat
     return outs
 
 
-GROUP_KINDS = {0: "unplanned", 1: "generic", 2: "generic-full", 3: "specialised"}
+GROUP_KINDS = {0: "unplanned", 1: "generic", 2: "generic-full", 3: "specialised", 4: "specialised (prebuilt)"}
 
 
 def step_group_kind(envs) -> str:
