@@ -219,7 +219,7 @@ def test_large_batch_without_runtime_compiler_warns_and_runs_generic():
              "except NsgError as err:\n"
              "    assert 'libhiprtc' in str(err)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.run([sys.executable, "-c", child], cwd=root, check=True, env=dict(os.environ, NSG_NO_HIPRTC="1", NSG_SPEC_CACHE="off"), timeout=300)
+    subprocess.run([sys.executable, "-c", child], cwd=root, check=True, env=dict(os.environ, NSG_NO_HIPRTC="1", NSG_SPEC_CACHE="off", NSG_PREBUILT_DIR="off"), timeout=300)   # (C1's unit ships prebuilt: switched off here)
 
 
 def test_units_from_a_filled_cache_load_without_the_runtime_compiler(tmp_path):
@@ -237,7 +237,7 @@ def test_units_from_a_filled_cache_load_without_the_runtime_compiler(tmp_path):
              "a = W.random_actions(e)\n"
              "for _ in range(5): e.step(a)\n"
              "torch.cuda.synchronize()\n")
-    env = dict(os.environ, NSG_SPEC_CACHE=str(tmp_path))
+    env = dict(os.environ, NSG_SPEC_CACHE=str(tmp_path), NSG_PREBUILT_DIR="off")   # (C2's unit also ships prebuilt: switched off here)
     subprocess.run([sys.executable, "-c", child], cwd=root, check=True, env=env, timeout=300)
     assert len(list(tmp_path.glob("nsg_*.hsaco"))) == 1
     subprocess.run([sys.executable, "-c", child], cwd=root, check=True, env=dict(env, NSG_NO_HIPRTC="1"), timeout=300)
