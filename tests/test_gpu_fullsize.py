@@ -263,7 +263,7 @@ def test_c4_mixed_group_launch_at_full_size_equals_oracle(specialize):
         allow.after_step(k, acro, orcs[1])
         if k % 10 == 0 or k == T - 1:
             compare_views(pview._out(), poview._out(), False, f"C4 group launch, Pendulum member: all {n} envs, step {k}")
-    assert step_group_kind([pend, acro]) == ("specialised" if specialize else "generic")
+    assert step_group_kind([pend, acro]) == ("specialised (prebuilt)" if specialize else "generic")   # C4's own unit ships with the library
     allow.conclude(f"C4 group launch ({'specialised unit' if specialize else 'generic kernel'}), Acrobot member 2^18 x {T}")
     # the launch's ballot counters: every call of every env was a step or a reset
     for e in envs:
@@ -346,7 +346,7 @@ def test_c4_group_rollout_at_full_size_equals_group_steps():
                 for e, o in zip(stepped, outs):
                     assert torch.equal(o["obs"][k], e.state) and torch.equal(o["reward"][k], e.reward)
                     assert torch.equal(o["terminated"][k], e.terminated) and torch.equal(o["truncated"][k], e.truncated)
-    assert step_group_kind(fused) == "specialised"
+    assert step_group_kind(fused).startswith("specialised")
     for a, b, nm in zip(fused, stepped, names):
         for row in ("phys", "theta", "t", "episode", "obs", "reward", "terminated", "truncated", "ep_return", "last_return", "last_length"):
             assert torch.equal(a.buf[row], b.buf[row]), (nm, row)
