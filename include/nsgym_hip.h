@@ -375,8 +375,9 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
  * The first launch of a member list PLANS it (block ranges, a device-side segment table, the group's specialised unit when
  * every member is specialised): that synchronises the device once.  The plan is kept per member list and stays valid until
  * one of ITS members is re-bound, specialised or destroyed; other handles coming and going do not touch it.  A segment table
- * is never overwritten while anything - a launch in flight, a captured HIP graph - may read it (a table that a re-plan or an
- * eviction replaced stays allocated for the next 1024 such events, or until one of its members is destroyed).  On a capturing
+ * is never overwritten or freed while anything - a launch in flight, a captured HIP graph - may read it (a table that a re-plan, an
+ * eviction or the destruction of a member replaced stays allocated for the next 1024 such events; it is then freed behind a
+ * synchronisation of its own device, on a planning call, never inside nsg_destroy and never while the stream is capturing).  On a capturing
  * stream a launch that would have to plan first is refused (NSG_EINVAL): launch the group once before the capture. */
 int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* actions_dev,
                    void* stream);

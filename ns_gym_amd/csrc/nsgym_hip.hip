@@ -796,10 +796,27 @@ static void retire_table_locked(GroupPlan& p) {
   if (p.d_table) g_retired.emplace_back(p.device, p.d_table);
   p.d_table = nullptr;
 }
-// Frees the retired tables; the caller has established that no launch can still read them (device synchronised, no capture).
-static void drain_retired_locked() {
-  for (auto& r : g_retired) (void)hipFree(r.second);
-  g_retired.clear();
+// Frees the retired tables, each behind a synchronisation of ITS device (a process may hold handles on several GPUs; the current
+// device is restored).  The caller has established that no stream of this thread is capturing (acquire_group_plan).
+static int drain_retired_locked() {
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  std::sort(g_retired.begin(), g_retired.end());
+  int synced = -1;
+  hipError_t bad = hipSuccess;
+  for (auto& r : g_retired) {
+    if (r.first != synced) {
+      hipError_t e = hipSetDevice(r.first);
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+      if (e != hipSuccess) { bad = e; (void)hipGetLastError(); synced = -1; continue; }   // its tables stay parked
+      synced = r.first;
+    }
+    (void)hipFree(r.second);
+    r.second = nullptr;
+  }
+  g_retired.erase(std::remove_if(g_retired.begin(), g_retired.end(), [](const std::pair<int, Segment*>& r) { return r.second == nullptr; }), g_retired.end());
+  if (cur >= 0) (void)hipSetDevice(cur);
+  return bad == hipSuccess ? NSG_OK : fail(NSG_EHIP, "draining retired segment tables: %s", hipGetErrorString(bad));
 }
 static bool same_members(const GroupPlan& p, nsg_handle* const* hs, int n) {
   if (p.n_members != n) return false;
@@ -837,8 +854,8 @@ static int make_group_plan_locked(GroupPlan& plan, nsg_handle* const* hs, int n_
   }
   retire_table_locked(plan);   // never overwritten: something in flight, or a captured graph, may still read it
   if (g_retired.size() > kMaxRetiredTables) {
-    HIP_TRY(hipDeviceSynchronize());
-    drain_retired_locked();
+    const int rc = drain_retired_locked();
+    if (rc) return rc;
   }
   HIP_TRY(hipMalloc((void**)&plan.d_table, sizeof(Segment) * NSG_MAX_SEGMENTS));
   HIP_TRY(hipMemcpy(plan.d_table, tmp, sizeof(Segment) * n_handles, hipMemcpyHostToDevice));
@@ -1259,22 +1276,20 @@ int nsg_destroy(nsg_handle* h) {
   if (!h) return NSG_OK;
   {   // plans this handle is a member of go with it; their tables once nothing can read them any more
     std::lock_guard<std::mutex> lock(g_plan_mutex);
-    // only THEIR tables are freed here (nothing can legitimately launch a group with a destroyed member again); tables retired by
-    // re-plans or evictions of other groups stay parked - a captured graph of live handles may still point at them
-    std::vector<Segment*> dead;
+    // their tables are RETIRED, not freed: a destroy may come from a finalizer at any moment - while another thread's group launch
+    // is between taking its plan snapshot and enqueueing, or while a stream is capturing (a device synchronisation here would
+    // invalidate the capture).  Retired tables are freed by the next drain, which runs on a planning path that has checked for
+    // captures and synchronises each table's own device (drain_retired_locked); 16 KB each, at most kMaxRetiredTables parked.
     for (size_t q = 0; q < g_plans.size();) {
       bool member = false;
       for (int k = 0; k < g_plans[q].n_members; k++) member |= g_plans[q].ids[k] == h->id;
       if (member) {
-        if (g_plans[q].d_table) dead.push_back(g_plans[q].d_table);
+        retire_table_locked(g_plans[q]);
         g_plans.erase(g_plans.begin() + (long)q);
       } else {
         q++;
       }
     }
-    if (!dead.empty() && hipDeviceSynchronize() == hipSuccess)
-      for (Segment* t : dead) (void)hipFree(t);
-    (void)hipGetLastError();
   }
   if (h->d_tables) (void)hipFree(h->d_tables);
   if (h->d_zig) (void)hipFree(h->d_zig);
