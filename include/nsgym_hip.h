@@ -370,6 +370,53 @@ typedef struct nsg_rollout_out {
 int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const nsg_rollout_out* out,
                 void* stream);
 
+/* ---- resident stepper: closed loops in the launch-bound regime ---------------------------------------------------------------
+ * nsg_step costs a dependent launch per step (4-5 us on this stack before the kernel does anything); a batch of <= 2^17 envs is
+ * one wavefront per SIMD, whose step itself takes ~2.7 us.  Callers that can hand over K action rows at once use nsg_rollout; a
+ * CLOSED loop - a policy that needs step k's observation to choose action k + 1 - cannot.  nsg_resident_start launches ONE kernel
+ * that stays on the device, keeps the env state in registers / LDS like nsg_rollout, and takes a step whenever the producer of
+ * the actions publishes the next row through the mailbox (caller-owned DEVICE memory, ZEROED by the caller before every start):
+ *
+ *   producer (a kernel on another stream):  write actions_dev[0..N) for step k; if mb->stop is clear, release-store
+ *                                           mb->act_seq = k + 1 (agent scope)
+ *   stepper:   every workgroup polls act_seq >= k + 1, steps its 256 envs, stores ALL rows (persistent + outputs), fences;
+ *              the workgroup that completes the count release-stores mb->step_seq = k + 1
+ *   consumer:  polls step_seq >= k + 1 (acquire), reads the handle's output rows (obs, reward, terminated, ...)
+ *
+ * The wait is BOUNDED.  A workgroup that has waited `wait_budget_us` for the next row raises mb->stop itself; from the moment a
+ * workgroup sees `stop` raised (by a starved workgroup, or by anyone who wants the loop to end) it keeps looking for ONE more
+ * row for a grace period (200 us) and then leaves.  A producer that honours "do not publish once stop is raised" publishes at
+ * most one row in the shadow of a stop, microseconds after it; every workgroup is still polling then, so all of them take that
+ * step or none does.  The last workgroup to leave writes steps_done and status: NSG_MB_FINISHED (max_steps done),
+ * NSG_MB_STARVED (the producer went silent), NSG_MB_STOPPED (stop was raised from outside), or NSG_MB_TORN (the workgroups
+ * disagree on the step count: only possible with a producer that publishes after it has seen stop; the batch must be reset).
+ * Because every step stores every row, the handle's buffers then describe the batch exactly as after `steps_done` nsg_step
+ * calls - bit for bit - and nsg_step / nsg_rollout / another nsg_resident_start carry on from there.  While the kernel is
+ * resident nothing else may launch on the handle.  Batches of at most NSG_RESIDENT_MAX_ENVS envs (one workgroup per 256-env
+ * chunk, all of them resident at once). */
+typedef struct nsg_mailbox {
+  uint64_t act_seq;       /* producer -> stepper: k + 1 once the action row of step k is in place                  */
+  uint64_t step_seq;      /* stepper  -> consumer: k + 1 once step k's outputs are in the handle's rows              */
+  uint64_t stop;          /* non-zero = leave after the grace period (NSG_MB_STARVED when a starved workgroup raised it) */
+  uint64_t status;        /* 0 while resident / never started; NSG_MB_* once the launch has left                    */
+  uint64_t steps_done;    /* valid with status: every env has taken exactly this many steps since the start         */
+  uint64_t arrive, leave, taken_max, taken_min_inv, policy_arrive;   /* internal */
+  uint64_t reserved[6];
+} nsg_mailbox;
+#define NSG_MB_FINISHED 1u
+#define NSG_MB_STARVED 2u
+#define NSG_MB_STOPPED 3u
+#define NSG_MB_TORN 4u
+#define NSG_RESIDENT_MAX_ENVS (1 << 17)
+#define NSG_RESIDENT_GRACE_US 200u
+int nsg_resident_start(nsg_handle* h, const void* actions_dev, nsg_mailbox* mb_dev, int32_t max_steps, uint32_t wait_budget_us,
+                       void* stream);
+/* A stand-in policy for measurements and tests (discrete-action classic-control envs): a resident kernel on the OTHER side of the
+ * mailbox that, for each of max_steps steps, waits (bounded, same rules) for step_seq, writes
+ * action[i] = ((obs[i][watch] > 0) + k) mod n_actions and publishes act_seq.  Launch it on a stream of its own. */
+int nsg_resident_demo_policy(nsg_handle* h, int32_t watch, int32_t* actions_dev, nsg_mailbox* mb_dev, int32_t max_steps,
+                             uint32_t wait_budget_us, void* stream);
+
 /* Heterogeneous batch: one launch over up to NSG_MAX_SEGMENTS handles of different env
  * types (per-env-type dispatch is wave-uniform because segments are block-aligned).
  * The first launch of a member list PLANS it (block ranges, a device-side segment table, the group's specialised unit when

@@ -118,6 +118,158 @@ __global__ __launch_bounds__(kBlock, (kRolloutMinWaves<ENV, FULL>)) void rollout
   rollout_body<ENV, FULL>(seg->cfg, *seg, actions, k_steps, ro, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// ============================================================================================
+// Resident stepper (nsg_resident_start): ONE launch that stays on the device and takes a step whenever the producer of the
+// actions says the next action row is in place - for closed loops (policy kernel -> step -> policy kernel) in the launch-bound
+// regime, where a dependent launch per step costs more than the step (C2 at 65 536 envs: 6.6 us per nsg_step launch, 2.7 us per
+// step inside nsg_rollout).  One workgroup per 256-env chunk, all resident (the host refuses batches beyond that); state lives
+// in registers / LDS between steps exactly as in rollout_body, and every step ALSO stores its persistent rows, so whenever the
+// kernel leaves - max_steps reached, stop requested, or the wait for the next action row outlasted its budget - the handle's
+// buffers describe the env as after that many nsg_step calls and a normal launch can carry on.
+//
+// Hand-shake (nsg_mailbox, device memory, agent scope): the producer writes the action row of step k, then act_seq = k + 1
+// (release); every workgroup's first lane polls act_seq (acquire) - BOUNDED: a 100-MHz wall clock is read in the loop and the
+// workgroup gives up when `budget_ticks` have passed; after its step a workgroup fences (release) and adds itself to `arrive`;
+// the workgroup that completes the count publishes step_seq = k + 1.  No workgroup ever waits for another one of this kernel.
+// ============================================================================================
+struct ResidentArgs {
+  nsg_mailbox* mb;
+  int32_t max_steps;
+  int32_t reserved;
+  uint64_t budget_ticks;     // of the 100-MHz s_memrealtime clock: how long a workgroup waits for the next action row
+  uint64_t grace_ticks;      // how long it keeps looking for one more row after `stop` has been raised (see resident_wait)
+};
+
+__device__ __forceinline__ uint64_t mb_peek(const uint64_t* p) {   // polling read: agent scope, no ordering (the fence follows success)
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mb_publish(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One lane's bounded wait for `*seq >= want`.  Returns 1 (go), 0 (leave).  Nobody waits for ever: past `budget_ticks` the waiter
+// raises mb->stop itself (NSG_MB_STARVED); from the moment a waiter sees `stop` raised - by itself, by another workgroup, by the host -
+// it keeps polling for `grace_ticks` more and then leaves.  A producer reads `stop` before it publishes and publishes within a few
+// microseconds of that read; with a grace period far beyond that, a row published in the shadow of a stop is seen by EVERY
+// workgroup (each polls until at least stop-time + grace), so either all of them take that step or none does.
+__device__ __forceinline__ int resident_wait(nsg_mailbox* mb, const uint64_t* seq, uint64_t want, uint64_t budget_ticks, uint64_t grace_ticks,
+                                             uint64_t starved_code) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  uint64_t deadline = t0 + budget_ticks;
+  bool draining = false;
+  for (;;) {
+    if (mb_peek(seq) >= want) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the row published before `seq` is visible from here on
+      return 1;
+    }
+    const uint64_t now = __builtin_amdgcn_s_memrealtime();
+    if (!draining && mb_peek(&mb->stop) != 0u) {
+      draining = true;
+      deadline = now + grace_ticks;
+    }
+    if (now > deadline) {
+      if (draining) return 0;
+      uint64_t zero = 0u;    // first to give up says why; everybody (this lane included) then drains
+      __hip_atomic_compare_exchange_strong(&mb->stop, &zero, starved_code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      draining = true;
+      deadline = now + grace_ticks;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+template <int ENV, bool FULL>
+__device__ __forceinline__ void resident_body(const nsg_config& cfg, const Segment& sg, const void* __restrict__ actions, const ResidentArgs ra) {
+  __shared__ int go_on;
+  LdsTables lds;
+  Tables tb;
+  ZigLds zg;
+  constexpr bool GRID = ENV == NSG_ENV_FROZENLAKE || ENV == NSG_ENV_CLIFFWALKING || ENV == NSG_ENV_BRIDGE;
+  stage_tables<false, true, GRID ? 2 : 1>(sg, lds, tb, zg);
+  WaveCounts wc;
+  const nsg_buffers& b = sg.buf;
+  const int64_t N = sg.N;
+  StepOut out = default_out(b);
+  if (GRID) out.obs = nullptr;
+  const int64_t c = blockIdx.x;                       // one chunk per workgroup, all resident (checked by the host)
+  const unsigned n_wg = gridDim.x;
+  [[maybe_unused]] LaneState<GRID ? NSG_ENV_CARTPOLE : ENV> ls;
+  [[maybe_unused]] GridLane<ENV == NSG_ENV_CLIFFWALKING ? 4 : 3> gl;
+  [[maybe_unused]] const int64_t ir = c * kBlock + threadIdx.x;
+  if constexpr (!GRID) {   // the chunk's env streams, derived once per launch (see rollout_body)
+    if (ir < N) {
+      Pcg g;
+      const uint64_t count = (uint64_t)((uint32_t)ldg(b.episode, (uint32_t)ir * 4u) >> NSG_EP_COUNT_SHIFT);
+      const u64x2 desc = {zg.sd0, zg.sd1};
+      env_stream_at(b.rng_env, ir, count * (uint64_t)EnvTraits<GRID ? NSG_ENV_CARTPOLE : ENV>::RESET_DRAWS, zg.jump, g, &desc);
+      uint64_t* rec = lds.streams + threadIdx.x * 4;
+      rec[0] = g.sh; rec[1] = g.sl; rec[2] = g.ih; rec[3] = g.il;
+    }
+    if constexpr (FULL) {
+      if (ir < N) {
+        for (int p = 0; p < cfg.n_params; p++) {
+          const nsg_param_cfg& pc = cfg.params[p];
+          if (!pc.uses_rng || pc.fn_slot != p || upd_lds_index(cfg, p) >= kMaxLdsUpd) continue;
+          Pcg u;
+          pcg_load(b.rng_upd + (int64_t)p * 4 * N, N, ir, u);
+          uint64_t* ur = lds.ustreams + ((int64_t)upd_lds_index(cfg, p) * kBlock + threadIdx.x) * 4;
+          ur[0] = u.sh; ur[1] = u.sl; ur[2] = u.ih; ur[3] = u.il;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  int parity = 0, taken = 0;
+  for (int k = 0; k < ra.max_steps; k++) {
+    if (threadIdx.x == 0) go_on = resident_wait(ra.mb, &ra.mb->act_seq, (uint64_t)k + 1u, ra.budget_ticks, ra.grace_ticks, NSG_MB_STARVED);
+    __syncthreads();
+    const int ok = go_on;
+    __syncthreads();            // (go_on is rewritten by the next iteration's first lane)
+    if (!ok) break;
+    if constexpr (GRID) {
+      step_grid<ENV, FULL>(cfg, b, N, tb, zg, actions, out, ir, ir < N, wc, gl, IoMode{k == 0, true, k > 0, false});
+    } else {
+      step_chunk<ENV, FULL>(cfg, b, N, tb, zg, actions, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, true, k > 0, true});
+    }
+    parity ^= 1;
+    taken++;
+    // this chunk's rows and outputs are out: release them, count this workgroup in; the one that completes the count publishes the step
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long seen = atomicAdd((unsigned long long*)&ra.mb->arrive, 1ULL);
+      if (seen + 1ULL == (unsigned long long)n_wg * (unsigned long long)(k + 1)) mb_publish(&ra.mb->step_seq, (uint64_t)k + 1u);
+    }
+  }
+  if constexpr (!GRID && FULL) {   // the update-fn streams held in LDS go back to their rows
+    __syncthreads();
+    if (ir < N) {
+      for (int p = 0; p < cfg.n_params; p++) {
+        const nsg_param_cfg& pc = cfg.params[p];
+        if (!pc.uses_rng || pc.fn_slot != p || upd_lds_index(cfg, p) >= kMaxLdsUpd) continue;
+        const uint64_t* ur = lds.ustreams + ((int64_t)upd_lds_index(cfg, p) * kBlock + threadIdx.x) * 4;
+        Pcg u = {ur[0], ur[1], 0, 0};
+        pcg_store_state(b.rng_upd + (int64_t)p * 4 * N, N, ir, u);
+      }
+    }
+  }
+  flush_counts(b.counters, (int)blockIdx.x, wc);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {       // the last workgroup out reports how the launch ended and how many steps the chunks have taken
+    atomicMax((unsigned long long*)&ra.mb->taken_max, (unsigned long long)taken);
+    atomicMax((unsigned long long*)&ra.mb->taken_min_inv, 0xffffffffULL - (unsigned long long)taken);
+    const unsigned long long seen = atomicAdd((unsigned long long*)&ra.mb->leave, 1ULL);
+    if (seen + 1ULL == (unsigned long long)n_wg) {
+      const uint64_t mx = mb_peek(&ra.mb->taken_max), mn = 0xffffffffULL - mb_peek(&ra.mb->taken_min_inv);
+      const uint64_t stop = mb_peek(&ra.mb->stop);
+      mb_publish(&ra.mb->steps_done, mn);
+      mb_publish(&ra.mb->status, mn != mx ? (uint64_t)NSG_MB_TORN : mn == (uint64_t)ra.max_steps ? (uint64_t)NSG_MB_FINISHED
+                                                                  : stop == NSG_MB_STARVED ? (uint64_t)NSG_MB_STARVED : (uint64_t)NSG_MB_STOPPED);
+    }
+  }
+}
+
 // Heterogeneous fused rollout (nsg_rollout_group): K steps of every member in ONE launch, a block range per member like
 // step_group_kernel; each member's persistent rows stay in registers / LDS for the K steps exactly as in nsg_rollout.
 struct RolloutOuts {
@@ -125,6 +277,40 @@ struct RolloutOuts {
 };
 
 #ifndef NSG_SPEC_BUILD
+template <int ENV, bool FULL>
+__global__ __launch_bounds__(kBlock) void resident_kernel(const Segment* __restrict__ seg, const void* __restrict__ actions, ResidentArgs ra) {
+  resident_body<ENV, FULL>(seg->cfg, *seg, actions, ra);
+}
+
+// A stand-in for the caller's policy (tools / tests / bench: the closed loop needs SOMETHING on the other side of the mailbox): a
+// resident kernel that, for every step, waits for the stepper's step_seq (bounded by the same rules), writes the discrete action
+// ((obs[i][watch] > 0) + k) mod n_actions for every env, reads `stop` and - if it is clear - publishes act_seq.  One workgroup per chunk.
+__global__ __launch_bounds__(kBlock) void resident_demo_policy_kernel(const float* __restrict__ obs, int obs_dim, int watch, int32_t* __restrict__ actions,
+                                                                     int64_t N, int n_actions, ResidentArgs ra) {
+  __shared__ int go_on;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const unsigned n_wg = gridDim.x;
+  for (int k = 0; k < ra.max_steps; k++) {
+    // the observation of step k - 1 (the reset observation before the first step: nothing to wait for)
+    if (threadIdx.x == 0) go_on = resident_wait(ra.mb, &ra.mb->step_seq, (uint64_t)k, ra.budget_ticks, ra.grace_ticks, NSG_MB_STARVED);
+    __syncthreads();
+    const int ok = go_on;
+    __syncthreads();
+    if (!ok) return;
+    if (i < N) {
+      const float x = __builtin_nontemporal_load(obs + i * obs_dim + watch);
+      actions[i] = (int32_t)(((x > 0.f ? 1 : 0) + k) % n_actions);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long seen = atomicAdd((unsigned long long*)&ra.mb->policy_arrive, 1ULL);
+      // a producer never publishes once it has seen `stop` (resident_wait's grace period relies on it)
+      if (seen + 1ULL == (unsigned long long)n_wg * (unsigned long long)(k + 1) && mb_peek(&ra.mb->stop) == 0u) mb_publish(&ra.mb->act_seq, (uint64_t)k + 1u);
+    }
+  }
+}
+
 template <bool FULL>
 __global__ __launch_bounds__(kBlock) void rollout_group_kernel(const Segment* __restrict__ segs, int nseg, ActionPtrs acts, int k_steps,
                                                                RolloutOuts outs) {

@@ -764,6 +764,53 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
   return NSG_OK;
 }
 
+// ---- resident stepper (nsg_rollout.hip.h: resident_body) -----------------------------------------------------------------
+int nsg_resident_start(nsg_handle* h, const void* actions_dev, nsg_mailbox* mb_dev, int32_t max_steps, uint32_t wait_budget_us, void* stream) {
+  if (!h) return fail(NSG_EINVAL, "handle is NULL");
+  if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
+  if (!actions_dev || !mb_dev || max_steps <= 0 || wait_budget_us == 0) return fail(NSG_EINVAL, "bad resident-stepper arguments");
+  if (h->n > NSG_RESIDENT_MAX_ENVS)
+    return fail(NSG_EINVAL, "the resident stepper keeps one workgroup per 256-env chunk on the device at once: at most %d envs (this batch: %lld); "
+                            "larger batches are bound by memory, not by launches - use nsg_step / nsg_rollout", NSG_RESIDENT_MAX_ENVS, (long long)h->n);
+  const int grid = (int)((h->n + kBlock - 1) / kBlock);
+  const size_t lds = (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp) +
+                     (is_grid_env(h->host.cfg.env_type) ? 0 : kLdsStreamBytes * (1 + upd_lds_count(h->host.cfg)));
+  ResidentArgs ra;
+  ra.mb = mb_dev;
+  ra.max_steps = max_steps;
+  ra.reserved = 0;
+  ra.budget_ticks = (uint64_t)wait_budget_us * 100u;          // s_memrealtime counts at 100 MHz
+  ra.grace_ticks = (uint64_t)NSG_RESIDENT_GRACE_US * 100u;
+  hipStream_t s = (hipStream_t)stream;
+  if (h->host.simple_theta) {
+    DISPATCH_ENV(h->host.cfg.env_type, hipLaunchKernelGGL((resident_kernel<E, false>), dim3(grid), dim3(kBlock), lds, s, h->dev, actions_dev, ra));
+  } else {
+    DISPATCH_ENV(h->host.cfg.env_type, hipLaunchKernelGGL((resident_kernel<E, true>), dim3(grid), dim3(kBlock), lds, s, h->dev, actions_dev, ra));
+  }
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
+int nsg_resident_demo_policy(nsg_handle* h, int32_t watch, int32_t* actions_dev, nsg_mailbox* mb_dev, int32_t max_steps, uint32_t wait_budget_us,
+                             void* stream) {
+  if (!h || !h->bound) return fail(NSG_ENOTBOUND, "a bound handle is required");
+  const int e = h->host.cfg.env_type;
+  if (is_grid_env(e) || kNActions[e] <= 0) return fail(NSG_EINVAL, "the demo policy drives discrete-action classic-control envs");
+  if (!actions_dev || !mb_dev || max_steps <= 0 || wait_budget_us == 0 || watch < 0 || watch >= kObsDim[e]) return fail(NSG_EINVAL, "bad demo-policy arguments");
+  if (h->n > NSG_RESIDENT_MAX_ENVS) return fail(NSG_EINVAL, "at most %d envs", NSG_RESIDENT_MAX_ENVS);
+  ResidentArgs ra;
+  ra.mb = mb_dev;
+  ra.max_steps = max_steps;
+  ra.reserved = 0;
+  ra.budget_ticks = (uint64_t)wait_budget_us * 100u;
+  ra.grace_ticks = (uint64_t)NSG_RESIDENT_GRACE_US * 100u;
+  const int grid = (int)((h->n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(resident_demo_policy_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, (const float*)h->host.buf.obs, kObsDim[e], watch,
+                     actions_dev, h->n, kNActions[e], ra);
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
 // ---- heterogeneous launches: plans ---------------------------------------------------------------------------------------
 // A launch of nsg_step_group reads a segment table: copies of its members' segments with their block ranges, passed as a
 // `const __restrict__` kernel argument (scalar loads, see step_group_kernel).  What is remembered about a member list is a PLAN:

@@ -615,6 +615,67 @@ class VecNSEnv:
             pass
 
 
+class ResidentStepper:
+    """A closed loop in the launch-bound regime (`nsg_resident_start`, include/nsgym_hip.h): ONE kernel stays on the device and takes a
+    step of `env` whenever the producer of the actions publishes the next row through the mailbox - no launch per step.
+
+        loop = ResidentStepper(env, actions)            # actions: the int32 / float32 [N] device tensor the producer rewrites
+        loop.start(max_steps, stream=side)              # zeroes the mailbox, launches the stepper on `side`
+        ... the producer: for k in 0 .. : wait for loop.step_seq >= k, write `actions`, publish act_seq = k + 1 ...
+        status, steps = loop.result()                   # waits for the kernel to leave: "finished" / "starved" / "stopped" / "torn"
+
+    Every wait on the device is bounded (`wait_budget_us`, then a 200-us grace period): a producer that goes silent costs that long,
+    never a hung process.  Every step stores every row, so afterwards `env` is exactly where `steps` calls of `env.step` would have
+    left it and ordinary `step()` / `rollout()` calls carry on.  Batches of at most 2^17 envs."""
+
+    WORDS = 16
+    STATUS = {0: "resident", 1: "finished", 2: "starved", 3: "stopped", 4: "torn"}
+
+    def __init__(self, env: "VecNSEnv", actions, wait_budget_us: int = 2000):
+        self.env, self.budget = env, int(wait_budget_us)
+        self.actions = env._as_actions(actions)
+        self.mailbox = torch.zeros(self.WORDS, dtype=torch.int64, device=env.device)   # nsg_mailbox
+        self._stream = None
+
+    def start(self, max_steps: int, stream=None):
+        e = self.env
+        cur = torch.cuda.current_stream(e.device)
+        stream = stream or cur
+        self.mailbox.zero_()                      # on the current stream; stepper and producer are ordered behind this point
+        self._zeroed = torch.cuda.Event()
+        self._zeroed.record(cur)
+        stream.wait_event(self._zeroed)
+        with torch.cuda.stream(stream):
+            _lib.check(e.lib.nsg_resident_start(e._h, self.actions.data_ptr(), self.mailbox.data_ptr(), int(max_steps), self.budget,
+                                                C.c_void_p(stream.cuda_stream)), "nsg_resident_start")
+        self._stream = stream
+        return self
+
+    def demo_policy(self, max_steps: int, stream, watch: int = 2):
+        """The library's stand-in producer (discrete-action classic-control envs), resident on `stream`: action[i] =
+        ((obs[i][watch] > 0) + k) mod n_actions.  `stream` must differ from the stepper's; it is ordered behind the mailbox's zeroing."""
+        e = self.env
+        assert stream != self._stream, "stepper and producer must run concurrently: give the producer a stream of its own"
+        stream.wait_event(self._zeroed)           # behind the mailbox's zeroing, NOT behind the stepper
+        with torch.cuda.stream(stream):
+            _lib.check(e.lib.nsg_resident_demo_policy(e._h, int(watch), self.actions.data_ptr(), self.mailbox.data_ptr(), int(max_steps), self.budget,
+                                                      C.c_void_p(stream.cuda_stream)), "nsg_resident_demo_policy")
+        return self
+
+    def stop(self, stream=None):
+        """Raise `stop` from another stream: producer and stepper leave after at most one more step."""
+        stream = stream or torch.cuda.Stream(self.env.device)
+        with torch.cuda.stream(stream):
+            self.mailbox[2:3].fill_(3)
+        return self
+
+    def result(self):
+        """(status, steps_done) once the stepper has left (waits for it)."""
+        self._stream.synchronize()
+        w = self.mailbox.cpu().tolist()
+        return self.STATUS.get(int(w[3]), str(w[3])), int(w[4])
+
+
 def step_group(envs, actions):
     """One heterogeneous launch over several VecNSEnv of different env types (per-env-type
     dispatch is uniform per workgroup)."""
