@@ -377,43 +377,48 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
  * that stays on the device, keeps the env state in registers / LDS like nsg_rollout, and takes a step whenever the producer of
  * the actions publishes the next row through the mailbox (caller-owned DEVICE memory, ZEROED by the caller before every start):
  *
- *   producer (a kernel on another stream):  write actions_dev[0..N) for step k; if mb->stop is clear, release-store
- *                                           mb->act_seq = k + 1 (agent scope)
- *   stepper:   every workgroup polls act_seq >= k + 1, steps its 256 envs, stores ALL rows (persistent + outputs), fences;
- *              the workgroup that completes the count release-stores mb->step_seq = k + 1
- *   consumer:  polls step_seq >= k + 1 (acquire), reads the handle's output rows (obs, reward, terminated, ...)
+ *   producer (kernels / a resident kernel on another stream), per 256-env CHUNK j:  write actions_dev[256 j .. 256 j + 256) for step
+ *              k; if mb->stop is clear, release-store mb->act_seq[j] = k + 1 (agent scope)
+ *   stepper:   the workgroup of chunk j polls act_seq[j] >= k + 1, steps its 256 envs, stores their OUTPUT rows, fences, release-stores
+ *              mb->step_seq[j] = k + 1
+ *   consumer:  polls step_seq[j] >= k + 1 (acquire), reads chunk j of the handle's output rows (obs, reward, terminated, ...)
  *
- * The wait is BOUNDED.  A workgroup that has waited `wait_budget_us` for the next row raises mb->stop itself; from the moment a
+ * The hand-shake is per chunk on purpose: a counter that all workgroups of a step add themselves to costs tens of microseconds
+ * per step on this chip (256 same-address device-scope atomics serialise at the memory side - measured, profiles/NOTEBOOK.md),
+ * more than the launches the resident kernel is there to save.  A policy that works env by env (or chunk by chunk) pairs its
+ * workgroup j with the stepper's; one that needs the whole batch waits for every step_seq[j] on its own side.
+ *
+ * The wait is BOUNDED.  A workgroup that has waited `wait_budget_us` for its next row raises mb->stop itself; from the moment a
  * workgroup sees `stop` raised (by a starved workgroup, or by anyone who wants the loop to end) it keeps looking for ONE more
- * row for a grace period (200 us) and then leaves.  A producer that honours "do not publish once stop is raised" publishes at
- * most one row in the shadow of a stop, microseconds after it; every workgroup is still polling then, so all of them take that
- * step or none does.  The last workgroup to leave writes steps_done and status: NSG_MB_FINISHED (max_steps done),
- * NSG_MB_STARVED (the producer went silent), NSG_MB_STOPPED (stop was raised from outside), or NSG_MB_TORN (the workgroups
- * disagree on the step count: only possible with a producer that publishes after it has seen stop; the batch must be reset).
- * Because every step stores every row, the handle's buffers then describe the batch exactly as after `steps_done` nsg_step
- * calls - bit for bit - and nsg_step / nsg_rollout / another nsg_resident_start carry on from there.  While the kernel is
- * resident nothing else may launch on the handle.  Batches of at most NSG_RESIDENT_MAX_ENVS envs (one workgroup per 256-env
- * chunk, all of them resident at once). */
+ * row for a grace period (NSG_RESIDENT_GRACE_US) and then leaves.  A producer that honours "do not publish once stop is raised"
+ * publishes at most one more step in the shadow of a stop, microseconds after it; every workgroup is still polling then, so all
+ * of them take that step or none does.  Leaving, a workgroup writes its persistent rows back; the last one out writes steps_done
+ * and status: NSG_MB_FINISHED (max_steps done), NSG_MB_STARVED (the producer went silent), NSG_MB_STOPPED (stop was raised from
+ * outside), or NSG_MB_TORN (the chunks disagree on the step count: only possible with a producer that publishes after it has
+ * seen stop, or that feeds some chunks and not others; the batch must be reset).  The handle's buffers then describe the batch
+ * exactly as after `steps_done` nsg_step calls - bit for bit - and nsg_step / nsg_rollout / another nsg_resident_start carry on
+ * from there.  While the kernel is resident nothing else may launch on the handle.  Batches of at most NSG_RESIDENT_MAX_ENVS envs
+ * (one workgroup per chunk, all of them resident at once). */
+#define NSG_RESIDENT_MAX_ENVS (1 << 17)
+#define NSG_RESIDENT_MAX_CHUNKS (NSG_RESIDENT_MAX_ENVS / 256)
+#define NSG_RESIDENT_GRACE_US 200u
 typedef struct nsg_mailbox {
-  uint64_t act_seq;       /* producer -> stepper: k + 1 once the action row of step k is in place                  */
-  uint64_t step_seq;      /* stepper  -> consumer: k + 1 once step k's outputs are in the handle's rows              */
-  uint64_t stop;          /* non-zero = leave after the grace period (NSG_MB_STARVED when a starved workgroup raised it) */
-  uint64_t status;        /* 0 while resident / never started; NSG_MB_* once the launch has left                    */
-  uint64_t steps_done;    /* valid with status: every env has taken exactly this many steps since the start         */
-  uint64_t arrive, leave, taken_max, taken_min_inv, policy_arrive;   /* internal */
-  uint64_t reserved[6];
+  uint64_t stop;          /* non-zero = leave after the grace period (NSG_MB_STARVED when a starved workgroup raised it)       */
+  uint64_t status;        /* 0 while resident / never started; NSG_MB_* once the launch has left                          */
+  uint64_t steps_done;    /* valid with status: every env has taken exactly this many steps since the start               */
+  uint64_t leave, taken_max, taken_min_inv, reserved[2];   /* internal */
+  uint64_t act_seq[NSG_RESIDENT_MAX_CHUNKS];    /* producer -> stepper, per chunk: k + 1 once chunk j's actions of step k are in place */
+  uint64_t step_seq[NSG_RESIDENT_MAX_CHUNKS];   /* stepper -> consumer, per chunk: k + 1 once chunk j's outputs of step k are in the rows */
 } nsg_mailbox;
 #define NSG_MB_FINISHED 1u
 #define NSG_MB_STARVED 2u
 #define NSG_MB_STOPPED 3u
 #define NSG_MB_TORN 4u
-#define NSG_RESIDENT_MAX_ENVS (1 << 17)
-#define NSG_RESIDENT_GRACE_US 200u
 int nsg_resident_start(nsg_handle* h, const void* actions_dev, nsg_mailbox* mb_dev, int32_t max_steps, uint32_t wait_budget_us,
                        void* stream);
 /* A stand-in policy for measurements and tests (discrete-action classic-control envs): a resident kernel on the OTHER side of the
- * mailbox that, for each of max_steps steps, waits (bounded, same rules) for step_seq, writes
- * action[i] = ((obs[i][watch] > 0) + k) mod n_actions and publishes act_seq.  Launch it on a stream of its own. */
+ * mailbox whose workgroup j, for each of max_steps steps, waits (bounded, same rules) for step_seq[j], writes
+ * action[i] = ((obs[i][watch] > 0) + k) mod n_actions for its chunk and publishes act_seq[j].  Launch it on a stream of its own. */
 int nsg_resident_demo_policy(nsg_handle* h, int32_t watch, int32_t* actions_dev, nsg_mailbox* mb_dev, int32_t max_steps,
                              uint32_t wait_budget_us, void* stream);
 

@@ -127,16 +127,16 @@ __global__ __launch_bounds__(kBlock, (kRolloutMinWaves<ENV, FULL>)) void rollout
 // kernel leaves - max_steps reached, stop requested, or the wait for the next action row outlasted its budget - the handle's
 // buffers describe the env as after that many nsg_step calls and a normal launch can carry on.
 //
-// Hand-shake (nsg_mailbox, device memory, agent scope): the producer writes the action row of step k, then act_seq = k + 1
-// (release); every workgroup's first lane polls act_seq (acquire) - BOUNDED: a 100-MHz wall clock is read in the loop and the
-// workgroup gives up when `budget_ticks` have passed; after its step a workgroup fences (release) and adds itself to `arrive`;
-// the workgroup that completes the count publishes step_seq = k + 1.  No workgroup ever waits for another one of this kernel.
+// Hand-shake (nsg_mailbox, device memory, agent scope), PER CHUNK: the producer writes chunk j's actions of step k, then
+// act_seq[j] = k + 1 (release); the chunk's workgroup polls it (its first lane; acquire on success) - BOUNDED: the device's steady
+// wall clock is read in the loop (resident_wait); after its step the workgroup fences (release) and publishes step_seq[j] = k + 1.
+// No workgroup ever waits for another one of this kernel, and nothing in a step is a same-address atomic.
 // ============================================================================================
 struct ResidentArgs {
   nsg_mailbox* mb;
   int32_t max_steps;
   int32_t reserved;
-  uint64_t budget_ticks;     // of the 100-MHz s_memrealtime clock: how long a workgroup waits for the next action row
+  uint64_t budget_ticks;     // of the device's steady wall clock (hipDeviceAttributeWallClockRate): how long a workgroup waits for its next action row
   uint64_t grace_ticks;      // how long it keeps looking for one more row after `stop` has been raised (see resident_wait)
 };
 
@@ -154,7 +154,7 @@ __device__ __forceinline__ void mb_publish(uint64_t* p, uint64_t v) {
 // workgroup (each polls until at least stop-time + grace), so either all of them take that step or none does.
 __device__ __forceinline__ int resident_wait(nsg_mailbox* mb, const uint64_t* seq, uint64_t want, uint64_t budget_ticks, uint64_t grace_ticks,
                                              uint64_t starved_code) {
-  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  const uint64_t t0 = (uint64_t)wall_clock64();
   uint64_t deadline = t0 + budget_ticks;
   bool draining = false;
   for (;;) {
@@ -162,7 +162,7 @@ __device__ __forceinline__ int resident_wait(nsg_mailbox* mb, const uint64_t* se
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the row published before `seq` is visible from here on
       return 1;
     }
-    const uint64_t now = __builtin_amdgcn_s_memrealtime();
+    const uint64_t now = (uint64_t)wall_clock64();
     if (!draining && mb_peek(&mb->stop) != 0u) {
       draining = true;
       deadline = now + grace_ticks;
@@ -221,24 +221,36 @@ __device__ __forceinline__ void resident_body(const nsg_config& cfg, const Segme
   }
   int parity = 0, taken = 0;
   for (int k = 0; k < ra.max_steps; k++) {
-    if (threadIdx.x == 0) go_on = resident_wait(ra.mb, &ra.mb->act_seq, (uint64_t)k + 1u, ra.budget_ticks, ra.grace_ticks, NSG_MB_STARVED);
+    if (threadIdx.x == 0) go_on = resident_wait(ra.mb, &ra.mb->act_seq[c], (uint64_t)k + 1u, ra.budget_ticks, ra.grace_ticks, NSG_MB_STARVED);
     __syncthreads();
     const int ok = go_on;
     __syncthreads();            // (go_on is rewritten by the next iteration's first lane)
     if (!ok) break;
     if constexpr (GRID) {
+      // (a grid env's observation IS its cell row, its info["prob"] the prob row: both live in the persistent-store block - every step stores)
       step_grid<ENV, FULL>(cfg, b, N, tb, zg, actions, out, ir, ir < N, wc, gl, IoMode{k == 0, true, k > 0, false});
     } else {
-      step_chunk<ENV, FULL>(cfg, b, N, tb, zg, actions, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, true, k > 0, true});
+      // outputs every step; the persistent rows stay in registers / LDS until the workgroup leaves (flush below)
+      step_chunk<ENV, FULL>(cfg, b, N, tb, zg, actions, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, false, k > 0, true});
     }
     parity ^= 1;
     taken++;
-    // this chunk's rows and outputs are out: release them, count this workgroup in; the one that completes the count publishes the step
-    __threadfence();
+    // this chunk's outputs are out: release them and say so
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned long long seen = atomicAdd((unsigned long long*)&ra.mb->arrive, 1ULL);
-      if (seen + 1ULL == (unsigned long long)n_wg * (unsigned long long)(k + 1)) mb_publish(&ra.mb->step_seq, (uint64_t)k + 1u);
+    if (threadIdx.x == 0) mb_publish(&ra.mb->step_seq[c], (uint64_t)k + 1u);
+  }
+  if constexpr (!GRID) {   // leaving: the persistent rows go back (what a step with io.store does, step_chunk)
+    if (taken > 0 && ir < N) {
+      using T = EnvTraits<GRID ? NSG_ENV_CARTPOLE : ENV>;
+      const uint32_t o4 = (uint32_t)ir * 4u, o8 = (uint32_t)ir * 8u;
+#pragma unroll
+      for (int q = 0; q < T::PHYS; q++) stg(b.phys, blk_off8(T::PHYS, q, ir), ls.s[q]);
+      stg(b.t, o4, ls.t);
+      stg(b.episode, o4, (int32_t)ls.st);
+      if (cfg.n_params > 0) stg(b.theta, o8, ls.th0);
+      if (cfg.n_params > 1) stg(b.theta + N, o8, ls.th1);
+      if ((cfg.flags & NSG_F_TRACK_RETURNS) && T::RETURN_PER_STEP == 0.f) stg(b.ep_return, o4, ls.er);
     }
   }
   if constexpr (!GRID && FULL) {   // the update-fn streams held in LDS go back to their rows
@@ -289,10 +301,9 @@ __global__ __launch_bounds__(kBlock) void resident_demo_policy_kernel(const floa
                                                                      int64_t N, int n_actions, ResidentArgs ra) {
   __shared__ int go_on;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const unsigned n_wg = gridDim.x;
   for (int k = 0; k < ra.max_steps; k++) {
     // the observation of step k - 1 (the reset observation before the first step: nothing to wait for)
-    if (threadIdx.x == 0) go_on = resident_wait(ra.mb, &ra.mb->step_seq, (uint64_t)k, ra.budget_ticks, ra.grace_ticks, NSG_MB_STARVED);
+    if (threadIdx.x == 0) go_on = resident_wait(ra.mb, &ra.mb->step_seq[blockIdx.x], (uint64_t)k, ra.budget_ticks, ra.grace_ticks, NSG_MB_STARVED);
     __syncthreads();
     const int ok = go_on;
     __syncthreads();
@@ -301,13 +312,10 @@ __global__ __launch_bounds__(kBlock) void resident_demo_policy_kernel(const floa
       const float x = __builtin_nontemporal_load(obs + i * obs_dim + watch);
       actions[i] = (int32_t)(((x > 0.f ? 1 : 0) + k) % n_actions);
     }
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned long long seen = atomicAdd((unsigned long long*)&ra.mb->policy_arrive, 1ULL);
-      // a producer never publishes once it has seen `stop` (resident_wait's grace period relies on it)
-      if (seen + 1ULL == (unsigned long long)n_wg * (unsigned long long)(k + 1) && mb_peek(&ra.mb->stop) == 0u) mb_publish(&ra.mb->act_seq, (uint64_t)k + 1u);
-    }
+    // a producer never publishes once it has seen `stop` (resident_wait's grace period relies on it)
+    if (threadIdx.x == 0 && mb_peek(&ra.mb->stop) == 0u) mb_publish(&ra.mb->act_seq[blockIdx.x], (uint64_t)k + 1u);
   }
 }
 

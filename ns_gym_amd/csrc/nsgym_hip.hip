@@ -779,8 +779,11 @@ int nsg_resident_start(nsg_handle* h, const void* actions_dev, nsg_mailbox* mb_d
   ra.mb = mb_dev;
   ra.max_steps = max_steps;
   ra.reserved = 0;
-  ra.budget_ticks = (uint64_t)wait_budget_us * 100u;          // s_memrealtime counts at 100 MHz
-  ra.grace_ticks = (uint64_t)NSG_RESIDENT_GRACE_US * 100u;
+  int khz = 0;   // the device's steady wall clock (wall_clock64() in the kernel)
+  HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device));
+  if (khz <= 0) return fail(NSG_EHIP, "the device reports no wall-clock rate: the resident stepper cannot bound its waits");
+  ra.budget_ticks = (uint64_t)wait_budget_us * (uint64_t)khz / 1000u;
+  ra.grace_ticks = (uint64_t)NSG_RESIDENT_GRACE_US * (uint64_t)khz / 1000u;
   hipStream_t s = (hipStream_t)stream;
   if (h->host.simple_theta) {
     DISPATCH_ENV(h->host.cfg.env_type, hipLaunchKernelGGL((resident_kernel<E, false>), dim3(grid), dim3(kBlock), lds, s, h->dev, actions_dev, ra));
@@ -802,8 +805,11 @@ int nsg_resident_demo_policy(nsg_handle* h, int32_t watch, int32_t* actions_dev,
   ra.mb = mb_dev;
   ra.max_steps = max_steps;
   ra.reserved = 0;
-  ra.budget_ticks = (uint64_t)wait_budget_us * 100u;
-  ra.grace_ticks = (uint64_t)NSG_RESIDENT_GRACE_US * 100u;
+  int khz = 0;
+  HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device));
+  if (khz <= 0) return fail(NSG_EHIP, "the device reports no wall-clock rate");
+  ra.budget_ticks = (uint64_t)wait_budget_us * (uint64_t)khz / 1000u;
+  ra.grace_ticks = (uint64_t)NSG_RESIDENT_GRACE_US * (uint64_t)khz / 1000u;
   const int grid = (int)((h->n + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(resident_demo_policy_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, (const float*)h->host.buf.obs, kObsDim[e], watch,
                      actions_dev, h->n, kNActions[e], ra);

@@ -628,7 +628,9 @@ class ResidentStepper:
     never a hung process.  Every step stores every row, so afterwards `env` is exactly where `steps` calls of `env.step` would have
     left it and ordinary `step()` / `rollout()` calls carry on.  Batches of at most 2^17 envs."""
 
-    WORDS = 16
+    MAX_CHUNKS = 512
+    HEADER = 8                      # stop, status, steps_done, 5 internal words; then act_seq[512], step_seq[512] (nsg_mailbox)
+    WORDS = HEADER + 2 * MAX_CHUNKS
     STATUS = {0: "resident", 1: "finished", 2: "starved", 3: "stopped", 4: "torn"}
 
     def __init__(self, env: "VecNSEnv", actions, wait_budget_us: int = 2000):
@@ -666,14 +668,23 @@ class ResidentStepper:
         """Raise `stop` from another stream: producer and stepper leave after at most one more step."""
         stream = stream or torch.cuda.Stream(self.env.device)
         with torch.cuda.stream(stream):
-            self.mailbox[2:3].fill_(3)
+            self.mailbox[0:1].fill_(3)
         return self
+
+    @property
+    def act_seq(self):
+        """int64[chunks] view: the producer's side of the hand-shake (chunk j's actions of step k in place -> k + 1)."""
+        return self.mailbox[self.HEADER:self.HEADER + self.MAX_CHUNKS][: (self.env.N + 255) // 256]
+
+    @property
+    def step_seq(self):
+        return self.mailbox[self.HEADER + self.MAX_CHUNKS:][: (self.env.N + 255) // 256]
 
     def result(self):
         """(status, steps_done) once the stepper has left (waits for it)."""
         self._stream.synchronize()
-        w = self.mailbox.cpu().tolist()
-        return self.STATUS.get(int(w[3]), str(w[3])), int(w[4])
+        w = self.mailbox[: self.HEADER].cpu().tolist()
+        return self.STATUS.get(int(w[1]), str(w[1])), int(w[2])
 
 
 def step_group(envs, actions):
