@@ -765,6 +765,45 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
 }
 
 // ---- resident stepper (nsg_rollout.hip.h: resident_body) -----------------------------------------------------------------
+// The waits of the resident kernels are budgets of the device's steady counter (wall_clock64()).  Its rate is MEASURED, once per
+// device: a one-lane kernel spins until the counter has advanced by 2^20 ticks between two events (measured rather than taken from
+// hipDeviceAttributeWallClockRate: a first cut that trusted a nominal rate left after 0.17 ms with a 5-ms budget).
+__global__ void wall_clock_spin_kernel(uint64_t ticks, uint64_t* out) {
+  const uint64_t t0 = (uint64_t)wall_clock64();
+  uint64_t t = t0;
+  for (int guard = 0; guard < (1 << 28) && t - t0 < ticks; guard++) {   // (the guard bounds the spin whatever the counter does)
+    __builtin_amdgcn_s_sleep(8);
+    t = (uint64_t)wall_clock64();
+  }
+  if (out) *out = t - t0;
+}
+static int wall_ticks_per_us(int device, double* out) {
+  static std::mutex m;
+  static std::map<int, double> rate;
+  std::lock_guard<std::mutex> lock(m);
+  auto it = rate.find(device);
+  if (it == rate.end()) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0.f;
+    const uint64_t ticks = 1u << 20;
+    HIP_TRY(hipEventCreate(&e0));
+    hipError_t he = hipEventCreate(&e1);
+    if (he == hipSuccess) { hipLaunchKernelGGL(wall_clock_spin_kernel, dim3(1), dim3(1), 0, 0, (uint64_t)1, (uint64_t*)nullptr); he = hipDeviceSynchronize(); }   // warm
+    if (he == hipSuccess) he = hipEventRecord(e0, 0);
+    if (he == hipSuccess) { hipLaunchKernelGGL(wall_clock_spin_kernel, dim3(1), dim3(1), 0, 0, ticks, (uint64_t*)nullptr); he = hipGetLastError(); }
+    if (he == hipSuccess) he = hipEventRecord(e1, 0);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (he != hipSuccess) return fail(NSG_EHIP, "measuring the device's wall-clock rate: %s", hipGetErrorString(he));
+    if (!(ms > 0.01f)) return fail(NSG_EHIP, "the device's wall clock does not advance: the resident stepper cannot bound its waits");
+    it = rate.emplace(device, (double)ticks / ((double)ms * 1000.0)).first;
+  }
+  *out = it->second;
+  return NSG_OK;
+}
+
 int nsg_resident_start(nsg_handle* h, const void* actions_dev, nsg_mailbox* mb_dev, int32_t max_steps, uint32_t wait_budget_us, void* stream) {
   if (!h) return fail(NSG_EINVAL, "handle is NULL");
   if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
@@ -779,11 +818,11 @@ int nsg_resident_start(nsg_handle* h, const void* actions_dev, nsg_mailbox* mb_d
   ra.mb = mb_dev;
   ra.max_steps = max_steps;
   ra.reserved = 0;
-  int khz = 0;   // the device's steady wall clock (wall_clock64() in the kernel)
-  HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device));
-  if (khz <= 0) return fail(NSG_EHIP, "the device reports no wall-clock rate: the resident stepper cannot bound its waits");
-  ra.budget_ticks = (uint64_t)wait_budget_us * (uint64_t)khz / 1000u;
-  ra.grace_ticks = (uint64_t)NSG_RESIDENT_GRACE_US * (uint64_t)khz / 1000u;
+  double per_us = 0.0;   // the device's steady wall clock (wall_clock64() in the kernel)
+  int rc = wall_ticks_per_us(h->device, &per_us);
+  if (rc) return rc;
+  ra.budget_ticks = (uint64_t)((double)wait_budget_us * per_us);
+  ra.grace_ticks = (uint64_t)((double)NSG_RESIDENT_GRACE_US * per_us);
   hipStream_t s = (hipStream_t)stream;
   if (h->host.simple_theta) {
     DISPATCH_ENV(h->host.cfg.env_type, hipLaunchKernelGGL((resident_kernel<E, false>), dim3(grid), dim3(kBlock), lds, s, h->dev, actions_dev, ra));
@@ -805,11 +844,11 @@ int nsg_resident_demo_policy(nsg_handle* h, int32_t watch, int32_t* actions_dev,
   ra.mb = mb_dev;
   ra.max_steps = max_steps;
   ra.reserved = 0;
-  int khz = 0;
-  HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device));
-  if (khz <= 0) return fail(NSG_EHIP, "the device reports no wall-clock rate");
-  ra.budget_ticks = (uint64_t)wait_budget_us * (uint64_t)khz / 1000u;
-  ra.grace_ticks = (uint64_t)NSG_RESIDENT_GRACE_US * (uint64_t)khz / 1000u;
+  double per_us = 0.0;
+  int rc = wall_ticks_per_us(h->device, &per_us);
+  if (rc) return rc;
+  ra.budget_ticks = (uint64_t)((double)wait_budget_us * per_us);
+  ra.grace_ticks = (uint64_t)((double)NSG_RESIDENT_GRACE_US * per_us);
   const int grid = (int)((h->n + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(resident_demo_policy_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, (const float*)h->host.buf.obs, kObsDim[e], watch,
                      actions_dev, h->n, kNActions[e], ra);

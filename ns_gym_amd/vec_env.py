@@ -639,11 +639,14 @@ class ResidentStepper:
         self.mailbox = torch.zeros(self.WORDS, dtype=torch.int64, device=env.device)   # nsg_mailbox
         self._stream = None
 
-    def start(self, max_steps: int, stream=None):
+    def start(self, max_steps: int, stream=None, prefilled: int = 0):
+        """`prefilled`: that many action rows count as published already (an open-loop run out of ONE action row: measurements)."""
         e = self.env
         cur = torch.cuda.current_stream(e.device)
         stream = stream or cur
         self.mailbox.zero_()                      # on the current stream; stepper and producer are ordered behind this point
+        if prefilled:
+            self.act_seq.fill_(int(prefilled))
         self._zeroed = torch.cuda.Event()
         self._zeroed.record(cur)
         stream.wait_event(self._zeroed)
