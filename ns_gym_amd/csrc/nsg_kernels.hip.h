@@ -233,8 +233,29 @@ template <> struct Unroll<0> {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int ENV> __device__ __forceinline__ void store_obs(float* obs, int64_t i, const float* o) {
+// a step output: write-once (non-temporal) - or written through, when another running kernel is about to read it (IoMode::coh)
+template <typename T> __device__ __forceinline__ void stg_o(bool coh, T* base, uint32_t byte_off, T v) {
+  if (coh) {
+    NSG_GLOBAL char* p = (NSG_GLOBAL char*)pin_sgpr((uint64_t)base);
+    __hip_atomic_store((NSG_GLOBAL T*)(p + byte_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    stg_out(base, byte_off, v);
+  }
+}
+template <typename T> __device__ __forceinline__ T ldg_in(bool coh, const T* base, uint32_t byte_off) {
+  if (coh) {
+    const NSG_GLOBAL char* p = (const NSG_GLOBAL char*)pin_sgpr((uint64_t)base);
+    return __hip_atomic_load((const NSG_GLOBAL T*)(p + byte_off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return ldg(base, byte_off);
+}
+template <int ENV> __device__ __forceinline__ void store_obs(float* obs, int64_t i, const float* o, bool coh = false) {
   const uint32_t u = (uint32_t)i;
+  if (coh) {   // resident stepper: element by element through the L2 (IoMode::coh)
+#pragma unroll
+    for (int k = 0; k < EnvTraits<ENV>::OBS; k++) stg_o(true, obs, u * (uint32_t)(4 * EnvTraits<ENV>::OBS) + 4u * (uint32_t)k, o[k]);
+    return;
+  }
   if constexpr (ENV == NSG_ENV_CARTPOLE) {
     stg_out(reinterpret_cast<f32x4*>(obs), u * 16u, f32x4{o[0], o[1], o[2], o[3]});
   } else if constexpr (ENV == NSG_ENV_PENDULUM) {
@@ -281,6 +302,11 @@ struct IoMode {  // wave-uniform
                  // records are in LDS: a reset inside the launch is four sequential draws, not a re-derivation
   bool wt = false;  // single-step launches (nsg_step): persistent rows of the grid envs / Pendulum state leave through
                     // agent-scope stores (stg_wt); fused rollouts keep plain stores (C3 rollout: 12.3 vs 14.6 us per step)
+  bool coh = false; // resident stepper (nsg_resident_start): another kernel that is running NOW reads this step's outputs and wrote
+                    // its actions.  They are accessed coherently one by one - outputs written through the L2 (agent-scope stores),
+                    // actions read past it (agent-scope loads) - so that the hand-over needs no L2-wide writeback / invalidate:
+                    // with 32 workgroups per XCD each issuing its own pair of cache-wide fences a resident step cost 20 us
+                    // (profiles/NOTEBOOK.md, round 4)
 };
 template <typename T> __device__ __forceinline__ void stg_p(bool wt, T* base, uint32_t byte_off, T v) {
   if (wt) stg_wt(base, byte_off, v);
@@ -397,8 +423,8 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   int ai = 0;
   float af = 0.f;
   if (ld_state) {
-    if constexpr (T::FLOAT_ACT) af = ldg((const float*)actions, o4);
-    else ai = ldg((const int32_t*)actions, o4);
+    if constexpr (T::FLOAT_ACT) af = ldg_in(io.coh, (const float*)actions, o4);
+    else ai = ldg_in(io.coh, (const int32_t*)actions, o4);
   }
   constexpr bool kReturnFromT = T::RETURN_PER_STEP != 0.f;  // the return is a function of t: no running row (nsg_envs.hip.h)
   float er = 0.f;
@@ -451,8 +477,8 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
         // rows 0/1 live in registers across fused steps: written when this step stores (always then,
         // because earlier fused steps may have changed them without a store)
         if (p > 1 ? fin != c : (io.store && (fin != c || io.dirty))) stg(b.theta + (int64_t)p * N, o8, fin);
-        stg_out(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
-        stg_out(out.delta_change + (int64_t)p * N, o4, (float)delta);
+        stg_o(io.coh, out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
+        stg_o(io.coh, out.delta_change + (int64_t)p * N, o4, (float)delta);
         if (cfg.flags & NSG_F_VIOLATION_MASK) stg(b.violation + (int64_t)p * N, o1, (uint8_t)(rejected && do_step ? 1 : 0));
       }
       n_fired += fired ? 1u : 0u;
@@ -516,8 +542,8 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
         // rows 0/1 live in registers across fused steps: written when this step stores (always then,
         // because earlier fused steps may have changed them without a store)
         if (p > 1 ? fin != c : (io.store && (fin != c || io.dirty))) stg(b.theta + (int64_t)p * N, o8, fin);
-        stg_out(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
-        stg_out(out.delta_change + (int64_t)p * N, o4, (float)delta);
+        stg_o(io.coh, out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
+        stg_o(io.coh, out.delta_change + (int64_t)p * N, o4, (float)delta);
         if (cfg.flags & NSG_F_VIOLATION_MASK) stg(b.violation + (int64_t)p * N, o1, (uint8_t)(rejected && do_step ? 1 : 0));
       }
       n_fired += fired ? 1u : 0u;
@@ -662,11 +688,11 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     }
     float o[T::OBS];
     env_obs<ENV>(s, o);
-    store_obs<ENV>(out.obs, i, o);
+    store_obs<ENV>(out.obs, i, o, io.coh);
     if (io.store) stg(b.t, o4, tnew);
-    stg_out(out.reward, o4, (float)reward);
-    stg_out(out.terminated, o1, (uint8_t)(term ? 1 : 0));
-    stg_out(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
+    stg_o(io.coh, out.reward, o4, (float)reward);
+    stg_o(io.coh, out.terminated, o1, (uint8_t)(term ? 1 : 0));
+    stg_o(io.coh, out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
     if (io.store && (!reset_from_t || do_reset || io.lds_rng)) stg(b.episode, o4, (int32_t)stw);
     if (track) {  // the episode length is the wrapper time t: only the return needs a running row
       if constexpr (kReturnFromT) {
@@ -779,7 +805,7 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
   const bool do_step = active && !do_reset;
 
   int cell = do_step ? gl.cell : 0;
-  const int a = do_step ? ldg((const int32_t*)actions, o4) : 0;
+  const int a = do_step ? ldg_in(io.coh, (const int32_t*)actions, o4) : 0;
   // one uniform per step from the env stream (categorical_sample / np.random.choice); FrozenLakeEnv
   // and CliffWalkingEnv.reset also draw one (categorical_sample over the one-hot start distribution),
   // Bridge.reset draws nothing (envs/Bridge.py:103-111)
@@ -867,8 +893,8 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       }
     }
     if (active) {
-      stg_out(out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
-      stg_out(out.delta_change + (int64_t)p * N, o4, (float)delta);
+      stg_o(io.coh, out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
+      stg_o(io.coh, out.delta_change + (int64_t)p * N, o4, (float)delta);
     }
     n_fired += fired ? 1u : 0u;
   }
@@ -942,10 +968,10 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
     gl.cell = cell;
     gl.t = tnew;
     gl.st = (done ? NSG_ST_NEEDS_RESET : 0u) | (table_hint << NSG_ST_TABLE_SHIFT);
-    if (out.obs) stg_out((int32_t*)out.obs, o4, cell);  // trajectory slice (rollout); NULL for nsg_step: cell[] is the obs
-    stg_out(out.reward, o4, (float)reward);
-    stg_out(out.terminated, o1, (uint8_t)(term ? 1 : 0));
-    stg_out(out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
+    if (out.obs) stg_o(io.coh, (int32_t*)out.obs, o4, cell);  // trajectory slice (rollout); NULL for nsg_step: cell[] is the obs
+    stg_o(io.coh, out.reward, o4, (float)reward);
+    stg_o(io.coh, out.terminated, o1, (uint8_t)(term ? 1 : 0));
+    stg_o(io.coh, out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
     if (track) {
       float er = return_is_last_reward ? (float)reward : do_reset ? 0.f : gl.er + (float)reward;
       if (done) {

@@ -158,10 +158,7 @@ __device__ __forceinline__ int resident_wait(nsg_mailbox* mb, const uint64_t* se
   uint64_t deadline = t0 + budget_ticks;
   bool draining = false;
   for (;;) {
-    if (mb_peek(seq) >= want) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the row published before `seq` is visible from here on
-      return 1;
-    }
+    if (mb_peek(seq) >= want) return 1;   // (what was published before `seq` is read with coherent loads: no cache invalidate here)
     const uint64_t now = (uint64_t)wall_clock64();
     if (!draining && mb_peek(&mb->stop) != 0u) {
       draining = true;
@@ -228,17 +225,20 @@ __device__ __forceinline__ void resident_body(const nsg_config& cfg, const Segme
     if (!ok) break;
     if constexpr (GRID) {
       // (a grid env's observation IS its cell row, its info["prob"] the prob row: both live in the persistent-store block - every step stores)
-      step_grid<ENV, FULL>(cfg, b, N, tb, zg, actions, out, ir, ir < N, wc, gl, IoMode{k == 0, true, k > 0, false});
+      // wt: the persistent rows (cell = the observation, prob) are written through as well
+      step_grid<ENV, FULL>(cfg, b, N, tb, zg, actions, out, ir, ir < N, wc, gl, IoMode{k == 0, true, k > 0, false, true, true});
     } else {
       // outputs every step; the persistent rows stay in registers / LDS until the workgroup leaves (flush below)
-      step_chunk<ENV, FULL>(cfg, b, N, tb, zg, actions, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, false, k > 0, true});
+      step_chunk<ENV, FULL>(cfg, b, N, tb, zg, actions, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, false, k > 0, true, false, true});
     }
     parity ^= 1;
     taken++;
-    // this chunk's outputs are out: release them and say so
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // This chunk's outputs were written THROUGH the L2 one by one (IoMode::coh): once every lane's stores have been acknowledged
+    // (vmcnt(0)) they are where the consumer's coherent loads look, and the sequence word - written through as well, after the
+    // barrier - cannot overtake them.  No cache-wide writeback.
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (threadIdx.x == 0) mb_publish(&ra.mb->step_seq[c], (uint64_t)k + 1u);
+    if (threadIdx.x == 0) __hip_atomic_store(&ra.mb->step_seq[c], (uint64_t)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if constexpr (!GRID) {   // leaving: the persistent rows go back (what a step with io.store does, step_chunk)
     if (taken > 0 && ir < N) {
@@ -308,14 +308,15 @@ __global__ __launch_bounds__(kBlock) void resident_demo_policy_kernel(const floa
     const int ok = go_on;
     __syncthreads();
     if (!ok) return;
-    if (i < N) {
-      const float x = __builtin_nontemporal_load(obs + i * obs_dim + watch);
-      actions[i] = (int32_t)(((x > 0.f ? 1 : 0) + k) % n_actions);
+    if (i < N) {   // coherent accesses on both sides (IoMode::coh): the observation past the L2, the action through it
+      const float x = __hip_atomic_load(obs + i * obs_dim + watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(actions + i, (int32_t)(((x > 0.f ? 1 : 0) + k) % n_actions), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     // a producer never publishes once it has seen `stop` (resident_wait's grace period relies on it)
-    if (threadIdx.x == 0 && mb_peek(&ra.mb->stop) == 0u) mb_publish(&ra.mb->act_seq[blockIdx.x], (uint64_t)k + 1u);
+    if (threadIdx.x == 0 && mb_peek(&ra.mb->stop) == 0u)
+      __hip_atomic_store(&ra.mb->act_seq[blockIdx.x], (uint64_t)k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
