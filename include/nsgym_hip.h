@@ -538,6 +538,8 @@ int nsg_spec_build(const nsg_config* cfg, const char* arch, void** code_out, siz
 /* the same for the unit nsg_step_group uses when every member is specialised: one kernel (nsg_spec_group) for the ordered tuple
  * of the members' configs */
 int nsg_spec_build_group(const nsg_config* const* cfgs, int32_t n, const char* arch, void** code_out, size_t* size_out);
+/* ... and for the unit nsg_resident_start builds, on first use, for a specialised handle (one kernel: nsg_spec_resident) */
+int nsg_spec_build_resident(const nsg_config* cfg, const char* arch, void** code_out, size_t* size_out);
 void nsg_spec_free(void* code);
 
 int nsg_destroy(nsg_handle* h);

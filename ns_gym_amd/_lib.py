@@ -16,7 +16,7 @@ EXPORTS = [
     "nsg_layout_query", "nsg_create", "nsg_bind", "nsg_reset", "nsg_reset_seeded", "nsg_step", "nsg_rollout", "nsg_step_group", "nsg_step_group_kind", "nsg_rollout_group",
     "nsg_fork", "nsg_seed_streams", "nsg_resident_start", "nsg_resident_demo_policy",
     "nsg_table_prob_dirty", "nsg_compact_done", "nsg_theta_trace", "nsg_theta_trace_stateful", "nsg_rng_fill", "nsg_time_steps", "nsg_calib_copy_f64", "nsg_read_back", "nsg_destroy",
-    "nsg_specialize", "nsg_is_specialized", "nsg_spec_origin", "nsg_spec_prebuild", "nsg_spec_prebuild_group", "nsg_spec_build", "nsg_spec_build_group",
+    "nsg_specialize", "nsg_is_specialized", "nsg_spec_origin", "nsg_spec_prebuild", "nsg_spec_prebuild_group", "nsg_spec_build", "nsg_spec_build_group", "nsg_spec_build_resident",
     "nsg_spec_free",
 ]
 
@@ -88,6 +88,7 @@ def load():
     lib.nsg_spec_free.restype = None
     lib.nsg_spec_free.argtypes = [C.c_void_p]
     lib.nsg_spec_build.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.nsg_spec_build_resident.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.nsg_spec_build_group.argtypes = [C.POINTER(C.c_void_p), i32, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.nsg_specialize.argtypes = [C.c_void_p]
     lib.nsg_is_specialized.argtypes = [C.c_void_p]

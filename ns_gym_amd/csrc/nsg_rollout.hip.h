@@ -157,10 +157,10 @@ __device__ __forceinline__ int resident_wait(nsg_mailbox* mb, const uint64_t* se
   const uint64_t t0 = (uint64_t)wall_clock64();
   uint64_t deadline = t0 + budget_ticks;
   bool draining = false;
-  for (;;) {
+  for (unsigned spin = 0;; spin++) {
     if (mb_peek(seq) >= want) return 1;   // (what was published before `seq` is read with coherent loads: no cache invalidate here)
     const uint64_t now = (uint64_t)wall_clock64();
-    if (!draining && mb_peek(&mb->stop) != 0u) {
+    if (!draining && (spin & 7u) == 7u && mb_peek(&mb->stop) != 0u) {   // (every 8th poll: the hot path is one coherent load per poll)
       draining = true;
       deadline = now + grace_ticks;
     }
@@ -171,7 +171,7 @@ __device__ __forceinline__ int resident_wait(nsg_mailbox* mb, const uint64_t* se
       draining = true;
       deadline = now + grace_ticks;
     }
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(1);
   }
 }
 

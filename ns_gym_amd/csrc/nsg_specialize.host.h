@@ -139,6 +139,21 @@ inline std::string spec_source(const nsg_config& cfg, bool full, bool resets_in_
   return s;
 }
 
+// The resident stepper (nsg_resident_start) of a specialised handle: its own small unit, compiled the first time a resident loop
+// is started on such a handle (the step / rollout units of everybody else stay as they are).
+inline std::string resident_source(const nsg_config& cfg, bool full) {
+  std::string s = spec_source(cfg, full, false, false, false);
+  const size_t cut = s.find("extern \"C\" __global__");
+  s.resize(cut);
+  char buf[40];
+  snprintf(buf, sizeof(buf), "%d, %s", (int)cfg.env_type, full ? "true" : "false");
+  s += "extern \"C\" __global__ __launch_bounds__(NSG_BLOCK) void nsg_spec_resident(const nsg::Segment* __restrict__ seg,\n"
+       "                                                                    const void* __restrict__ actions, nsg::ResidentArgs ra) {\n"
+       "  nsg::resident_body<" + std::string(buf) + ">(NSG_SPEC_CFG, *seg, actions, ra);\n"
+       "}\n";
+  return s;
+}
+
 inline void emit_cfg_words(std::string& s, const nsg_config& cfg, int index) {
   char buf[48];
   snprintf(buf, sizeof(buf), "__device__ const uint64_t kCfgWords%d[] = {\n", index);
@@ -263,6 +278,14 @@ inline std::vector<char> spec_compile(const nsg_config& cfg, bool full, const ch
 }
 // The heterogeneous launch's unit is held to the same rule: a group kernel that spills is refused (the generic group kernel
 // stays in force, nsg_step_group).
+inline std::vector<char> resident_compile(const nsg_config& cfg, bool full, const char* arch, std::string& err) {
+  std::vector<char> code = compile_source(resident_source(cfg, full), arch, err);
+  if (!code.empty() && unit_uses_scratch(code) && !allow_spill()) {
+    err = "the specialised resident kernel spills vector registers (scratch memory); such builds are not used (see spec_compile)";
+    code.clear();
+  }
+  return code;
+}
 // The two kernels of the unit are judged separately: when the unit with both spills, the single-step kernel is built on its own -
 // if IT is clean the unit ships without nsg_spec_group_rollout (fused group rollouts of this member list run the generic kernel),
 // so a spilling rollout never costs nsg_step_group its specialised kernel.
@@ -358,6 +381,7 @@ struct Module {
   hipModule_t mod = nullptr;
   hipFunction_t step = nullptr, rollout = nullptr;  // single-config unit
   hipFunction_t group = nullptr, group_rollout = nullptr;   // heterogeneous-launch unit (single step, fused rollout)
+  hipFunction_t resident = nullptr;                         // resident-stepper unit
   uint64_t h0 = 0;                                    // config key (group keys are built from their members')
   int step_waves = 0;                                 // wavefronts per SIMD the step kernel's registers allow (0 = unknown)
   int origin = 0;                                     // NSG_SPEC_ORIGIN_*: where this code object came from

@@ -134,6 +134,7 @@ struct nsg_handle {
   bool bound;
   int device;
   const nsg_spec::Module* spec;  // config-specialised step / rollout kernels (nsg_specialize), or NULL
+  const nsg_spec::Module* spec_resident = nullptr;   // ... and its resident stepper (built on the first nsg_resident_start)
   unsigned launches = 0;
   // What nsg_step_group remembers about a member list is keyed on these two: `id` is unique per nsg_create for the life of the
   // process (a new handle at a recycled address is a different member), `generation` counts the launch-relevant changes of
@@ -248,8 +249,10 @@ bool read_file(const std::string& path, std::vector<char>& code) {
 
 // Look a code object up in the process cache, then among the prebuilt units, then in the disk cache (spec_cache_dir), else
 // compile it; load it.
+enum { kUnitSingle = 0, kUnitGroup = 1, kUnitResident = 2 };
 template <typename Compile>
-int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, const nsg_spec::Module** out) {
+int get_spec_module(int device, uint64_t h0, int unit_kind, Compile&& compile, const nsg_spec::Module** out) {
+  const bool group = unit_kind == kUnitGroup;
   const uint64_t h1 = spec_source_hash();
   const nsg_spec::Key key{device, h0, h1};
   std::lock_guard<std::mutex> lock(nsg_spec::cache_mutex());
@@ -331,7 +334,9 @@ int get_spec_module(int device, uint64_t h0, bool group, Compile&& compile, cons
     }
     if (le != hipSuccess) return fail(NSG_EHIP, "hipModuleLoadData: %s", hipGetErrorString(le));
     m.origin = origin;
-    if (group) {
+    if (unit_kind == kUnitResident) {
+      HIP_TRY(hipModuleGetFunction(&m.resident, m.mod, "nsg_spec_resident"));
+    } else if (group) {
       HIP_TRY(hipModuleGetFunction(&m.group, m.mod, "nsg_spec_group"));
       // a unit whose fused rollout would have spilled ships the single-step kernel alone (group_compile): rollouts of this member
       // list then run the generic kernel
@@ -824,6 +829,23 @@ int nsg_resident_start(nsg_handle* h, const void* actions_dev, nsg_mailbox* mb_d
   ra.budget_ticks = (uint64_t)((double)wait_budget_us * per_us);
   ra.grace_ticks = (uint64_t)((double)NSG_RESIDENT_GRACE_US * per_us);
   hipStream_t s = (hipStream_t)stream;
+  if (h->spec) {   // a specialised handle: the resident kernel compiled for its configuration (its own unit, built on first use)
+    if (!h->spec_resident) {
+      hipDeviceProp_t prop;
+      HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+      const bool full = !h->host.simple_theta;
+      uint64_t h0 = h->spec->h0;
+      h0 = nsg_spec::fnv1a("resident", 8, h0);
+      const int grc = get_spec_module(h->device, h0, kUnitResident,
+                                      [&](std::string& err) { return nsg_spec::resident_compile(h->host.cfg, full, prop.gcnArchName, err); }, &h->spec_resident);
+      if (grc) h->spec_resident = nullptr;   // the generic resident kernel stays in force
+    }
+    if (h->spec_resident) {
+      void* args[] = {(void*)&h->dev, (void*)&actions_dev, (void*)&ra};
+      HIP_TRY(hipModuleLaunchKernel(h->spec_resident->resident, grid, 1, 1, kBlock, 1, 1, (unsigned)lds, s, args, nullptr));
+      return NSG_OK;
+    }
+  }
   if (h->host.simple_theta) {
     DISPATCH_ENV(h->host.cfg.env_type, hipLaunchKernelGGL((resident_kernel<E, false>), dim3(grid), dim3(kBlock), lds, s, h->dev, actions_dev, ra));
   } else {
@@ -982,7 +1004,7 @@ static int make_group_plan_locked(GroupPlan& plan, nsg_handle* const* hs, int n_
     const uint64_t h0 = group_key(keys, n_handles);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, hs[0]->device));
-    const int rc = get_spec_module(hs[0]->device, h0, true,
+    const int rc = get_spec_module(hs[0]->device, h0, kUnitGroup,
                                    [&](std::string& err) { return nsg_spec::group_compile(cfgs, full, n_handles, prop.gcnArchName, err); },
                                    &plan.group_spec);
     if (rc) plan.group_spec = nullptr;  // the generic group kernel stays in force
@@ -1294,6 +1316,23 @@ int nsg_spec_build(const nsg_config* cfg, const char* arch, void** code_out, siz
   return NSG_OK;
 }
 
+int nsg_spec_build_resident(const nsg_config* cfg, const char* arch, void** code_out, size_t* size_out) {
+  if (!code_out || !size_out) return fail(NSG_EINVAL, "NULL output argument");
+  *code_out = nullptr;
+  *size_out = 0;
+  int rc = validate(cfg, (size_t)kMaxTableBytes);
+  if (rc) return rc;
+  std::string err;
+  std::vector<char> code = nsg_spec::resident_compile(*cfg, !cfg_simple_theta(*cfg), arch && *arch ? arch : "gfx950", err);
+  if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
+  void* p = malloc(code.size());
+  if (!p) return fail(NSG_ENOMEM, "out of host memory");
+  memcpy(p, code.data(), code.size());
+  *code_out = p;
+  *size_out = code.size();
+  return NSG_OK;
+}
+
 int nsg_spec_build_group(const nsg_config* const* cfgs, int32_t n, const char* arch, void** code_out, size_t* size_out) {
   if (!code_out || !size_out || !cfgs || n <= 0 || n > NSG_MAX_SEGMENTS) return fail(NSG_EINVAL, "bad arguments");
   *code_out = nullptr;
@@ -1326,7 +1365,7 @@ int nsg_specialize(nsg_handle* h) {
   HIP_TRY(hipGetDeviceProperties(&prop, h->device));
   const SpecPolicy pol = spec_policy(h->host.cfg, h->n);
   const uint64_t h0 = spec_key(h->host.cfg, pol, prop.gcnArchName);
-  const int rc = get_spec_module(h->device, h0, false,
+  const int rc = get_spec_module(h->device, h0, kUnitSingle,
                                  [&](std::string& err) { return nsg_spec::spec_compile(h->host.cfg, pol.full, prop.gcnArchName, err, pol.inlane, pol.stream_state); }, &h->spec);
   h->generation++;   // a group that contains this handle re-plans (its specialised unit depends on every member's)
   return rc;

@@ -44,13 +44,10 @@ for spec in (False, True):
         ref.step(a)
     torch.cuda.synchronize()
     res[f"{tag}:nsg_step_alone_us"] = (time.perf_counter() - t0) / K * 1e6
-    if spec:
-        ref.close()
-        continue
     ref.reset(seed=3)
     launch_loop(ref, a, K)
     torch.cuda.synchronize()
-    env = W.build(work, n, specialize=False, seed=3, track_returns=False)
+    env = W.build(work, n, specialize=spec, seed=3, track_returns=False)
     loop = ResidentStepper(env, torch.zeros(n, dtype=torch.int32, device="cuda"), wait_budget_us=20000)
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
     for rep in range(2):     # the first run pays the kernels' first launches
@@ -63,8 +60,8 @@ for spec in (False, True):
         e1.record(sa)
         status, steps = loop.result()
         torch.cuda.synchronize()
-        res[f"resident:closed_loop_run{rep}"] = {"status": status, "steps_done": steps, "us_per_step": e0.elapsed_time(e1) * 1e3 / max(steps, 1)}
-    res["resident:rows_equal_to_the_launch_loop"] = {r: bool(torch.equal(env.buf[r], ref.buf[r])) for r in ROWS if env.buf[r] is not None}
+        res[f"{tag}:resident:closed_loop_run{rep}"] = {"status": status, "steps_done": steps, "us_per_step": e0.elapsed_time(e1) * 1e3 / max(steps, 1)}
+    res[f"{tag}:resident:rows_equal_to_the_launch_loop"] = all(bool(torch.equal(env.buf[r], ref.buf[r])) for r in ROWS if env.buf[r] is not None)
     # open loop: every action row "published" in advance (the same row each step): no hand-over wait at all
     for rep in range(2):
         env.reset(seed=3)
@@ -74,13 +71,13 @@ for spec in (False, True):
         loop.start(K, stream=sa, prefilled=K)
         e1.record(sa)
         status, steps = loop.result()
-        res[f"resident:open_loop_run{rep}"] = {"status": status, "steps_done": steps, "us_per_step": e0.elapsed_time(e1) * 1e3 / max(steps, 1)}
+        res[f"{tag}:resident:open_loop_run{rep}"] = {"status": status, "steps_done": steps, "us_per_step": e0.elapsed_time(e1) * 1e3 / max(steps, 1)}
     # starvation: nobody publishes - the kernel must leave inside its budget (2 ms) + grace (0.2 ms)
     loop2 = ResidentStepper(env, torch.zeros(n, dtype=torch.int32, device="cuda"), wait_budget_us=2000)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loop2.start(50, stream=sa)
     status, steps = loop2.result()
-    res["resident:starved"] = {"status": status, "steps_done": steps, "host_ms_until_it_left": (time.perf_counter() - t0) * 1e3}
+    res[f"{tag}:resident:starved"] = {"status": status, "steps_done": steps, "host_ms_until_it_left": (time.perf_counter() - t0) * 1e3}
     env.close(); ref.close()
 print(json.dumps(res, indent=1))
