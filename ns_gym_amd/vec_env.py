@@ -620,13 +620,18 @@ class ResidentStepper:
     step of `env` whenever the producer of the actions publishes the next row through the mailbox - no launch per step.
 
         loop = ResidentStepper(env, actions)            # actions: the int32 / float32 [N] device tensor the producer rewrites
-        loop.start(max_steps, stream=side)              # zeroes the mailbox, launches the stepper on `side`
+        loop.start(max_steps)                           # zeroes the mailbox, launches the stepper on the loop's own HIGH-PRIORITY stream
         ... the producer: for k in 0 .. : wait for loop.step_seq >= k, write `actions`, publish act_seq = k + 1 ...
         status, steps = loop.result()                   # waits for the kernel to leave: "finished" / "starved" / "stopped" / "torn"
 
     Every wait on the device is bounded (`wait_budget_us`, then a 200-us grace period): a producer that goes silent costs that long,
-    never a hung process.  Every step stores every row, so afterwards `env` is exactly where `steps` calls of `env.step` would have
-    left it and ordinary `step()` / `rollout()` calls carry on.  Batches of at most 2^17 envs."""
+    never a hung process.  Leaving, the kernel writes every row back, so afterwards `env` is exactly where `steps` calls of `env.step`
+    would have left it and ordinary `step()` / `rollout()` calls carry on.  Batches of at most 2^17 envs.
+
+    Stepper and producer must RUN AT THE SAME TIME.  Two ordinary streams may share one hardware queue (the runtime multiplexes
+    streams onto a few), in which case the second kernel would start only after the first has left - starved, safely, but useless.
+    Streams of different priority never share a queue: the loop owns a high-priority stream for the stepper; give the producer an
+    ordinary one."""
 
     MAX_CHUNKS = 512
     HEADER = 8                      # stop, status, steps_done, 5 internal words; then act_seq[512], step_seq[512] (nsg_mailbox)
@@ -637,13 +642,14 @@ class ResidentStepper:
         self.env, self.budget = env, int(wait_budget_us)
         self.actions = env._as_actions(actions)
         self.mailbox = torch.zeros(self.WORDS, dtype=torch.int64, device=env.device)   # nsg_mailbox
+        self.stream = torch.cuda.Stream(env.device, priority=-1)                       # the stepper's own (high-priority) stream
         self._stream = None
 
     def start(self, max_steps: int, stream=None, prefilled: int = 0):
         """`prefilled`: that many action rows count as published already (an open-loop run out of ONE action row: measurements)."""
         e = self.env
         cur = torch.cuda.current_stream(e.device)
-        stream = stream or cur
+        stream = stream or self.stream
         self.mailbox.zero_()                      # on the current stream; stepper and producer are ordered behind this point
         if prefilled:
             self.act_seq.fill_(int(prefilled))

@@ -49,7 +49,7 @@ for spec in (False, True):
     torch.cuda.synchronize()
     env = W.build(work, n, specialize=spec, seed=3, track_returns=False)
     loop = ResidentStepper(env, torch.zeros(n, dtype=torch.int32, device="cuda"), wait_budget_us=20000)
-    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    sa, sb = loop.stream, torch.cuda.Stream()     # the stepper on the loop's high-priority stream, the producer on an ordinary one
     for rep in range(2):     # the first run pays the kernels' first launches
         env.reset(seed=3)
         torch.cuda.synchronize()
