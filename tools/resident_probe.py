@@ -38,6 +38,23 @@ for spec in (False, True):
     launch_loop(ref, a, K)
     torch.cuda.synchronize()
     res[f"{tag}:policy(4 torch kernels)+nsg_step_us"] = (time.perf_counter() - t0) / K * 1e6
+    # the same loop as a HIP graph of 64 iterations (5 kernels each): no host in the loop
+    ref.reset(seed=3)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        launch_loop(ref, a, 2)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        launch_loop(ref, a, 64)
+    g.replay(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(max(K // 64, 1)):
+        g.replay()
+    torch.cuda.synchronize()
+    res[f"{tag}:policy(4 torch kernels)+nsg_step_as_a_graph_us"] = (time.perf_counter() - t0) / (max(K // 64, 1) * 64) * 1e6
     # the step alone, back to back (no policy): the floor of any launch-per-step loop
     t0 = time.perf_counter()
     for k in range(K):
