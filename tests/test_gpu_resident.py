@@ -32,14 +32,14 @@ def _same(a, b, what):
 
 @pytest.mark.parametrize("name,n,specialize", [("c2", 1 << 16, True), ("c2", 5000, False), ("c1", 30000, True), ("acro", 4096, False)])
 def test_closed_loop_is_bit_identical_to_step_calls(name, n, specialize):
-    K = 700 if name != "acro" else 120
+    K = 700 if name != "acro" else 520      # (Acrobot: past its TimeLimit of 500, so every env is reset inside the loop)
     ref = W.build(name, n, specialize=specialize, seed=11, track_returns=False)
     env = W.build(name, n, specialize=specialize, seed=11, track_returns=False)
     a = torch.zeros(n, dtype=torch.int32, device="cuda")
     for k in range(K):
         _policy(ref, k, a)
         ref.step(a)
-    assert ref.counters()["episodes"] > n and ref.counters()["updates_applied"] > 0        # resets and fires happened inside the loop
+    assert ref.counters()["episodes"] >= n and ref.counters()["updates_applied"] > 0       # resets and fires happened inside the loop
     loop = ResidentStepper(env, torch.zeros(n, dtype=torch.int32, device="cuda"), wait_budget_us=50_000)
     loop.start(K)
     loop.demo_policy(K, stream=torch.cuda.Stream())
