@@ -416,6 +416,10 @@ typedef struct nsg_mailbox {
 #define NSG_MB_TORN 4u
 int nsg_resident_start(nsg_handle* h, const void* actions_dev, nsg_mailbox* mb_dev, int32_t max_steps, uint32_t wait_budget_us,
                        void* stream);
+/* The producer's publish for callers whose policy is ordinary kernels (or host copies) enqueued per step: call it on THEIR stream
+ * right behind whatever wrote actions_dev for step `step` - it sets act_seq[j] = step + 1 for every chunk of the batch (coherently;
+ * not at all once stop has been raised).  The consumer side of such a caller reads mb->step_seq[] with ordinary kernels. */
+int nsg_resident_publish(nsg_handle* h, nsg_mailbox* mb_dev, int32_t step, void* stream);
 /* A stand-in policy for measurements and tests (discrete-action classic-control envs): a resident kernel on the OTHER side of the
  * mailbox whose workgroup j, for each of max_steps steps, waits (bounded, same rules) for step_seq[j], writes
  * action[i] = ((obs[i][watch] > 0) + k) mod n_actions for its chunk and publishes act_seq[j].  Launch it on a stream of its own. */

@@ -14,7 +14,7 @@ _lib = None
 EXPORTS = [
     "nsg_abi_version", "nsg_last_error", "nsg_sizeof_config", "nsg_sizeof_buffers", "nsg_sizeof_layout", "nsg_pcg64_jump_table",
     "nsg_layout_query", "nsg_create", "nsg_bind", "nsg_reset", "nsg_reset_seeded", "nsg_step", "nsg_rollout", "nsg_step_group", "nsg_step_group_kind", "nsg_rollout_group",
-    "nsg_fork", "nsg_seed_streams", "nsg_resident_start", "nsg_resident_demo_policy",
+    "nsg_fork", "nsg_seed_streams", "nsg_resident_start", "nsg_resident_publish", "nsg_resident_demo_policy",
     "nsg_table_prob_dirty", "nsg_compact_done", "nsg_theta_trace", "nsg_theta_trace_stateful", "nsg_rng_fill", "nsg_time_steps", "nsg_calib_copy_f64", "nsg_read_back", "nsg_destroy",
     "nsg_specialize", "nsg_is_specialized", "nsg_spec_origin", "nsg_spec_prebuild", "nsg_spec_prebuild_group", "nsg_spec_build", "nsg_spec_build_group", "nsg_spec_build_resident",
     "nsg_spec_free",
@@ -73,6 +73,7 @@ def load():
     lib.nsg_fork.argtypes = [vp, vp, C.c_uint64, i32, vp]
     lib.nsg_resident_start.argtypes = [vp, vp, vp, i32, C.c_uint32, vp]
     lib.nsg_resident_demo_policy.argtypes = [vp, i32, vp, vp, i32, C.c_uint32, vp]
+    lib.nsg_resident_publish.argtypes = [vp, vp, i32, vp]
     lib.nsg_seed_streams.argtypes = [vp, vp, i32, vp]
     lib.nsg_compact_done.argtypes = [vp, vp, vp, vp]
     lib.nsg_table_prob_dirty.argtypes = [vp, vp]

@@ -320,6 +320,13 @@ __global__ __launch_bounds__(kBlock) void resident_demo_policy_kernel(const floa
   }
 }
 
+// The producer side for callers whose policy is ORDINARY kernels launched per step (or the host): enqueued behind them on their
+// stream, it publishes "the action rows of step k are in place" for every chunk - unless stop has been raised.
+__global__ void resident_publish_kernel(nsg_mailbox* mb, int n_chunks, uint64_t seq) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_chunks && mb_peek(&mb->stop) == 0u) __hip_atomic_store(&mb->act_seq[j], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <bool FULL>
 __global__ __launch_bounds__(kBlock) void rollout_group_kernel(const Segment* __restrict__ segs, int nseg, ActionPtrs acts, int k_steps,
                                                                RolloutOuts outs) {

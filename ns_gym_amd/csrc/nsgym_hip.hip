@@ -855,6 +855,15 @@ int nsg_resident_start(nsg_handle* h, const void* actions_dev, nsg_mailbox* mb_d
   return NSG_OK;
 }
 
+int nsg_resident_publish(nsg_handle* h, nsg_mailbox* mb_dev, int32_t step, void* stream) {
+  if (!h || !mb_dev || step < 0) return fail(NSG_EINVAL, "bad arguments");
+  const int chunks = (int)((h->n + kBlock - 1) / kBlock);
+  if (chunks > NSG_RESIDENT_MAX_CHUNKS) return fail(NSG_EINVAL, "at most %d envs", NSG_RESIDENT_MAX_ENVS);
+  hipLaunchKernelGGL(resident_publish_kernel, dim3((chunks + 255) / 256), dim3(256), 0, (hipStream_t)stream, mb_dev, chunks, (uint64_t)step + 1u);
+  HIP_TRY(hipGetLastError());
+  return NSG_OK;
+}
+
 int nsg_resident_demo_policy(nsg_handle* h, int32_t watch, int32_t* actions_dev, nsg_mailbox* mb_dev, int32_t max_steps, uint32_t wait_budget_us,
                              void* stream) {
   if (!h || !h->bound) return fail(NSG_ENOTBOUND, "a bound handle is required");

@@ -673,6 +673,13 @@ class ResidentStepper:
                                                       C.c_void_p(stream.cuda_stream)), "nsg_resident_demo_policy")
         return self
 
+    def publish(self, step: int, stream=None):
+        """Producer side for policies made of ordinary kernels: enqueue on the stream that has just written `actions` for `step`."""
+        e = self.env
+        stream = stream or torch.cuda.current_stream(e.device)
+        _lib.check(e.lib.nsg_resident_publish(e._h, self.mailbox.data_ptr(), int(step), C.c_void_p(stream.cuda_stream)), "nsg_resident_publish")
+        return self
+
     def stop(self, stream=None):
         """Raise `stop` from another stream: producer and stepper leave after at most one more step."""
         stream = stream or torch.cuda.Stream(self.env.device)

@@ -87,10 +87,11 @@ def test_host_driven_rows_then_silence_leaves_exactly_those_steps():
     side.wait_event(loop._zeroed)
     with torch.cuda.stream(side):
         for k, a in enumerate(acts):
+            t0 = time.perf_counter()
             while int(loop.step_seq.min()) < k:      # (host round trips: slow, but this is the protocol)
-                pass
+                assert time.perf_counter() - t0 < 5.0, f"step {k - 1} was never published (step_seq = {loop.step_seq.tolist()[:8]} ...)"
             buf.copy_(a)
-            loop.act_seq.fill_(k + 1)
+            loop.publish(k, stream=side)             # behind the copy on ITS stream: act_seq[j] = k + 1 for every chunk
     status, steps = loop.result()
     assert (status, steps) == ("starved", 3)
     _same(env, ref, "three host-driven resident steps")
