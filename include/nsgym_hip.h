@@ -390,30 +390,33 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
  *
  * The wait is BOUNDED.  A workgroup that has waited `wait_budget_us` for its next row raises mb->stop itself; from the moment a
  * workgroup sees `stop` raised (by a starved workgroup, or by anyone who wants the loop to end) it keeps looking for ONE more
- * row for a grace period (NSG_RESIDENT_GRACE_US) and then leaves.  A producer that honours "do not publish once stop is raised"
- * publishes at most one more step in the shadow of a stop, microseconds after it; every workgroup is still polling then, so all
- * of them take that step or none does.  Leaving, a workgroup writes its persistent rows back; the last one out writes steps_done
- * and status: NSG_MB_FINISHED (max_steps done), NSG_MB_STARVED (the producer went silent), NSG_MB_STOPPED (stop was raised from
- * outside), or NSG_MB_TORN (the chunks disagree on the step count: only possible with a producer that publishes after it has
- * seen stop, or that feeds some chunks and not others; the batch must be reset).  The handle's buffers then describe the batch
- * exactly as after `steps_done` nsg_step calls - bit for bit - and nsg_step / nsg_rollout / another nsg_resident_start carry on
- * from there.  While the kernel is resident nothing else may launch on the handle.  Batches of at most NSG_RESIDENT_MAX_ENVS envs
- * (one workgroup per chunk, all of them resident at once). */
+ * row for a grace period (NSG_RESIDENT_GRACE_US) and then leaves.  Leaving, a workgroup writes its persistent rows back; the last
+ * one out writes status, steps_done (the FEWEST steps any chunk has taken) and steps_max (the most):
+ *   NSG_MB_FINISHED  every chunk has taken max_steps steps - the way a loop of K steps ends.  The handle's buffers describe the batch
+ *                    exactly as after max_steps nsg_step calls, bit for bit.
+ *   NSG_MB_STARVED   the producer went silent / NSG_MB_STOPPED  stop was raised from outside.  Every env is consistent at the step
+ *                    count of ITS chunk (step_seq[j]).  With a producer that publishes for all chunks at once (nsg_resident_publish,
+ *                    which does not publish once stop is raised) the chunks agree - steps_done == steps_max - and the batch is as
+ *                    after that many nsg_step calls: such a producer publishes at most one more step in the shadow of a stop,
+ *                    microseconds after it, when every workgroup is still polling.  Chunks whose producers run independently of
+ *                    each other (the demo policy's workgroups) are wherever each got to.
+ * Afterwards nsg_step / nsg_rollout / another nsg_resident_start carry on from there.  While the kernel is resident nothing else
+ * may launch on the handle.  Batches of at most NSG_RESIDENT_MAX_ENVS envs (one workgroup per chunk, all of them resident at once). */
 #define NSG_RESIDENT_MAX_ENVS (1 << 17)
 #define NSG_RESIDENT_MAX_CHUNKS (NSG_RESIDENT_MAX_ENVS / 256)
 #define NSG_RESIDENT_GRACE_US 200u
 typedef struct nsg_mailbox {
   uint64_t stop;          /* non-zero = leave after the grace period (NSG_MB_STARVED when a starved workgroup raised it)       */
   uint64_t status;        /* 0 while resident / never started; NSG_MB_* once the launch has left                          */
-  uint64_t steps_done;    /* valid with status: every env has taken exactly this many steps since the start               */
-  uint64_t leave, taken_max, taken_min_inv, reserved[2];   /* internal */
+  uint64_t steps_done;    /* valid with status: the fewest steps a chunk has taken since the start ...                      */
+  uint64_t steps_max;     /* ... and the most (equal for NSG_MB_FINISHED and for producers that publish for all chunks at once) */
+  uint64_t leave, taken_max, taken_min_inv, reserved[1];   /* internal */
   uint64_t act_seq[NSG_RESIDENT_MAX_CHUNKS];    /* producer -> stepper, per chunk: k + 1 once chunk j's actions of step k are in place */
   uint64_t step_seq[NSG_RESIDENT_MAX_CHUNKS];   /* stepper -> consumer, per chunk: k + 1 once chunk j's outputs of step k are in the rows */
 } nsg_mailbox;
 #define NSG_MB_FINISHED 1u
 #define NSG_MB_STARVED 2u
 #define NSG_MB_STOPPED 3u
-#define NSG_MB_TORN 4u
 int nsg_resident_start(nsg_handle* h, const void* actions_dev, nsg_mailbox* mb_dev, int32_t max_steps, uint32_t wait_budget_us,
                        void* stream);
 /* The producer's publish for callers whose policy is ordinary kernels (or host copies) enqueued per step: call it on THEIR stream

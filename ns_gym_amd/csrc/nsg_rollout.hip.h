@@ -150,8 +150,10 @@ __device__ __forceinline__ void mb_publish(uint64_t* p, uint64_t v) {
 // One lane's bounded wait for `*seq >= want`.  Returns 1 (go), 0 (leave).  Nobody waits for ever: past `budget_ticks` the waiter
 // raises mb->stop itself (NSG_MB_STARVED); from the moment a waiter sees `stop` raised - by itself, by another workgroup, by the host -
 // it keeps polling for `grace_ticks` more and then leaves.  A producer reads `stop` before it publishes and publishes within a few
-// microseconds of that read; with a grace period far beyond that, a row published in the shadow of a stop is seen by EVERY
-// workgroup (each polls until at least stop-time + grace), so either all of them take that step or none does.
+// microseconds of that read; with a grace period far beyond that, a row that a producer publishes for ALL chunks in the shadow of a
+// stop (nsg_resident_publish) is seen by every workgroup (each polls until at least stop-time + grace): all of them take that step
+// or none does.  (Chunks whose producers run independently of each other - the demo policy's workgroups - are wherever each of
+// them got to when the stop reached it: mb->steps_done / steps_max, step_seq[j].)
 __device__ __forceinline__ int resident_wait(nsg_mailbox* mb, const uint64_t* seq, uint64_t want, uint64_t budget_ticks, uint64_t grace_ticks,
                                              uint64_t starved_code) {
   const uint64_t t0 = (uint64_t)wall_clock64();
@@ -276,8 +278,8 @@ __device__ __forceinline__ void resident_body(const nsg_config& cfg, const Segme
       const uint64_t mx = mb_peek(&ra.mb->taken_max), mn = 0xffffffffULL - mb_peek(&ra.mb->taken_min_inv);
       const uint64_t stop = mb_peek(&ra.mb->stop);
       mb_publish(&ra.mb->steps_done, mn);
-      mb_publish(&ra.mb->status, mn != mx ? (uint64_t)NSG_MB_TORN : mn == (uint64_t)ra.max_steps ? (uint64_t)NSG_MB_FINISHED
-                                                                  : stop == NSG_MB_STARVED ? (uint64_t)NSG_MB_STARVED : (uint64_t)NSG_MB_STOPPED);
+      mb_publish(&ra.mb->steps_max, mx);
+      mb_publish(&ra.mb->status, mn == (uint64_t)ra.max_steps ? (uint64_t)NSG_MB_FINISHED : stop == NSG_MB_STARVED ? (uint64_t)NSG_MB_STARVED : (uint64_t)NSG_MB_STOPPED);
     }
   }
 }

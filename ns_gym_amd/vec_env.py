@@ -622,7 +622,7 @@ class ResidentStepper:
         loop = ResidentStepper(env, actions)            # actions: the int32 / float32 [N] device tensor the producer rewrites
         loop.start(max_steps)                           # zeroes the mailbox, launches the stepper on the loop's own HIGH-PRIORITY stream
         ... the producer: for k in 0 .. : wait for loop.step_seq >= k, write `actions`, publish act_seq = k + 1 ...
-        status, steps = loop.result()                   # waits for the kernel to leave: "finished" / "starved" / "stopped" / "torn"
+        status, steps = loop.result()                   # waits for the kernel to leave: "finished" / "starved" / "stopped"
 
     Every wait on the device is bounded (`wait_budget_us`, then a 200-us grace period): a producer that goes silent costs that long,
     never a hung process.  Leaving, the kernel writes every row back, so afterwards `env` is exactly where `steps` calls of `env.step`
@@ -634,9 +634,9 @@ class ResidentStepper:
     ordinary one."""
 
     MAX_CHUNKS = 512
-    HEADER = 8                      # stop, status, steps_done, 5 internal words; then act_seq[512], step_seq[512] (nsg_mailbox)
+    HEADER = 8                      # stop, status, steps_done, steps_max, 4 internal words; then act_seq[512], step_seq[512] (nsg_mailbox)
     WORDS = HEADER + 2 * MAX_CHUNKS
-    STATUS = {0: "resident", 1: "finished", 2: "starved", 3: "stopped", 4: "torn"}
+    STATUS = {0: "resident", 1: "finished", 2: "starved", 3: "stopped"}
 
     def __init__(self, env: "VecNSEnv", actions, wait_budget_us: int = 2000):
         self.env, self.budget = env, int(wait_budget_us)
@@ -697,9 +697,11 @@ class ResidentStepper:
         return self.mailbox[self.HEADER + self.MAX_CHUNKS:][: (self.env.N + 255) // 256]
 
     def result(self):
-        """(status, steps_done) once the stepper has left (waits for it)."""
+        """(status, steps) once the stepper has left (waits for it).  `steps`: what every chunk has taken - for "finished" always, for
+        "stopped" / "starved" when the producer publishes for all chunks at once (`publish`); `self.steps_range` has (fewest, most)."""
         self._stream.synchronize()
         w = self.mailbox[: self.HEADER].cpu().tolist()
+        self.steps_range = (int(w[2]), int(w[3]))
         return self.STATUS.get(int(w[1]), str(w[1])), int(w[2])
 
 

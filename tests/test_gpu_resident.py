@@ -93,28 +93,38 @@ def test_host_driven_rows_then_silence_leaves_exactly_those_steps():
             buf.copy_(a)
             loop.publish(k, stream=side)             # behind the copy on ITS stream: act_seq[j] = k + 1 for every chunk
     status, steps = loop.result()
-    assert (status, steps) == ("starved", 3)
+    assert (status, steps) == ("starved", 3) and loop.steps_range == (3, 3)     # a publish-for-all producer: the chunks agree
     _same(env, ref, "three host-driven resident steps")
     env.close(); ref.close()
 
 
-def test_stop_ends_the_loop_consistently():
-    n, K = 1 << 15, 10_000_000
+def test_stop_ends_the_loop_and_every_chunk_is_where_its_own_count_says():
+    """`stop` raised from outside: producer and stepper leave within the grace period.  The demo policy's workgroups run
+    independently of each other, so the chunks stand at their own step counts (step_seq[j]); every chunk's rows are the
+    reference's after exactly that many steps."""
+    n, K = 1 << 14, 10_000_000
     env = W.build("c2", n, specialize=True, seed=5, track_returns=False)
     loop = ResidentStepper(env, torch.zeros(n, dtype=torch.int32, device="cuda"), wait_budget_us=50_000)
     loop.start(K)
     loop.demo_policy(K, stream=torch.cuda.Stream())
-    time.sleep(0.02)
+    time.sleep(0.01)
     loop.stop()
-    status, steps = loop.result()
-    assert status == "stopped" and 100 < steps < K, (status, steps)
-    assert int(env.t.max()) <= 500 and int(loop.step_seq.min()) == int(loop.step_seq.max()) == steps
-    # the batch is where `steps` ordinary steps would have left it
+    status, lo = loop.result()
+    lo, hi = loop.steps_range
+    counts = loop.step_seq.cpu().numpy()
+    assert status == "stopped" and 100 < lo <= hi < K and counts.min() == lo and counts.max() == hi and hi - lo < 2000, (status, lo, hi)
     ref = W.build("c2", n, specialize=True, seed=5, track_returns=False)
     a = torch.zeros(n, dtype=torch.int32, device="cuda")
-    for k in range(steps):
+    snaps = {}
+    for k in range(hi):
         _policy(ref, k, a); ref.step(a)
-    _same(env, ref, f"stopped after {steps} steps")
+        if k + 1 >= lo:
+            snaps[k + 1] = (ref.state.clone(), ref.t.clone(), ref.theta.clone(), ref.buf["rng_upd"].clone())
+    for j, c in enumerate(counts):
+        sl = slice(256 * j, 256 * (j + 1))
+        obs, t, theta, rng = snaps[int(c)]
+        assert torch.equal(env.state[sl], obs[sl]) and torch.equal(env.t[sl], t[sl]) and torch.equal(env.theta[:, sl], theta[:, sl]), f"chunk {j} at {c} steps"
+        assert torch.equal(env.buf["rng_upd"].view(-1, n, 4)[:, sl], rng.view(-1, n, 4)[:, sl]), f"chunk {j}: update-fn streams"
     env.close(); ref.close()
 
 
