@@ -102,6 +102,10 @@ def baseline_configs_at_own_size(dev, c1_step_us, c1_rollout_rate, n_c1):
                      "rollout_k64_us_per_step": ru, "rollout_k64_env_steps_per_sec": env.N / (ru * 1e-6)}
         if env.N <= 1 << 16:
             rows[tag]["regime"] = "one wavefront per SIMD: bound by launch latency + the step's serial chain, not by memory"
+            try:   # the same batch as a CLOSED loop without a launch per step (nsg_resident_start + the resident demo policy)
+                rows[tag].update(_resident_loop_us(env, a))
+            except Exception as e:
+                rows[tag]["resident_error"] = f"{type(e).__name__}: {e}"[:200]
         env.close()
     pend, acro = W.build("pend", specialize=True, device=dev), W.build("acro", specialize=True, device=dev)
     ap_, aa = W.random_actions(pend), W.random_actions(acro)
@@ -142,6 +146,36 @@ def baseline_configs_at_own_size(dev, c1_step_us, c1_rollout_rate, n_c1):
                   "bound": "the Acrobot member's float64 vector-ALU issue (RK4: 15 sincos + 12 divisions per step), not HBM"}
     pend.close(); acro.close()
     return rows
+
+
+def _resident_loop_us(env, a, K=4000):
+    """us per step of ONE resident launch taking K steps: closed loop (the library's resident demo policy on a second stream reads
+    each step's observation and publishes the next action row, per 256-env chunk) and open loop (rows published in advance)."""
+    import torch
+
+    from ns_gym_amd.vec_env import ResidentStepper
+
+    loop = ResidentStepper(env, a.clone(), wait_budget_us=50_000)
+    pol = torch.cuda.Stream()
+    out = {}
+    for mode in ("closed", "open"):
+        best = 1e9
+        for rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record(loop.stream)
+            loop.start(K, prefilled=K if mode == "open" else 0)
+            if mode == "closed":
+                loop.demo_policy(K, stream=pol)
+            e1.record(loop.stream)
+            status, steps = loop.result()
+            if (status, steps) != ("finished", K):
+                raise RuntimeError(f"resident loop ended {status} after {steps} steps")
+            if rep:
+                best = min(best, e0.elapsed_time(e1) * 1e3 / K)
+        out[f"resident_{mode}_loop_us_per_step"] = best
+    out["resident_closed_loop_env_steps_per_sec"] = env.N / (out["resident_closed_loop_us_per_step"] * 1e-6)
+    return out
 
 
 def job_roofline(value, world, n_per_gpu, kern_ms_rank0, kern_ms_slowest):

@@ -35,15 +35,46 @@ def main():
     ap.add_argument("--no-track", action="store_true")
     ap.add_argument("--spec", action="store_true", help="config-specialised kernels (nsg_specialize)")
     ap.add_argument("--rollout", type=int, default=0, help="K fused steps per launch (nsg_rollout) instead of nsg_step")
+    ap.add_argument("--resident", type=int, default=0, help="K steps through ONE resident launch (nsg_resident_start): closed loop with the library's "
+                                                              "resident demo policy on a second stream, and open loop (action rows published in advance)")
     args = ap.parse_args()
     res = {}
     for name in args.work.split(","):
         n = args.n
-        e = mk(name, n, track=not args.no_track, spec=args.spec)
+        e = mk(name, n, track=not args.no_track and not args.resident, spec=args.spec)
         a = actions(e, n)
         for _ in range(30):
             e.step(a)
         torch.cuda.synchronize()
+        if args.resident:
+            from ns_gym_amd.vec_env import ResidentStepper
+
+            K = args.resident
+            loop = ResidentStepper(e, a.clone(), wait_budget_us=50_000)
+            pol = torch.cuda.Stream()
+            out = {}
+            for mode in ("closed_loop", "open_loop"):
+                best = 1e9
+                for rep in range(4):          # (the first run pays the kernels' first launches)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    e0.record(loop.stream)
+                    loop.start(K, prefilled=K if mode == "open_loop" else 0)
+                    if mode == "closed_loop":
+                        loop.demo_policy(K, stream=pol)
+                    e1.record(loop.stream)
+                    status, steps = loop.result()
+                    assert (status, steps) == ("finished", K), (status, steps)
+                    if rep:
+                        best = min(best, e0.elapsed_time(e1) * 1e3 / K)
+                out[mode + "_us_per_step"] = best
+            out["Gsteps/s_closed_loop"] = n / (out["closed_loop_us_per_step"] * 1e-6) / 1e9
+            out["what"] = (f"one nsg_resident_start launch, {K} steps; closed loop = the resident demo policy (one workgroup per chunk) on the other "
+                           "side of the mailbox, observation -> action -> step; open loop = rows published in advance (no hand-over wait)")
+            res[name] = out
+            print(name, json.dumps(out), flush=True)
+            e.close()
+            continue
         if args.rollout:
             K = args.rollout
             acts = torch.stack([actions(e, n) for _ in range(K)])

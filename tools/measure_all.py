@@ -30,4 +30,6 @@ for spec in (False, True):
     # every BASELINE config at ITS size: C2 is quoted at 65 536 envs (one wavefront per SIMD: the latency regime)
     run(f"own_size_step:{t}", ["--work", "c2", "--n", str(1 << 16)] + s)
     run(f"own_size_rollout64:{t}", ["--work", "c2", "--n", str(1 << 16), "--rollout", "64"] + s)
+    # ... and as a CLOSED loop without a launch per step: the resident stepper with a resident policy kernel on the other side
+    run(f"own_size_resident:{t}", ["--work", "c2", "--n", str(1 << 16), "--resident", "4000"] + s)
 print(json.dumps(rows, indent=1))
