@@ -771,8 +771,8 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
 
 // ---- resident stepper (nsg_rollout.hip.h: resident_body) -----------------------------------------------------------------
 // The waits of the resident kernels are budgets of the device's steady counter (wall_clock64()).  Its rate is MEASURED, once per
-// device: a one-lane kernel spins until the counter has advanced by 2^20 ticks between two events (measured rather than taken from
-// hipDeviceAttributeWallClockRate: a first cut that trusted a nominal rate left after 0.17 ms with a 5-ms budget).
+// device: a one-lane kernel spins until the counter has advanced by 2^20 ticks between two events (10.49 ms on the MI355X: 100 MHz).
+// Measured rather than assumed: a first cut read s_memrealtime and assumed 100 MHz - it left after 0.17 ms of a 5-ms budget.
 __global__ void wall_clock_spin_kernel(uint64_t ticks, uint64_t* out) {
   const uint64_t t0 = (uint64_t)wall_clock64();
   uint64_t t = t0;
