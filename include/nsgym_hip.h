@@ -370,6 +370,67 @@ typedef struct nsg_rollout_out {
 int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const nsg_rollout_out* out,
                 void* stream);
 
+/* ---- fused rollouts that choose their own actions and keep the episode accounts ------------------------------------------------
+ * The reference's step consumers are loops of the shape `action = policy(observation); observation, reward, ... = env.step(action)`
+ * that sum rewards until the episode ends: MCTS._default_policy (benchmark_algorithms/MCTS.py:162-181: uniformly random actions,
+ * tot_reward += reward * gamma ** depth while not terminated and depth < d and not truncated), run_episode
+ * (evaluate/run_experiment.py:108-129: total_reward += reward until done / truncated), the tutorial's run_episode with a tabular
+ * policy (tutorial.ipynb cell 12: action = policy[observation]).  With nsg_rollout such a loop needs the actions of all K steps
+ * up front, so only open loops fuse; nsg_rollout_policy evaluates the policy INSIDE the launch, per env, from the observation the
+ * previous fused step produced, and keeps the accounts in registers: a closed loop of K steps is one launch with no per-step
+ * traffic at all (no action row in, and - when `out` is NULL - nothing out but the accounts).
+ *
+ * Action sources (nsg_policy.kind):
+ *   NSG_POL_TABLE     data = actions[K][N] (int32 / float): exactly nsg_rollout.
+ *   NSG_POL_UNIFORM   counter-based uniform actions: env i, step k of the launch draws from bits = nsg_policy_bits(seed, index0 + i,
+ *                     step0 + k) (below; a pure function - any sharding of the batch and any chunking of the K steps reproduce the
+ *                     same actions).  Discrete: action = ((bits >> 32) * n_actions) >> 32.  Continuous: low + (high - low) *
+ *                     ((float)(bits >> 40) * 2^-24f) in float32, [low, high] the env type's action bounds (Pendulum +-2, MountainCarContinuous +-1).
+ *                     (The reference draws from NumPy's unseeded global generator - np.random.choice, MCTS.py:176 - or from the action
+ *                     space's own unseeded one: a distribution, not a stream that could be reproduced.)
+ *   NSG_POL_BY_STATE  grid envs: action = ((const int32_t*)data)[cell], n_data >= nrow * ncol entries (tutorial cell 12).
+ *   NSG_POL_LINEAR    classic control: data = float W[rows][obs_dim + 1] (bias last), score_j = W[j][obs_dim] + sum_d W[j][d] * obs[d]
+ *                     accumulated in float32 in that order on the float32 observation an agent would see.  Discrete: rows =
+ *                     n_actions, action = first argmax_j.  Continuous: rows = 1, action = clip(score_0, low, high).
+ * actions_out (may be NULL): the actions taken, [K][N] - the A of run_episode's SARNS records.
+ *
+ * Accounts (nsg_episode_acc, may be NULL; every pointer in it may be NULL): per env, in/out across launches,
+ *   alive[i]   1 while the env's episode is running; cleared by the step that returns terminated or truncated
+ *   ret[i]     += reward64 * discount[length[i]] on every step taken while alive - the float64 reward of the base MDP and Python's
+ *              operation order (`tot_reward += reward * gamma ** depth`); discount NULL or length[i] >= n_discount: 1.0.  The caller
+ *              fills discount[j] = gamma ** j with ITS pow, which is the reference's
+ *   length[i]  += 1 on every step taken while alive
+ * A step that performs a pending autoreset instead of a transition takes no action and changes no account. */
+enum { NSG_POL_TABLE = 0, NSG_POL_UNIFORM = 1, NSG_POL_BY_STATE = 2, NSG_POL_LINEAR = 3 };
+typedef struct nsg_policy {
+  int32_t kind;
+  int32_t step0;        /* NSG_POL_UNIFORM: counter of the launch's first step                                   */
+  uint64_t seed;        /* NSG_POL_UNIFORM: key of the action streams                                             */
+  int64_t index0;       /* NSG_POL_UNIFORM: global index of the handle's env 0 (shards of one job, copy batches)  */
+  const void* data;     /* device memory, see above                                                               */
+  int32_t n_data;       /* NSG_POL_BY_STATE: entries; NSG_POL_LINEAR: rows                                        */
+  int32_t reserved0;
+  void* actions_out;    /* [K][N] int32 / float, or NULL                                                          */
+} nsg_policy;
+typedef struct nsg_episode_acc {
+  double* ret;            /* [N] */
+  int32_t* length;        /* [N] */
+  uint8_t* alive;         /* [N]; NULL: every env counts as alive on entry and nothing is carried over              */
+  const double* discount; /* [n_discount] device memory, or NULL                                                     */
+  int32_t n_discount;
+  int32_t reserved0;
+} nsg_episode_acc;
+int nsg_rollout_policy(nsg_handle* h, const nsg_policy* pol, int32_t k_steps, const nsg_rollout_out* out,
+                       const nsg_episode_acc* acc, void* stream);
+/* Which kernel nsg_rollout_policy launches for this handle: 0 the precompiled generic kernel, 1 the handle's specialised unit
+ * (valid after the first such rollout of a specialised handle). */
+int nsg_rollout_policy_kind(const nsg_handle* h);
+/* The bits behind NSG_POL_UNIFORM (host-callable; tests and callers that want the same actions elsewhere). */
+uint64_t nsg_policy_bits(uint64_t seed, uint64_t env_index, uint64_t step);
+/* The specialised unit nsg_rollout_policy builds, on first use, for a specialised handle (one kernel: nsg_spec_rollout_policy);
+ * no GPU needed, see nsg_spec_build. */
+int nsg_spec_build_policy(const nsg_config* cfg, const char* arch, void** code_out, size_t* size_out);
+
 /* ---- resident stepper: closed loops in the launch-bound regime ---------------------------------------------------------------
  * nsg_step costs a dependent launch per step (4-5 us on this stack before the kernel does anything); a batch of <= 2^17 envs is
  * one wavefront per SIMD, whose step itself takes ~2.7 us.  Callers that can hand over K action rows at once use nsg_rollout; a

@@ -123,3 +123,19 @@ class TraceState(C.Structure):
 class RolloutOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("obs", "reward", "terminated", "truncated", "env_change", "delta_change")]
+
+
+# nsg_policy.kind: where a fused rollout takes its actions from (nsg_rollout_policy)
+NSG_POL_TABLE, NSG_POL_UNIFORM, NSG_POL_BY_STATE, NSG_POL_LINEAR = 0, 1, 2, 3
+
+
+class Policy(C.Structure):
+    """nsg_policy"""
+    _fields_ = [("kind", C.c_int32), ("step0", C.c_int32), ("seed", C.c_uint64), ("index0", C.c_int64), ("data", C.c_void_p),
+                ("n_data", C.c_int32), ("reserved0", C.c_int32), ("actions_out", C.c_void_p)]
+
+
+class EpisodeAcc(C.Structure):
+    """nsg_episode_acc"""
+    _fields_ = [("ret", C.c_void_p), ("length", C.c_void_p), ("alive", C.c_void_p), ("discount", C.c_void_p),
+                ("n_discount", C.c_int32), ("reserved0", C.c_int32)]

@@ -17,6 +17,7 @@ EXPORTS = [
     "nsg_fork", "nsg_seed_streams", "nsg_resident_start", "nsg_resident_publish", "nsg_resident_demo_policy",
     "nsg_table_prob_dirty", "nsg_compact_done", "nsg_theta_trace", "nsg_theta_trace_stateful", "nsg_rng_fill", "nsg_time_steps", "nsg_calib_copy_f64", "nsg_read_back", "nsg_destroy",
     "nsg_specialize", "nsg_is_specialized", "nsg_spec_origin", "nsg_spec_prebuild", "nsg_spec_prebuild_group", "nsg_spec_build", "nsg_spec_build_group", "nsg_spec_build_resident",
+    "nsg_rollout_policy", "nsg_rollout_policy_kind", "nsg_spec_build_policy", "nsg_policy_bits",
     "nsg_spec_free",
 ]
 
@@ -87,6 +88,11 @@ def load():
     for f in EXPORTS[6:]:
         getattr(lib, f).restype = C.c_int
     lib.nsg_spec_free.restype = None
+    lib.nsg_rollout_policy.argtypes = [vp, C.POINTER(A.Policy), i32, C.POINTER(A.RolloutOut), C.POINTER(A.EpisodeAcc), vp]
+    lib.nsg_rollout_policy_kind.argtypes = [vp]
+    lib.nsg_spec_build_policy.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.nsg_policy_bits.restype = C.c_uint64
+    lib.nsg_policy_bits.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
     lib.nsg_spec_free.argtypes = [C.c_void_p]
     lib.nsg_spec_build.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.nsg_spec_build_resident.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]

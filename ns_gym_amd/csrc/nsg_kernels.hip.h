@@ -293,6 +293,13 @@ template <int ENV> struct LaneState {
   // planning copies only: TimeLimit origin (t_fork) and CartPole's fork-time total_mass / polemass_length (derived)
   int tf = 0;
   double d0 = 0.0, d1 = 0.0;
+  // fused policy rollouts only (IoMode::act_lane; dead everywhere else): the action this lane takes next, and what its last step
+  // produced - the float32 observation an agent sees, the base MDP's float64 reward, terminated | truncated << 1 | transition taken << 2
+  int ai = 0;
+  float af = 0.f;
+  float o[EnvTraits<ENV>::OBS] = {};
+  double rw = 0.0;
+  unsigned fl = 0;
 };
 struct IoMode {  // wave-uniform
   bool load;   // fetch the persistent rows from memory (else: they are in the LaneState)
@@ -307,6 +314,8 @@ struct IoMode {  // wave-uniform
                     // actions read past it (agent-scope loads) - so that the hand-over needs no L2-wide writeback / invalidate:
                     // with 32 workgroups per XCD each issuing its own pair of cache-wide fences a resident step cost 20 us
                     // (profiles/NOTEBOOK.md, round 4)
+  bool act_lane = false;  // fused policy rollouts (nsg_rollout_policy): the action comes from the lane's own registers (LaneState::ai / af,
+                          // GridLane::ai), and the step leaves its observation, float64 reward and flags there for the next decision
 };
 template <typename T> __device__ __forceinline__ void stg_p(bool wt, T* base, uint32_t byte_off, T v) {
   if (wt) stg_wt(base, byte_off, v);
@@ -423,7 +432,8 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
   int ai = 0;
   float af = 0.f;
   if (ld_state) {
-    if constexpr (T::FLOAT_ACT) af = ldg_in(io.coh, (const float*)actions, o4);
+    if (io.act_lane) { ai = ls.ai; af = ls.af; }
+    else if constexpr (T::FLOAT_ACT) af = ldg_in(io.coh, (const float*)actions, o4);
     else ai = ldg_in(io.coh, (const int32_t*)actions, o4);
   }
   constexpr bool kReturnFromT = T::RETURN_PER_STEP != 0.f;  // the return is a function of t: no running row (nsg_envs.hip.h)
@@ -689,6 +699,12 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     float o[T::OBS];
     env_obs<ENV>(s, o);
     store_obs<ENV>(out.obs, i, o, io.coh);
+    if (io.act_lane) {
+#pragma unroll
+      for (int k = 0; k < T::OBS; k++) ls.o[k] = o[k];
+      ls.rw = reward;
+      ls.fl = (term ? 1u : 0u) | (trunc ? 2u : 0u) | (do_step ? 4u : 0u);
+    }
     if (io.store) stg(b.t, o4, tnew);
     stg_o(io.coh, out.reward, o4, (float)reward);
     stg_o(io.coh, out.terminated, o1, (uint8_t)(term ? 1 : 0));
@@ -752,6 +768,10 @@ template <int ND> struct GridLane {
   float er = 0.f;
   Pcg g = {0, 0, 0, 0};
   double tp[ND] = {};
+  // fused policy rollouts only (IoMode::act_lane): next action; last step's float64 reward and terminated | truncated << 1 | taken << 2
+  int ai = 0;
+  double rw = 0.0;
+  unsigned fl = 0;
 };
 
 template <int ENV, bool FULL>
@@ -805,7 +825,7 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
   const bool do_step = active && !do_reset;
 
   int cell = do_step ? gl.cell : 0;
-  const int a = do_step ? ldg_in(io.coh, (const int32_t*)actions, o4) : 0;
+  const int a = !do_step ? 0 : io.act_lane ? gl.ai : ldg_in(io.coh, (const int32_t*)actions, o4);
   // one uniform per step from the env stream (categorical_sample / np.random.choice); FrozenLakeEnv
   // and CliffWalkingEnv.reset also draw one (categorical_sample over the one-hot start distribution),
   // Bridge.reset draws nothing (envs/Bridge.py:103-111)
@@ -968,6 +988,10 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
     gl.cell = cell;
     gl.t = tnew;
     gl.st = (done ? NSG_ST_NEEDS_RESET : 0u) | (table_hint << NSG_ST_TABLE_SHIFT);
+    if (io.act_lane) {
+      gl.rw = reward;
+      gl.fl = (term ? 1u : 0u) | (trunc ? 2u : 0u) | (do_step ? 4u : 0u);
+    }
     if (out.obs) stg_o(io.coh, (int32_t*)out.obs, o4, cell);  // trajectory slice (rollout); NULL for nsg_step: cell[] is the obs
     stg_o(io.coh, out.reward, o4, (float)reward);
     stg_o(io.coh, out.terminated, o1, (uint8_t)(term ? 1 : 0));

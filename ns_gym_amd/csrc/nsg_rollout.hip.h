@@ -12,11 +12,62 @@
 
 namespace nsg {
 
+// ---- fused policy rollouts (nsg_rollout_policy): the action of step k is computed in the lane from what step k - 1 left there ----
+// The loops this replaces: MCTS._default_policy (benchmark_algorithms/MCTS.py:162-181), run_episode
+// (evaluate/run_experiment.py:108-129), the tutorial's tabular run_episode (tutorial.ipynb cell 12).
+struct PolicyArgs {
+  nsg_policy pol;
+  nsg_episode_acc acc;
+  float act_lo, act_hi;   // continuous env types: the action bounds (Box.sample / clip)
+  int32_t n_actions;      // discrete env types
+  int32_t reserved;
+};
+
+// NSG_POL_UNIFORM: two rounds of the splitmix64 finaliser over (key, env, step) - a pure function, so any sharding of the batch and any
+// chunking of the steps draw the same actions (host-callable: nsg_policy_bits, the oracle and the tests mirror it)
+__host__ __device__ __forceinline__ uint64_t pol_mix(uint64_t x) {
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t pol_bits(uint64_t seed, uint64_t env, uint64_t step) {
+  return pol_mix(pol_mix(seed + 0x9E3779B97F4A7C15ull * (env + 1u)) + 0xD1B54A32D192ED03ull * (step + 1u));
+}
+__device__ __forceinline__ int pol_uniform_discrete(uint64_t bits, int n_actions) { return (int)(((bits >> 32) * (uint64_t)(uint32_t)n_actions) >> 32); }
+__device__ __forceinline__ float pol_uniform_float(uint64_t bits, float lo, float hi) { return lo + (hi - lo) * ((float)(bits >> 40) * 5.9604644775390625e-08f); }
+
+// NSG_POL_LINEAR on the float32 observation: score_j = W[j][D] + sum_d W[j][d] * o[d], float32, in that order (the weights are uniform:
+// scalar loads).  Discrete: first argmax.  Continuous: clip(score_0).
+template <int D, bool FLOAT_ACT>
+__device__ __forceinline__ void pol_linear(const PolicyArgs& pa, const float* o, int& ai, float& af) {
+  typedef const __attribute__((address_space(4))) float* scalar_f32;
+  scalar_f32 W = (scalar_f32)(uint64_t)pa.pol.data;
+  if constexpr (FLOAT_ACT) {
+    float sc = W[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) sc = sc + W[d] * o[d];
+    af = sc < pa.act_lo ? pa.act_lo : sc > pa.act_hi ? pa.act_hi : sc;
+  } else {
+    int best = 0;
+    float top = 0.f;
+    for (int j = 0; j < pa.n_actions; j++) {
+      float sc = W[j * (D + 1) + D];
+#pragma unroll
+      for (int d = 0; d < D; d++) sc = sc + W[j * (D + 1) + d] * o[d];
+      if (j == 0 || sc > top) { top = sc; best = j; }
+    }
+    ai = best;
+  }
+}
+
 // `block_rel` / `block_count`: the workgroup's index within, and the size of, the range of workgroups that walks this segment
 // (the whole launch for nsg_rollout; a member's block range for nsg_rollout_group).
-template <int ENV, bool FULL>
+// POL: nsg_rollout_policy - `pa` says where the actions come from and where the episode accounts live; everything else is the same
+// launch (POL = false compiles to exactly the table-driven rollout).
+template <int ENV, bool FULL, bool POL = false>
 __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segment& sg, const void* __restrict__ actions,
-                                             int k_steps, const nsg_rollout_out& ro, const int block_rel, const int block_count) {
+                                             int k_steps, const nsg_rollout_out& ro, const int block_rel, const int block_count,
+                                             const PolicyArgs* __restrict__ pa = nullptr) {
   LdsTables lds;
   Tables tb;
   ZigLds zg;
@@ -38,6 +89,29 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
     // classic envs: the first stochastic update fns' streams live in LDS for the K steps (each lane touches only its own
     // record); the env's own np_random needs no state at all (episode word + jump-ahead, nsg_rng.hip.h)
     [[maybe_unused]] const int64_t ir = c * kBlock + threadIdx.x;
+    // policy rollouts: the lane's episode accounts, and what its first decision looks at - the handle's own observation row (the last
+    // reset / step left it there: nsg_step's and nsg_rollout's contract), for the grid envs the cell row
+    [[maybe_unused]] double acc_ret = 0.0;
+    [[maybe_unused]] int acc_len = 0;
+    [[maybe_unused]] bool acc_alive = false;
+    [[maybe_unused]] int cell0 = 0;
+    if constexpr (POL) {
+      if (ir < N) {
+        const nsg_episode_acc& ac = pa->acc;
+        acc_alive = ac.alive ? ldg(ac.alive, (uint32_t)ir) != 0 : true;
+        if (ac.ret) acc_ret = ldg(ac.ret, (uint32_t)ir * 8u);
+        if (ac.length) acc_len = ldg(ac.length, (uint32_t)ir * 4u);
+        if (pa->pol.kind == NSG_POL_LINEAR) {
+          if constexpr (!GRID) {
+#pragma unroll
+            for (int q = 0; q < D; q++) ls.o[q] = ldg(b.obs, (uint32_t)ir * (uint32_t)(4 * D) + 4u * (uint32_t)q);
+          }
+        }
+        if (pa->pol.kind == NSG_POL_BY_STATE) {
+          if constexpr (GRID) cell0 = ldg(b.cell, (uint32_t)ir * 4u);
+        }
+      }
+    }
     if constexpr (!GRID) {
       // every lane derives its env stream ONCE per launch (seed -> jump to draw D * episodes so far: ~500 instructions, all lanes
       // busy) and parks it in LDS: the resets of the K fused steps then draw sequentially from there (4 PCG64 steps each)
@@ -82,13 +156,62 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
       out.delta_change = ro.delta_change ? ro.delta_change + (int64_t)k * P * N : dflt.delta_change;
       }
       const void* act = FA ? (const void*)((const float*)actions + (int64_t)k * N) : (const void*)((const int32_t*)actions + (int64_t)k * N);
-      if constexpr (GRID) {
+      if constexpr (POL) {
+        // ---- the decision: one action per lane, from the lane's own registers (a lane beyond the batch decides nothing) ----
+        int ai = 0;
+        float af = 0.f;
+        if (ir < N) {
+          const int kind = pa->pol.kind;
+          if (kind == NSG_POL_TABLE) {
+            if constexpr (FA) af = ldg((const float*)act, (uint32_t)ir * 4u);
+            else ai = ldg((const int32_t*)act, (uint32_t)ir * 4u);
+          } else if (kind == NSG_POL_UNIFORM) {
+            const uint64_t bits = pol_bits(pa->pol.seed, (uint64_t)(pa->pol.index0 + ir), (uint64_t)(uint32_t)(pa->pol.step0 + k));
+            if constexpr (FA) af = pol_uniform_float(bits, pa->act_lo, pa->act_hi);
+            else ai = pol_uniform_discrete(bits, pa->n_actions);
+          } else if (kind == NSG_POL_BY_STATE) {
+            if constexpr (GRID) ai = ldg((const int32_t*)pa->pol.data, (uint32_t)(k == 0 ? cell0 : gl.cell) * 4u);
+          } else {
+            if constexpr (!GRID) pol_linear<D, FA>(*pa, ls.o, ai, af);
+          }
+          if (pa->pol.actions_out) {
+            if constexpr (FA) stg_out((float*)pa->pol.actions_out + (int64_t)k * N, (uint32_t)ir * 4u, af);
+            else stg_out((int32_t*)pa->pol.actions_out + (int64_t)k * N, (uint32_t)ir * 4u, ai);
+          }
+        }
+        double rw;
+        unsigned fl;
+        if constexpr (GRID) {
+          gl.ai = ai;
+          step_grid<ENV, FULL>(cfg, b, N, tb, zg, act, out, ir, ir < N, wc, gl, IoMode{k == 0, k == k_steps - 1, k > 0, false, false, false, true});
+          rw = gl.rw; fl = gl.fl;
+        } else {
+          ls.ai = ai; ls.af = af;
+          step_chunk<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, k == k_steps - 1, k > 0, true, false, false, true});
+          rw = ls.rw; fl = ls.fl;
+        }
+        // ---- the accounts: tot_reward += reward * gamma ** depth (MCTS.py:179), total_reward += reward (run_experiment.py:117) ----
+        if (ir < N && acc_alive && (fl & 4u)) {
+          const double g = (pa->acc.discount && acc_len < pa->acc.n_discount) ? ldg(pa->acc.discount, (uint32_t)acc_len * 8u) : 1.0;
+          acc_ret = acc_ret + rw * g;
+          acc_len++;
+          if (fl & 3u) acc_alive = false;
+        }
+      } else if constexpr (GRID) {
         const int64_t ig = c * kBlock + threadIdx.x;
         step_grid<ENV, FULL>(cfg, b, N, tb, zg, act, out, ig, ig < N, wc, gl, IoMode{k == 0, k == k_steps - 1, k > 0, false});
       } else {
         step_chunk<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, k == k_steps - 1, k > 0, true});
       }
       parity ^= 1;
+    }
+    if constexpr (POL) {
+      if (ir < N) {
+        const nsg_episode_acc& ac = pa->acc;
+        if (ac.alive) stg(ac.alive, (uint32_t)ir, (uint8_t)(acc_alive ? 1 : 0));
+        if (ac.ret) stg(ac.ret, (uint32_t)ir * 8u, acc_ret);
+        if (ac.length) stg(ac.length, (uint32_t)ir * 4u, (int32_t)acc_len);
+      }
     }
     if constexpr (!GRID && !FULL) __syncthreads();  // the next chunk refills the env streams
     if constexpr (!GRID && FULL) {
@@ -117,6 +240,14 @@ __global__ __launch_bounds__(kBlock, (kRolloutMinWaves<ENV, FULL>)) void rollout
                                                          int k_steps, nsg_rollout_out ro) {
   rollout_body<ENV, FULL>(seg->cfg, *seg, actions, k_steps, ro, (int)blockIdx.x, (int)gridDim.x);
 }
+
+#ifndef NSG_SPEC_BUILD
+// (no register bound: the decision and the accounts ride on top of the table-driven rollout's registers)
+template <int ENV, bool FULL>
+__global__ __launch_bounds__(kBlock) void rollout_policy_kernel(const Segment* __restrict__ seg, int k_steps, nsg_rollout_out ro, PolicyArgs pa) {
+  rollout_body<ENV, FULL, true>(seg->cfg, *seg, pa.pol.data, k_steps, ro, (int)blockIdx.x, (int)gridDim.x, &pa);
+}
+#endif
 
 // ============================================================================================
 // Resident stepper (nsg_resident_start): ONE launch that stays on the device and takes a step whenever the producer of the

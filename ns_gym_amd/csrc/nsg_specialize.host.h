@@ -154,6 +154,22 @@ inline std::string resident_source(const nsg_config& cfg, bool full) {
   return s;
 }
 
+// The fused policy rollout (nsg_rollout_policy) of a specialised handle: its own small unit like the resident stepper's, compiled the
+// first time such a rollout is asked for (with the batch-size policy of the handle's main unit, so that its resets and stores behave
+// like the handle's nsg_rollout).
+inline std::string policy_source(const nsg_config& cfg, bool full, bool resets_in_lane, bool stream_state) {
+  std::string s = spec_source(cfg, full, resets_in_lane, false, stream_state);
+  const size_t cut = s.find("extern \"C\" __global__");
+  s.resize(cut);
+  char buf[40];
+  snprintf(buf, sizeof(buf), "%d, %s", (int)cfg.env_type, full ? "true" : "false");
+  s += "extern \"C\" __global__ __launch_bounds__(NSG_BLOCK) void nsg_spec_rollout_policy(const nsg::Segment* __restrict__ seg, int k_steps,\n"
+       "                                                                          nsg_rollout_out ro, nsg::PolicyArgs pa) {\n"
+       "  nsg::rollout_body<" + std::string(buf) + ", true>(NSG_SPEC_CFG, *seg, pa.pol.data, k_steps, ro, (int)blockIdx.x, (int)gridDim.x, &pa);\n"
+       "}\n";
+  return s;
+}
+
 inline void emit_cfg_words(std::string& s, const nsg_config& cfg, int index) {
   char buf[48];
   snprintf(buf, sizeof(buf), "__device__ const uint64_t kCfgWords%d[] = {\n", index);
@@ -286,6 +302,15 @@ inline std::vector<char> resident_compile(const nsg_config& cfg, bool full, cons
   }
   return code;
 }
+inline std::vector<char> policy_compile(const nsg_config& cfg, bool full, const char* arch, std::string& err, bool resets_in_lane = false,
+                                        bool stream_state = false) {
+  std::vector<char> code = compile_source(policy_source(cfg, full, resets_in_lane, stream_state), arch, err);
+  if (!code.empty() && unit_uses_scratch(code) && !allow_spill()) {
+    err = "the specialised policy-rollout kernel spills vector registers (scratch memory); such builds are not used (see spec_compile)";
+    code.clear();
+  }
+  return code;
+}
 // The two kernels of the unit are judged separately: when the unit with both spills, the single-step kernel is built on its own -
 // if IT is clean the unit ships without nsg_spec_group_rollout (fused group rollouts of this member list run the generic kernel),
 // so a spilling rollout never costs nsg_step_group its specialised kernel.
@@ -382,6 +407,7 @@ struct Module {
   hipFunction_t step = nullptr, rollout = nullptr;  // single-config unit
   hipFunction_t group = nullptr, group_rollout = nullptr;   // heterogeneous-launch unit (single step, fused rollout)
   hipFunction_t resident = nullptr;                         // resident-stepper unit
+  hipFunction_t rollout_policy = nullptr;                   // fused policy-rollout unit
   uint64_t h0 = 0;                                    // config key (group keys are built from their members')
   int step_waves = 0;                                 // wavefronts per SIMD the step kernel's registers allow (0 = unknown)
   int origin = 0;                                     // NSG_SPEC_ORIGIN_*: where this code object came from

@@ -135,6 +135,8 @@ struct nsg_handle {
   int device;
   const nsg_spec::Module* spec;  // config-specialised step / rollout kernels (nsg_specialize), or NULL
   const nsg_spec::Module* spec_resident = nullptr;   // ... and its resident stepper (built on the first nsg_resident_start)
+  const nsg_spec::Module* spec_policy_unit = nullptr;   // ... and its fused policy rollout (built on the first nsg_rollout_policy)
+  bool spec_policy_tried = false;
   unsigned launches = 0;
   // What nsg_step_group remembers about a member list is keyed on these two: `id` is unique per nsg_create for the life of the
   // process (a new handle at a recycled address is a different member), `generation` counts the launch-relevant changes of
@@ -249,7 +251,7 @@ bool read_file(const std::string& path, std::vector<char>& code) {
 
 // Look a code object up in the process cache, then among the prebuilt units, then in the disk cache (spec_cache_dir), else
 // compile it; load it.
-enum { kUnitSingle = 0, kUnitGroup = 1, kUnitResident = 2 };
+enum { kUnitSingle = 0, kUnitGroup = 1, kUnitResident = 2, kUnitPolicy = 3 };
 template <typename Compile>
 int get_spec_module(int device, uint64_t h0, int unit_kind, Compile&& compile, const nsg_spec::Module** out) {
   const bool group = unit_kind == kUnitGroup;
@@ -336,6 +338,8 @@ int get_spec_module(int device, uint64_t h0, int unit_kind, Compile&& compile, c
     m.origin = origin;
     if (unit_kind == kUnitResident) {
       HIP_TRY(hipModuleGetFunction(&m.resident, m.mod, "nsg_spec_resident"));
+    } else if (unit_kind == kUnitPolicy) {
+      HIP_TRY(hipModuleGetFunction(&m.rollout_policy, m.mod, "nsg_spec_rollout_policy"));
     } else if (group) {
       HIP_TRY(hipModuleGetFunction(&m.group, m.mod, "nsg_spec_group"));
       // a unit whose fused rollout would have spilled ships the single-step kernel alone (group_compile): rollouts of this member
@@ -730,6 +734,24 @@ int nsg_step(nsg_handle* h, const void* actions_dev, void* stream) {
   return NSG_OK;
 }
 
+// the last step of a fused rollout landed in the handle's own output rows: mirror them into the last trajectory slice
+static int mirror_last_slice(nsg_handle* h, const nsg_rollout_out& o, int32_t k_steps, hipStream_t s) {
+  const nsg_buffers& bb = h->host.buf;
+  const int64_t n = h->n, K1 = k_steps - 1;
+  const int e = h->host.cfg.env_type;
+  const int P = h->host.cfg.n_params > 0 ? h->host.cfg.n_params : 1;
+  if (o.obs) {
+    if (is_grid_env(e)) HIP_TRY(hipMemcpyAsync((int32_t*)o.obs + K1 * n, bb.cell, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    else HIP_TRY(hipMemcpyAsync(o.obs + K1 * n * kObsDim[e], bb.obs, n * kObsDim[e] * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  if (o.reward) HIP_TRY(hipMemcpyAsync(o.reward + K1 * n, bb.reward, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (o.terminated) HIP_TRY(hipMemcpyAsync(o.terminated + K1 * n, bb.terminated, n, hipMemcpyDeviceToDevice, s));
+  if (o.truncated) HIP_TRY(hipMemcpyAsync(o.truncated + K1 * n, bb.truncated, n, hipMemcpyDeviceToDevice, s));
+  if (o.env_change) HIP_TRY(hipMemcpyAsync(o.env_change + K1 * P * n, bb.env_change, (size_t)P * n, hipMemcpyDeviceToDevice, s));
+  if (o.delta_change) HIP_TRY(hipMemcpyAsync(o.delta_change + K1 * P * n, bb.delta_change, (size_t)P * n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return NSG_OK;
+}
+
 int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const nsg_rollout_out* out, void* stream) {
   if (!h) return fail(NSG_EINVAL, "handle is NULL");
   if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
@@ -752,22 +774,86 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
                  hipLaunchKernelGGL((rollout_kernel<E, true>), dim3(launch_grid_for(h)), dim3(kBlock), rollout_lds, s, h->dev, actions_dev, k_steps, o));
   }
   HIP_TRY(hipGetLastError());
-  // the last step landed in the handle's own output rows: mirror them into the last trajectory slice
-  const nsg_buffers& bb = h->host.buf;
-  const int64_t n = h->n, K1 = k_steps - 1;
-  const int e = h->host.cfg.env_type;
-  const int P = h->host.cfg.n_params > 0 ? h->host.cfg.n_params : 1;
-  if (o.obs) {
-    if (is_grid_env(e)) HIP_TRY(hipMemcpyAsync((int32_t*)o.obs + K1 * n, bb.cell, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-    else HIP_TRY(hipMemcpyAsync(o.obs + K1 * n * kObsDim[e], bb.obs, n * kObsDim[e] * sizeof(float), hipMemcpyDeviceToDevice, s));
-  }
-  if (o.reward) HIP_TRY(hipMemcpyAsync(o.reward + K1 * n, bb.reward, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-  if (o.terminated) HIP_TRY(hipMemcpyAsync(o.terminated + K1 * n, bb.terminated, n, hipMemcpyDeviceToDevice, s));
-  if (o.truncated) HIP_TRY(hipMemcpyAsync(o.truncated + K1 * n, bb.truncated, n, hipMemcpyDeviceToDevice, s));
-  if (o.env_change) HIP_TRY(hipMemcpyAsync(o.env_change + K1 * P * n, bb.env_change, (size_t)P * n, hipMemcpyDeviceToDevice, s));
-  if (o.delta_change) HIP_TRY(hipMemcpyAsync(o.delta_change + K1 * P * n, bb.delta_change, (size_t)P * n * sizeof(float), hipMemcpyDeviceToDevice, s));
-  return NSG_OK;
+  return mirror_last_slice(h, o, k_steps, s);
 }
+
+// ---- fused policy rollouts (nsg_rollout.hip.h: rollout_body<ENV, FULL, true>) ---------------------------------------------------
+static const float kActLow[NSG_ENV_COUNT] = {0.f, -2.f, 0.f, 0.f, -1.f, 0.f, 0.f, 0.f};   // Pendulum max_torque 2.0, MountainCarContinuous +-1 [UPSTREAM]
+static const float kActHigh[NSG_ENV_COUNT] = {0.f, 2.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
+
+uint64_t nsg_policy_bits(uint64_t seed, uint64_t env_index, uint64_t step) { return pol_bits(seed, env_index, step); }
+
+int nsg_rollout_policy(nsg_handle* h, const nsg_policy* pol, int32_t k_steps, const nsg_rollout_out* out, const nsg_episode_acc* acc, void* stream) {
+  if (!h) return fail(NSG_EINVAL, "handle is NULL");
+  if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
+  if (!pol || k_steps <= 0) return fail(NSG_EINVAL, "bad policy-rollout arguments");
+  const int e = h->host.cfg.env_type;
+  const bool grid_env = is_grid_env(e);
+  switch (pol->kind) {
+    case NSG_POL_TABLE:
+      if (!pol->data) return fail(NSG_EINVAL, "NSG_POL_TABLE: data (actions[K][N]) is NULL");
+      break;
+    case NSG_POL_UNIFORM:
+      if (pol->step0 < 0 || pol->index0 < 0) return fail(NSG_EINVAL, "NSG_POL_UNIFORM: step0 and index0 must not be negative");
+      break;
+    case NSG_POL_BY_STATE:
+      if (!grid_env) return fail(NSG_EINVAL, "NSG_POL_BY_STATE needs a discrete state: grid envs only (classic control: NSG_POL_LINEAR)");
+      if (!pol->data || pol->n_data < h->host.cfg.nrow * h->host.cfg.ncol)
+        return fail(NSG_EINVAL, "NSG_POL_BY_STATE: the table must hold one action per cell (%d), got %d", h->host.cfg.nrow * h->host.cfg.ncol, pol->n_data);
+      break;
+    case NSG_POL_LINEAR:
+      if (grid_env) return fail(NSG_EINVAL, "NSG_POL_LINEAR works on the float32 observation of the classic-control envs (grid envs: NSG_POL_BY_STATE)");
+      if (!pol->data || pol->n_data != (kNActions[e] > 0 ? kNActions[e] : 1))
+        return fail(NSG_EINVAL, "NSG_POL_LINEAR: %d weight rows of obs_dim + 1 floats are required, got %d", kNActions[e] > 0 ? kNActions[e] : 1, pol->n_data);
+      break;
+    default: return fail(NSG_EINVAL, "unknown policy kind %d", pol->kind);
+  }
+  PolicyArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.pol = *pol;
+  if (acc) pa.acc = *acc;
+  if (pa.acc.discount && pa.acc.n_discount <= 0) pa.acc.discount = nullptr;
+  pa.act_lo = kActLow[e];
+  pa.act_hi = kActHigh[e];
+  pa.n_actions = kNActions[e];
+  nsg_rollout_out o;
+  memset(&o, 0, sizeof(o));
+  if (out) o = *out;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t rollout_lds = (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp) +
+                             (grid_env ? 0 : kLdsStreamBytes * (1 + upd_lds_count(h->host.cfg)));
+  const int grid = launch_grid_for(h);
+  bool launched = false;
+  if (h->spec) {   // a specialised handle: the policy rollout compiled for its configuration (its own unit, built on first use)
+    if (!h->spec_policy_unit && !h->spec_policy_tried) {
+      h->spec_policy_tried = true;
+      hipDeviceProp_t prop;
+      HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+      const SpecPolicy sp = spec_policy(h->host.cfg, h->n);
+      uint64_t h0 = nsg_spec::fnv1a("policy", 6, h->spec->h0);
+      const int grc = get_spec_module(h->device, h0, kUnitPolicy,
+                                      [&](std::string& err) { return nsg_spec::policy_compile(h->host.cfg, sp.full, prop.gcnArchName, err, sp.inlane, sp.stream_state); },
+                                      &h->spec_policy_unit);
+      if (grc) h->spec_policy_unit = nullptr;   // the generic kernel stays in force
+    }
+    if (h->spec_policy_unit) {
+      void* args[] = {(void*)&h->dev, (void*)&k_steps, (void*)&o, (void*)&pa};
+      HIP_TRY(hipModuleLaunchKernel(h->spec_policy_unit->rollout_policy, grid, 1, 1, kBlock, 1, 1, (unsigned)rollout_lds, s, args, nullptr));
+      launched = true;
+    }
+  }
+  if (!launched) {
+    if (h->host.simple_theta) {
+      DISPATCH_ENV(e, hipLaunchKernelGGL((rollout_policy_kernel<E, false>), dim3(grid), dim3(kBlock), rollout_lds, s, h->dev, k_steps, o, pa));
+    } else {
+      DISPATCH_ENV(e, hipLaunchKernelGGL((rollout_policy_kernel<E, true>), dim3(grid), dim3(kBlock), rollout_lds, s, h->dev, k_steps, o, pa));
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return mirror_last_slice(h, o, k_steps, s);
+}
+/* Which kernel nsg_rollout_policy launches for this handle: 0 generic, 1 the specialised unit (after the first such rollout). */
+int nsg_rollout_policy_kind(const nsg_handle* h) { return h && h->spec_policy_unit ? 1 : 0; }
 
 // ---- resident stepper (nsg_rollout.hip.h: resident_body) -----------------------------------------------------------------
 // The waits of the resident kernels are budgets of the device's steady counter (wall_clock64()).  Its rate is MEASURED, once per
@@ -1333,6 +1419,23 @@ int nsg_spec_build_resident(const nsg_config* cfg, const char* arch, void** code
   if (rc) return rc;
   std::string err;
   std::vector<char> code = nsg_spec::resident_compile(*cfg, !cfg_simple_theta(*cfg), arch && *arch ? arch : "gfx950", err);
+  if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
+  void* p = malloc(code.size());
+  if (!p) return fail(NSG_ENOMEM, "out of host memory");
+  memcpy(p, code.data(), code.size());
+  *code_out = p;
+  *size_out = code.size();
+  return NSG_OK;
+}
+
+int nsg_spec_build_policy(const nsg_config* cfg, const char* arch, void** code_out, size_t* size_out) {
+  if (!code_out || !size_out) return fail(NSG_EINVAL, "NULL output argument");
+  *code_out = nullptr;
+  *size_out = 0;
+  int rc = validate(cfg, (size_t)kMaxTableBytes);
+  if (rc) return rc;
+  std::string err;
+  std::vector<char> code = nsg_spec::policy_compile(*cfg, !cfg_simple_theta(*cfg), arch && *arch ? arch : "gfx950", err);
   if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
   void* p = malloc(code.size());
   if (!p) return fail(NSG_ENOMEM, "out of host memory");

@@ -305,6 +305,41 @@ class VecNSEnv:
                 out[k] = out[k].view(torch.bool)
         return out
 
+    def rollout_policy(self, policy, k_steps: int, record=(), accounts=None, step0: int = 0, record_actions: bool = False):
+        """K CLOSED-LOOP steps in one launch (`nsg_rollout_policy`): every env's action of step k is computed inside the kernel from
+        what its step k - 1 produced - `policy` is a `ns_gym_amd.policies.Policy` (UniformRandom, TabularPolicy, LinearPolicy) -
+        and `accounts` (`policies.EpisodeAccounts`) keeps each env's discounted return, length and alive flag in registers across
+        the K steps.  With `record=()` nothing but the accounts leaves the launch.  `step0`: the index of this launch's first
+        step in the caller's loop (UniformRandom's counter).  Returns the recorded [K, ...] tensors (+ "actions" when asked)."""
+        K = int(k_steps)
+        P, N = max(self.cfg.n_params, 1), self.N
+        shapes = {"obs": ((K, N) if self.is_frozenlake else (K, N, self.obs_dim),
+                          torch.int32 if self.is_frozenlake else torch.float32),
+                  "reward": ((K, N), torch.float32), "terminated": ((K, N), torch.uint8),
+                  "truncated": ((K, N), torch.uint8), "env_change": ((K, P, N), torch.uint8),
+                  "delta_change": ((K, P, N), torch.float32)}
+        out = {k: torch.empty(shapes[k][0], dtype=shapes[k][1], device=self.device) for k in record}
+        ro = A.RolloutOut(**{k: v.data_ptr() for k, v in out.items()})
+        acts = None
+        if record_actions:
+            acts = torch.empty((K, N), dtype=torch.float32 if self.action_is_float else torch.int32, device=self.device)
+        pol = policy._struct(self, step0, acts)
+        acc = accounts._struct() if accounts is not None else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nsg_rollout_policy(self._h, C.byref(pol), K, C.byref(ro), C.byref(acc) if acc is not None else None,
+                                                   self._stream), "nsg_rollout_policy")
+        for k in ("terminated", "truncated"):
+            if k in out:
+                out[k] = out[k].view(torch.bool)
+        if acts is not None:
+            out["actions"] = acts
+        return out
+
+    @property
+    def policy_kernels(self) -> str:
+        """Which kernel `rollout_policy` launches: the handle's specialised unit (after the first such rollout) or the generic one."""
+        return "config-specialised" if self.lib.nsg_rollout_policy_kind(self._h) == 1 else "generic"
+
     def _as_actions(self, actions):
         dt = torch.float32 if self.action_is_float else torch.int32
         if (type(actions) is torch.Tensor and actions.dtype == dt and actions.dim() == 1 and actions.shape[0] == self.N

@@ -1,0 +1,240 @@
+"""nsg_rollout_policy: K closed-loop steps in one launch - the policy is evaluated inside the kernel, the episode accounts stay in
+registers.  Whatever the action source, the launch must be indistinguishable from the loop it replaces (MCTS._default_policy,
+MCTS.py:162-181; run_episode, run_experiment.py:108-129; the tutorial's tabular run_episode, cell 12):
+
+  * UniformRandom / action tables: bit-identical to `VecNSEnv.rollout` over the same action table - every recorded row, every
+    persistent row, the counters - for every env type, generic kernels and the specialised unit, in one launch or chunked;
+  * TabularPolicy / LinearPolicy (closed loops): bit-identical to `step()` loops driven by the same policy evaluated on the host;
+  * the accounts: Python's `tot_reward += reward * gamma ** depth` over the recorded rewards, bit for bit (float64).
+"""
+import numpy as np
+import pytest
+
+from tests.util import TRAJ_SPECS, make_env_from_spec
+
+pytestmark = pytest.mark.gpu
+
+REC = ("obs", "reward", "terminated", "truncated", "env_change", "delta_change")
+
+
+def _vec(*a, **k):
+    from ns_gym_amd.vec_env import VecNSEnv
+
+    return VecNSEnv(*a, **k)
+
+
+def _same_batch(a, b):
+    import torch
+
+    for field in ("theta", "t", "state"):
+        assert torch.equal(getattr(a, field), getattr(b, field)), field
+    if not a.is_grid:
+        assert torch.equal(a.phys, b.phys)
+    for row in ("status", "episode", "rng_env", "rng_upd", "cursor", "ep_return", "last_return", "last_length", "reward", "terminated", "truncated"):
+        if a.buf.get(row) is not None:
+            assert torch.equal(a.buf[row], b.buf[row]), row
+    assert a.counters() == b.counters()
+
+
+def _spec_of(name):
+    if name in TRAJ_SPECS:
+        return TRAJ_SPECS[name]
+    from tests.test_oracle_grid import grid_spec
+
+    return grid_spec(name)
+
+
+@pytest.mark.parametrize("specialize", [False, True])
+@pytest.mark.parametrize("name,n,K", [
+    ("c1_cartpole_masspole_inc", 5000, 97), ("c2_cartpole_gravity_rw", 8192, 40), ("cartpole_two_params", 4096, 64),
+    ("c4_pendulum_m_inc", 4096, 230), ("acrobot_constraints", 2048, 40), ("mountaincar", 2048, 210),
+    ("c3_frozenlake_step50", 8192, 120), ("frozenlake_randomcat", 2048, 60), ("cliff_decrement", 4096, 90), ("bridge_split_onehot", 2048, 60),
+])
+def test_uniform_policy_equals_table_rollout(name, n, K, specialize):
+    """The in-kernel uniform draws are the table `UniformRandom.table()` produces on the host; a fused policy rollout over them - in
+    one launch, and again chunked with the step counter carried over - equals nsg_rollout over that table in every row."""
+    import torch
+
+    from ns_gym_amd.policies import EpisodeAccounts, UniformRandom
+
+    spec = _spec_of(name)
+    a, b, c = (make_env_from_spec(_vec, spec, n=n, track_returns=True, specialize=specialize) for _ in range(3))
+    for e in (a, b, c):
+        e.reset(seed=99)
+    pol = UniformRandom(seed=1234, index0=7)
+    table = pol.table(a, 0, K)
+    assert table.shape == (K, n)
+    if a.action_is_float:
+        lo, hi = a.spec.env_type.action_low, a.spec.env_type.action_high
+        assert table.min() >= lo and table.max() <= hi and table.std() > 0.2 * (hi - lo)
+    else:
+        assert set(np.unique(table)) == set(range(a.n_actions))
+    ref = a.rollout(torch.from_numpy(table).cuda(), record=REC)
+    acc = EpisodeAccounts(b, gamma=0.97, horizon=K + 1)
+    out = b.rollout_policy(pol, K, record=REC, accounts=acc, record_actions=True)
+    assert torch.equal(out["actions"].cpu(), torch.from_numpy(table))
+    for k in REC:
+        assert torch.equal(out[k], ref[k]), k
+    _same_batch(a, b)
+    assert b.policy_kernels == ("config-specialised" if (specialize and b.specialized) else "generic")
+    # chunked: three launches, the counter carried over, the accounts carried over
+    acc_c = EpisodeAccounts(c, gamma=0.97, horizon=K + 1)
+    k1, k2 = K // 3, K // 2
+    parts = [c.rollout_policy(pol, k1, record=REC, accounts=acc_c, step0=0), c.rollout_policy(pol, k2 - k1, record=REC, accounts=acc_c, step0=k1),
+             c.rollout_policy(pol, K - k2, record=REC, accounts=acc_c, step0=k2)]
+    for k in REC:
+        assert torch.equal(torch.cat([p[k] for p in parts]), ref[k]), k
+    _same_batch(a, c)
+    for f in ("ret", "length", "alive"):
+        assert torch.equal(getattr(acc, f), getattr(acc_c, f)), f
+    # the accounts against Python's own loop over the recorded rewards (float32-exact rewards only: CartPole, Acrobot, MountainCar, grid defaults)
+    rew = ref["reward"].cpu().numpy().astype(np.float64)
+    done = (ref["terminated"] | ref["truncated"]).cpu().numpy()
+    exact = spec["env_id"] not in ("Pendulum-v1", "MountainCarContinuous-v0") and not spec.get("wrapper_kwargs", {}).get("modified_rewards")
+    ret, length, alive = acc.ret.cpu().numpy(), acc.length.cpu().numpy(), acc.alive.cpu().numpy()
+    for i in list(range(0, n, max(1, n // 300))):
+        tot, depth, live = 0.0, 0, True
+        for k in range(K):
+            if not live:
+                break
+            tot += rew[k, i] * 0.97 ** depth
+            depth += 1
+            if done[k, i]:
+                live = False
+        assert length[i] == depth and bool(alive[i]) == live
+        if exact:
+            assert ret[i] == tot, (i, ret[i], tot)
+        else:
+            assert abs(ret[i] - tot) <= 1e-5 * max(1.0, abs(tot))
+    for e in (a, b, c):
+        e.close()
+
+
+@pytest.mark.parametrize("specialize", [False, True])
+def test_table_kind_is_nsg_rollout(specialize):
+    import ctypes as C
+
+    import torch
+
+    from ns_gym_amd import _abi as A
+    from ns_gym_amd import _lib
+    from tests.golden.make_golden import make_actions
+
+    spec = TRAJ_SPECS["c2_cartpole_gravity_rw"]
+    n, K = 4096, 33
+    a, b = (make_env_from_spec(_vec, spec, n=n, specialize=specialize) for _ in range(2))
+    a.reset(seed=3); b.reset(seed=3)
+    acts = torch.from_numpy(make_actions(spec["env_id"], K, n)).cuda()
+    ref = a.rollout(acts, record=REC)
+
+    class Table:
+        kind = A.NSG_POL_TABLE
+
+        def _struct(self, env, step0, actions_out):
+            return A.Policy(kind=self.kind, step0=0, seed=0, index0=0, data=acts.data_ptr(), n_data=0, reserved0=0, actions_out=None)
+
+    out = b.rollout_policy(Table(), K, record=REC)
+    for k in REC:
+        assert torch.equal(out[k], ref[k]), k
+    _same_batch(a, b)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("name,seed", [("c3_frozenlake_step50", 1), ("frozenlake_decrement", 2), ("frozenlake_4x4_drift_rewards", 3),
+                                       ("cliff_decrement", 4), ("bridge_split_onehot", 5)])
+@pytest.mark.parametrize("specialize", [False, True])
+def test_tabular_policy_closed_loop(name, seed, specialize):
+    """`action = policy[observation]` (tutorial.ipynb cell 12) fused: equal to a step() loop that looks the action up in the same
+    table on the host side of the launch boundary."""
+    import torch
+
+    from ns_gym_amd.policies import EpisodeAccounts, TabularPolicy
+
+    spec = _spec_of(name)
+    n, K = 3000, 130
+    a, b = (make_env_from_spec(_vec, spec, n=n, specialize=specialize) for _ in range(2))
+    a.reset(seed=seed); b.reset(seed=seed)
+    nS = a.cfg.nrow * a.cfg.ncol
+    rng = np.random.default_rng(seed)
+    pol = TabularPolicy(rng.integers(0, 4, size=nS))
+    acc = EpisodeAccounts(b, gamma=None)
+    # a few plain steps first, so that the first in-kernel decision reads a cell row that is not the start state
+    warm = torch.from_numpy(rng.integers(0, 4, size=(3, n)).astype(np.int32)).cuda()
+    for k in range(3):
+        a.step(warm[k]); b.step(warm[k])
+    acc.restart(alive=~(b.buf["terminated"].bool() | b.buf["truncated"].bool()))
+    alive0 = acc.alive.clone().bool()
+    out = b.rollout_policy(pol, K, record=("obs", "reward", "terminated", "truncated"), accounts=acc, record_actions=True)
+    tot = torch.zeros(n, dtype=torch.float64, device="cuda")
+    steps = torch.zeros(n, dtype=torch.int32, device="cuda")
+    alive = alive0.clone()
+    for k in range(K):
+        act = pol(a.state).to(torch.int32)
+        needs_reset = (a.buf["status"] & 1).bool()          # a pending autoreset takes no action and changes no account
+        obs, r, te, tr, _ = a.step(act)
+        took = ~needs_reset
+        assert torch.equal(out["actions"][k][took], act[took]), k
+        assert torch.equal(out["obs"][k], a.state) and torch.equal(out["reward"][k], r)
+        assert torch.equal(out["terminated"][k], te) and torch.equal(out["truncated"][k], tr)
+        live = alive & took
+        tot += torch.where(live, r.to(torch.float64), torch.zeros_like(tot))
+        steps += live.to(torch.int32)
+        alive = alive & ~(live & (te | tr))
+    _same_batch(a, b)
+    assert torch.equal(acc.length, steps) and torch.equal(acc.alive.bool(), alive)
+    if not spec.get("wrapper_kwargs", {}).get("modified_rewards"):
+        assert torch.equal(acc.ret, tot)
+    else:
+        assert torch.allclose(acc.ret, tot, rtol=1e-6, atol=1e-6)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("name", ["c1_cartpole_masspole_inc", "c2_cartpole_gravity_rw", "c4_pendulum_m_inc", "acrobot_constraints", "mountaincar"])
+@pytest.mark.parametrize("specialize", [False, True])
+def test_linear_policy_closed_loop(name, specialize):
+    """A linear policy on the float32 observation, fused: equal to a step() loop whose actions the host computes from the
+    observation of the previous step with the same float32 operation order."""
+    import torch
+
+    from ns_gym_amd.policies import EpisodeAccounts, LinearPolicy
+
+    spec = TRAJ_SPECS[name]
+    n, K = 2048, 90
+    a, b = (make_env_from_spec(_vec, spec, n=n, specialize=specialize) for _ in range(2))
+    a.reset(seed=17); b.reset(seed=17)
+    rng = np.random.default_rng(5)
+    rows = 1 if a.action_is_float else a.n_actions
+    pol = LinearPolicy(rng.normal(size=(rows, a.obs_dim + 1)).astype(np.float32))
+    lo, hi = a.spec.env_type.action_low, a.spec.env_type.action_high
+    acc = EpisodeAccounts(b, gamma=0.999, horizon=K + 1)
+    out = b.rollout_policy(pol, K, record=("obs", "reward", "terminated", "truncated"), accounts=acc, record_actions=True)
+    for k in range(K):
+        act_np = pol.decide(a.state.cpu().numpy(), a.action_is_float, lo, hi)
+        act = torch.from_numpy(act_np).cuda()
+        needs_reset = (a.buf["episode"] & 1).bool() if a.spec.class_name != "PendulumEnv" else (a.t >= a.cfg.max_episode_steps)
+        obs, r, te, tr, _ = a.step(act)
+        took = ~needs_reset
+        assert torch.equal(out["actions"][k][took], act[took]), (k, name)
+        assert torch.equal(out["obs"][k], a.state), k
+        assert torch.equal(out["reward"][k], r) and torch.equal(out["terminated"][k], te) and torch.equal(out["truncated"][k], tr)
+    _same_batch(a, b)
+    assert int(acc.length.min()) >= 1
+    a.close(); b.close()
+
+
+def test_policy_argument_errors():
+    from ns_gym_amd._lib import NsgError
+    from ns_gym_amd.policies import LinearPolicy, TabularPolicy
+
+    cp = make_env_from_spec(_vec, TRAJ_SPECS["c1_cartpole_masspole_inc"], n=256)
+    fl = make_env_from_spec(_vec, TRAJ_SPECS["c3_frozenlake_step50"], n=256)
+    cp.reset(seed=0); fl.reset(seed=0)
+    with pytest.raises(NsgError, match="grid envs only"):
+        cp.rollout_policy(TabularPolicy(np.zeros(64)), 4)
+    with pytest.raises(NsgError, match="one action per cell"):
+        fl.rollout_policy(TabularPolicy(np.zeros(10)), 4)
+    with pytest.raises(NsgError, match="classic-control"):
+        fl.rollout_policy(LinearPolicy(np.zeros((4, 2), dtype=np.float32)), 4)
+    with pytest.raises(NsgError, match="weight rows"):
+        cp.rollout_policy(LinearPolicy(np.zeros((3, 5), dtype=np.float32)), 4)
+    cp.close(); fl.close()
