@@ -231,7 +231,10 @@ typedef struct nsg_buffers {
   double* derived;       /* [2][N] CartPole planning copies only: total_mass, polemass_length as resolved
                             at fork time.  get_planning_env() re-installs the initial θ AFTER the
                             copy's _dependency_resolver() ran and a frozen copy never resolves again
-                            (classic_control.py:70-75,133-136,183), so these can be stale w.r.t. θ  */
+                            (classic_control.py:70-75,133-136,183), so these can be stale w.r.t. θ.
+                            [4][N] CliffWalking planning copies: the probabilities of the copy's OWN table (the wrapper's
+                            `self.P`, toy_text.py:246-248), which a frozen copy never steps with (table_prob holds the base
+                            env's) but hands to a copy taken of IT (nsg_fork)                                            */
   int32_t* t;            /* [N]    wrapper time t == obs["relative_time"] (base.py:314,347) */
   int32_t* t_fork;       /* [N]    planning copies only: t at fork time.  __deepcopy__ builds a fresh
                             gym.make() env, so TimeLimit's elapsed count restarts at 0 while the
@@ -348,6 +351,11 @@ int nsg_step(nsg_handle* h, const void* actions_dev, void* stream);
  *   1 = construction-time θ (get_planning_env without delta_change_notification)
  * and re-seeds every stream from `entropy` (the reference uses fresh OS entropy:
  * _reseed_planning_env_rngs, base.py:433-441; env np_random of the new gym.make() env).
+ * `src` may itself be a planning copy (MCTS.search deep-copies the planning env it is given for every simulation, MCTS.py:131).
+ * Grid envs then follow the reference's two P tables (the wrapper's own and the base env's): a FrozenLake copy of a copy steps
+ * with the table of initial_prob_dist (toy_text.py:491-508: the first copy's own table is its constructor's), a CliffWalking copy
+ * of a copy with the first source's current table even where get_planning_env() had given the first copy the initial one
+ * (toy_text.py:219-221,246-249).  tests/golden/policy_mcts_frozenlake_*.npz, policy_mcts_cliff_theta0.npz.
  * dst may hold k whole copies of src (dst N = k * src N; copy j <- env j mod src N, streams from
  * entropy + j): the simulations a planner runs for one decision (MCTS.py:131: one deepcopy per
  * simulation) as ONE batch that a single nsg_rollout launch then advances. */

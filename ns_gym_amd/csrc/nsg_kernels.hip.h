@@ -1449,13 +1449,34 @@ __global__ __launch_bounds__(kBlock) void fork_kernel(const Segment* __restrict_
     }
     if (fl) {
       if (db.table_prob) {
-        // which P table the copy steps with.  FrozenLake (toy_text.py:479-480,505-508,365-367): an
-        // in_sim_change copy re-installs ITS OWN table, built from initial_prob_dist by its constructor.
-        // CliffWalking (toy_text.py:219-221,246-249,187): the copy's own table IS the copied current one.
-        const bool use_initial = env == NSG_ENV_FROZENLAKE ? (in_sim_change || theta_mode == 1) : (theta_mode == 1 && !in_sim_change);
-        for (int k = 0; k < nd; k++)
-          db.table_prob[blk_off8(nd, k, i) / 8] = use_initial ? cfg.initial_prob[0][k] : sb.table_prob[blk_off8(nd, k, is) / 8];
-        if (use_initial) db.status[i] = (uint8_t)((sb.status[is] & NSG_ST_NEEDS_RESET) | (NSG_ST_TABLE_INITIAL << NSG_ST_TABLE_SHIFT));
+        // which P table the copy steps with.  The reference wrappers hold TWO tables - the wrapper's own `self.P` and the base env's
+        // `unwrapped.P`; a frozen copy steps with the latter and never touches either, an in_sim_change copy (like a real env)
+        // re-installs its own before every step.  buffers.table_prob is the one the env steps with.
+        // FrozenLake (toy_text.py:479-480,505-508,365-367): a copy's OWN table is built from initial_prob_dist by its constructor and
+        // its base env gets the SOURCE's own table - so an in_sim_change copy steps with the initial table, and so does a copy OF A
+        // COPY (the source's own table is that initial one; MCTS.search deep-copies the planning env it was given, MCTS.py:131:
+        // its simulations run on the initial distribution whatever the slipperiness has become).
+        // CliffWalking (toy_text.py:219-221,246-249,187): a copy's own table AND its base env's are the source's own table; only
+        // get_planning_env() without delta notification then overwrites the base env's with the initial one - which a copy of THAT
+        // copy does not inherit (it takes the source's own, still current, table).  A frozen CliffWalking copy therefore keeps its
+        // own table's probabilities in buffers.derived.
+        const bool src_sim = (cfg.flags & NSG_F_SIM_ENV) != 0;
+        if (env == NSG_ENV_FROZENLAKE) {
+          const bool use_initial = in_sim_change || theta_mode == 1 || src_sim;
+          for (int k = 0; k < nd; k++)
+            db.table_prob[blk_off8(nd, k, i) / 8] = use_initial ? cfg.initial_prob[0][k] : sb.table_prob[blk_off8(nd, k, is) / 8];
+          if (use_initial) db.status[i] = (uint8_t)((sb.status[is] & NSG_ST_NEEDS_RESET) | (NSG_ST_TABLE_INITIAL << NSG_ST_TABLE_SHIFT));
+        } else {
+          const bool own_in_derived = src_sim && !in_sim_change && sb.derived;   // the source is a frozen copy
+          const bool use_initial = theta_mode == 1 && !in_sim_change;
+          for (int k = 0; k < nd; k++) {
+            const double own = own_in_derived ? sb.derived[(int64_t)k * Ns + is] : sb.table_prob[blk_off8(nd, k, is) / 8];
+            if (db.derived) db.derived[(int64_t)k * N + i] = own;
+            db.table_prob[blk_off8(nd, k, i) / 8] = use_initial ? cfg.initial_prob[0][k] : own;
+          }
+          if (use_initial) db.status[i] = (uint8_t)((sb.status[is] & NSG_ST_NEEDS_RESET) | (NSG_ST_TABLE_INITIAL << NSG_ST_TABLE_SHIFT));
+          else if (own_in_derived) db.status[i] = (uint8_t)(sb.status[is] & NSG_ST_NEEDS_RESET);   // (the source's hint names ITS stepping table: read the rows)
+        }
       }
       if (db.prob && sb.prob) db.prob[i] = sb.prob[is];
     }

@@ -484,7 +484,7 @@ int nsg_layout_query(const nsg_config* cfg, int64_t n, nsg_layout* out) {
   out->t = n;
   const bool simenv = (cfg->flags & NSG_F_SIM_ENV) != 0;
   out->t_fork = simenv ? n : 0;
-  out->derived = (simenv && e == NSG_ENV_CARTPOLE) ? 2 * n : 0;
+  out->derived = (simenv && e == NSG_ENV_CARTPOLE) ? 2 * n : (simenv && e == NSG_ENV_CLIFFWALKING) ? 4 * n : 0;
   out->status = fl ? n : 0;     // grid envs: a byte; classic-control envs: the episode word
   out->episode = fl ? 0 : n;
   // grid envs: chunk-blocked PCG64 state rows; classic-control envs: descriptor + one (seed, spawn key) record per env

@@ -766,9 +766,17 @@ static void frozenlake_move(const nsg_config* cfg, int row, int col, int a, int*
   *nr = row; *nc = col;
 }
 
+/* what the last step_one of this thread paid, in the base MDP's own float64 (the reward row is float32), and whether it was a
+   transition at all (a pending autoreset takes no action): the closed loops of orc_rollout_policy sum THIS, like the reference's
+   Python loops sum the env's Python float */
+static __thread double g_reward64;
+static __thread int g_took_step;
+
 static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N, int64_t i,
                      const void* actions, uint64_t* cnt) {
   int env = cfg->env_type, P = cfg->n_params;
+  g_reward64 = 0.0;
+  g_took_step = 0;
   /* NSG_F_NO_AUTORESET: the reference's single wrappers forward every step() to gymnasium whatever `done` said (base.py:313);
      status bit 0 then means "terminated at an earlier step of this episode" (CartPole's steps_beyond_terminated [UPSTREAM]) */
   const int noauto = (cfg->flags & NSG_F_NO_AUTORESET) != 0;
@@ -949,6 +957,8 @@ static void step_one(const nsg_config* cfg, const uint8_t* tables, const nsg_buf
   int elapsed = t - ((sim && b->t_fork) ? b->t_fork[i] : 0);
   int trunc = cfg->max_episode_steps > 0 && elapsed >= cfg->max_episode_steps;
   b->reward[i] = (float)reward;
+  g_reward64 = reward;
+  g_took_step = 1;
   b->terminated[i] = (uint8_t)term;
   b->truncated[i] = (uint8_t)trunc;
   int done = term || trunc;
@@ -977,6 +987,84 @@ int orc_step(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b,
 int orc_step_range(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N, const void* actions,
                    int64_t lo, int64_t hi, uint64_t* cnt) {
   for (int64_t i = lo; i < hi; i++) step_one(cfg, tables, b, N, i, actions, cnt);
+  return 0;
+}
+
+/* ---- closed loops: the reference's step consumers, restated --------------------------------------------------------------------
+ *   MCTS._default_policy       benchmark_algorithms/MCTS.py:162-181   while not terminated and depth < d and not truncated:
+ *                                                                      action = np.random.choice(actions); step; tot_reward += reward * gamma ** depth
+ *   run_episode                evaluate/run_experiment.py:108-129     while not done and not truncated: act, step, total_reward += reward
+ *   the tutorial's run_episode tutorial.ipynb cell 12                  action = policy[observation]
+ * One env at a time, one step at a time: decide from the env's last observation (the float32 obs row / the cell), step, add.
+ * Mirrors nsg_rollout_policy's contract (include/nsgym_hip.h): `discount[j]` is gamma ** j as the CALLER's pow computed it, and a
+ * pending autoreset takes no action and changes no account.  reward64_out / actions_out: [K][N] or NULL. */
+static uint64_t pol_mix64(uint64_t x) { /* splitmix64's finaliser */
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+  x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+uint64_t orc_policy_bits(uint64_t seed, uint64_t env, uint64_t step) {
+  return pol_mix64(pol_mix64(seed + 0x9E3779B97F4A7C15ULL * (env + 1)) + 0xD1B54A32D192ED03ULL * (step + 1));
+}
+int orc_rollout_policy(const nsg_config* cfg, const uint8_t* tables, const nsg_buffers* b, int64_t N, const nsg_policy* pol, int k_steps,
+                       const nsg_episode_acc* acc, double* reward64_out, uint8_t* took_out) {
+  static const float ACT_LO[NSG_ENV_COUNT] = {0, -2.f, 0, 0, -1.f, 0, 0, 0}, ACT_HI[NSG_ENV_COUNT] = {0, 2.f, 0, 0, 1.f, 0, 0, 0};
+  static const int N_ACT[NSG_ENV_COUNT] = {2, 0, 3, 3, 0, 4, 4, 4};
+  const int env = cfg->env_type, D = OBS_DIM[env];
+  const int fa = env == NSG_ENV_PENDULUM || env == NSG_ENV_MOUNTAINCAR_CONT;
+  int32_t* ai = (int32_t*)calloc((size_t)N, sizeof(int32_t));
+  float* af = (float*)ai;
+  if (!ai) return -1;
+  uint64_t* cnt = b->counters;
+  for (int k = 0; k < k_steps; k++) {
+    for (int64_t i = 0; i < N; i++) {
+      switch (pol->kind) {
+        case NSG_POL_TABLE:
+          if (fa) af[i] = ((const float*)pol->data)[(int64_t)k * N + i]; else ai[i] = ((const int32_t*)pol->data)[(int64_t)k * N + i];
+          break;
+        case NSG_POL_UNIFORM: {
+          const uint64_t bits = orc_policy_bits(pol->seed, (uint64_t)(pol->index0 + i), (uint64_t)(uint32_t)(pol->step0 + k));
+          if (fa) af[i] = ACT_LO[env] + (ACT_HI[env] - ACT_LO[env]) * ((float)(bits >> 40) * 5.9604644775390625e-08f);
+          else ai[i] = (int32_t)(((bits >> 32) * (uint64_t)N_ACT[env]) >> 32);
+        } break;
+        case NSG_POL_BY_STATE: ai[i] = ((const int32_t*)pol->data)[b->cell[i]]; break;
+        default: { /* NSG_POL_LINEAR: float32, bias first, then the terms in order */
+          const float* W = (const float*)pol->data;
+          const float* o = b->obs + i * D;
+          if (fa) {
+            float sc = W[D];
+            for (int d = 0; d < D; d++) sc = sc + W[d] * o[d];
+            af[i] = sc < ACT_LO[env] ? ACT_LO[env] : sc > ACT_HI[env] ? ACT_HI[env] : sc;
+          } else {
+            int best = 0; float top = 0.f;
+            for (int j = 0; j < N_ACT[env]; j++) {
+              float sc = W[j * (D + 1) + D];
+              for (int d = 0; d < D; d++) sc = sc + W[j * (D + 1) + d] * o[d];
+              if (j == 0 || sc > top) { top = sc; best = j; }
+            }
+            ai[i] = best;
+          }
+        }
+      }
+      if (pol->actions_out) {
+        if (fa) ((float*)pol->actions_out)[(int64_t)k * N + i] = af[i]; else ((int32_t*)pol->actions_out)[(int64_t)k * N + i] = ai[i];
+      }
+      step_one(cfg, tables, b, N, i, ai, cnt);
+      if (reward64_out) reward64_out[(int64_t)k * N + i] = g_reward64;
+      if (took_out) took_out[(int64_t)k * N + i] = (uint8_t)g_took_step;
+      if (acc && g_took_step) {
+        const int alive = acc->alive ? acc->alive[i] != 0 : 1;
+        if (alive) {
+          const int len = acc->length ? acc->length[i] : 0;
+          const double g = (acc->discount && len < acc->n_discount) ? acc->discount[len] : 1.0;
+          if (acc->ret) acc->ret[i] = acc->ret[i] + g_reward64 * g; /* tot_reward += reward * gamma ** depth */
+          if (acc->length) acc->length[i] = len + 1;
+          if (acc->alive && (b->terminated[i] || b->truncated[i])) acc->alive[i] = 0;
+        }
+      }
+    }
+  }
+  free(ai);
   return 0;
 }
 
@@ -1011,9 +1099,26 @@ int orc_fork(const nsg_config* scfg, const nsg_buffers* sb, const nsg_config* dc
                       built from initial_prob_dist by its constructor;
          CliffWalking toy_text.py:219-221,246-249 + :187: the copy's own table IS the copied current one, so an
                       in_sim_change planning copy steps with the current table although θ reads initial */
-      int use_initial = env == NSG_ENV_FROZENLAKE ? (in_sim_change || theta_mode == 1) : (theta_mode == 1 && !in_sim_change);
-      for (int k = 0; k < nd; k++)
-        db->table_prob[k * N + i] = use_initial ? scfg->initial_prob[0][k] : sb->table_prob[k * N + i];
+      /* A copy OF A COPY (MCTS.search deep-copies the planning env it is given, MCTS.py:131) takes the source copy's OWN table
+         (`deepcopy(self.P)`, toy_text.py:508 / 246-249), not the one the source steps with (`unwrapped.P`):
+         FrozenLake   a copy's own table is the constructor's, built from initial_prob_dist: the second copy steps with THAT;
+         CliffWalking a copy's own table is the first source's current one, also after get_planning_env() without delta
+                      notification overwrote the base env's table with the initial one: the second copy steps with the CURRENT
+                      table again.  The own table of a frozen CliffWalking copy is kept in buffers.derived ([4][N]). */
+      const int src_sim = (scfg->flags & NSG_F_SIM_ENV) != 0;
+      if (env == NSG_ENV_FROZENLAKE) {
+        int use_initial = in_sim_change || theta_mode == 1 || src_sim;
+        for (int k = 0; k < nd; k++)
+          db->table_prob[k * N + i] = use_initial ? scfg->initial_prob[0][k] : sb->table_prob[k * N + i];
+      } else {
+        const int own_in_derived = src_sim && !in_sim_change && sb->derived;
+        const int use_initial = theta_mode == 1 && !in_sim_change;
+        for (int k = 0; k < nd; k++) {
+          const double own = own_in_derived ? sb->derived[k * N + i] : sb->table_prob[k * N + i];
+          if (db->derived) db->derived[k * N + i] = own;
+          db->table_prob[k * N + i] = use_initial ? scfg->initial_prob[0][k] : own;
+        }
+      }
     }
     for (int p = 0; p < P; p++) {
       if (db->cursor && sb->cursor) db->cursor[p * N + i] = sb->cursor[p * N + i]; /* deepcopy(tunable_params) */

@@ -71,7 +71,7 @@ class OracleVecEnv:
         z = lambda shape, dt: np.zeros(shape, dtype=dt)  # noqa: E731
         self.a = {
             "phys": z((max(PHYS_DIM[et], 1), N), np.float64), "cell": z(N, np.int32),
-            "theta": z((max(rows, 1), N), np.float64), "table_prob": z((4, N), np.float64), "derived": z((2, N), np.float64), "t": z(N, np.int32), "t_fork": z(N, np.int32), "status": z(N, np.uint8), "episode": z(N, np.int32),
+            "theta": z((max(rows, 1), N), np.float64), "table_prob": z((4, N), np.float64), "derived": z((4, N), np.float64), "t": z(N, np.int32), "t_fork": z(N, np.int32), "status": z(N, np.uint8), "episode": z(N, np.int32),
             "rng_env": z((N, 4), np.uint64), "rng_upd": z((max(P, 1), N, 4), np.uint64), "rng_sched": z((max(P, 1), N, 4), np.uint64),
             "sched_next": z((max(P, 1), N), np.int32),
             "cursor": z((max(P, 1), N), np.int32), "obs": z((N, OBS_DIM[et]), np.float32),
@@ -120,6 +120,31 @@ class OracleVecEnv:
         act = np.ascontiguousarray(actions, dtype=dt)
         lib().orc_step_mt(C.byref(self.cfg), _ptr(self.tab), C.byref(self.bufs), C.c_int64(self.N), _ptr(act), int(nthreads))
         return self.a
+
+    def rollout_policy(self, kind, k_steps, data=None, seed=0, index0=0, step0=0, accounts=None):
+        """The reference's closed loops restated (orc_rollout_policy): K steps of `action = policy(last observation); step; add`.
+        `kind`: A.NSG_POL_*; `data`: the action table / state table / weight rows (NumPy); `accounts`: dict of NumPy arrays
+        ret (float64), length (int32), alive (uint8), discount (float64 or None), updated in place.
+        Returns (actions[K, N], reward64[K, N], took[K, N])."""
+        K, N = int(k_steps), self.N
+        acts = np.zeros((K, N), dtype=np.float32 if self.action_is_float else np.int32)
+        r64 = np.zeros((K, N), dtype=np.float64)
+        took = np.zeros((K, N), dtype=np.uint8)
+        d = None
+        if data is not None:
+            d = np.ascontiguousarray(data)
+        n_data = 0 if d is None else (int(d.shape[0]) if kind == A.NSG_POL_LINEAR else int(d.size))
+        pol = A.Policy(kind=int(kind), step0=int(step0), seed=int(seed) & ((1 << 64) - 1), index0=int(index0), data=_ptr(d), n_data=n_data,
+                       reserved0=0, actions_out=_ptr(acts))
+        acc = None
+        if accounts is not None:
+            disc = accounts.get("discount")
+            acc = A.EpisodeAcc(ret=_ptr(accounts["ret"]), length=_ptr(accounts["length"]), alive=_ptr(accounts["alive"]),
+                               discount=_ptr(disc), n_discount=0 if disc is None else int(disc.size), reserved0=0)
+        rc = lib().orc_rollout_policy(C.byref(self.cfg), _ptr(self.tab), C.byref(self.bufs), C.c_int64(N), C.byref(pol), K,
+                                      C.byref(acc) if acc is not None else None, _ptr(r64), _ptr(took))
+        assert rc == 0
+        return acts, r64, took
 
     # convenience views -----------------------------------------------------------------
     def state(self):

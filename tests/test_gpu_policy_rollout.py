@@ -238,3 +238,23 @@ def test_policy_argument_errors():
     with pytest.raises(NsgError, match="weight rows"):
         cp.rollout_policy(LinearPolicy(np.zeros((3, 5), dtype=np.float32)), 4)
     cp.close(); fl.close()
+
+
+# ---- the reference's own loops (tests/golden/policy_*.npz; the oracle is pinned to the same files by tests/test_oracle_policy_rollouts.py) ----
+from tests.policy_cases import EPISODE_CASES, MCTS_CASES, HipSide, run_episode_case, run_mcts_case  # noqa: E402
+
+
+@pytest.mark.parametrize("specialize", [False, True])
+@pytest.mark.parametrize("name", sorted(MCTS_CASES))
+def test_default_policy_matches_reference_mcts(name, specialize):
+    """`MCTS._default_policy` (MCTS.py:162-181) on copies made the way `MCTS.search` makes them: the reference's `tot_reward` and
+    step count, bit for bit, from ONE nsg_rollout_policy launch per fixture."""
+    run_mcts_case(HipSide, name, specialize=specialize)
+
+
+@pytest.mark.parametrize("specialize", [False, True])
+@pytest.mark.parametrize("name", sorted(EPISODE_CASES))
+def test_closed_loop_matches_reference_run_episode(name, specialize):
+    """`run_episode` (run_experiment.py:91-148) with a linear agent: total reward, number of steps and every action of every
+    episode, from ONE launch."""
+    run_episode_case(HipSide, name, specialize=specialize)

@@ -1,0 +1,53 @@
+"""Pins the oracle's closed loops (oracle/nsgym_oracle.c: orc_rollout_policy) against what the REFERENCE's own loop code returned
+(tests/golden/policy_*.npz from tests/golden/make_policy_rollouts.py): `MCTS._default_policy` (MCTS.py:162-181) on planning copies
+made the way `MCTS.search` makes them, and `run_episode` (run_experiment.py:91-148) with a linear agent.  The GPU tests
+(tests/test_gpu_policy_rollout.py) run the same cases through nsg_rollout_policy."""
+import numpy as np
+import pytest
+
+from tests.policy_cases import EPISODE_CASES, MCTS_CASES, OracleSide, run_episode_case, run_mcts_case
+
+
+@pytest.mark.parametrize("name", sorted(MCTS_CASES))
+def test_oracle_default_policy_matches_reference_mcts(name):
+    run_mcts_case(OracleSide, name)
+
+
+@pytest.mark.parametrize("name", sorted(EPISODE_CASES))
+def test_oracle_closed_loop_matches_reference_run_episode(name):
+    run_episode_case(OracleSide, name)
+
+
+def test_oracle_policy_bits_are_the_python_restatement():
+    """Three statements of the uniform action source agree: the oracle's C, the package's NumPy (`policies.policy_bits`) and plain
+    Python integers."""
+    import ctypes as C
+
+    from ns_gym_amd.policies import policy_bits
+    from oracle.oracle import lib
+
+    f = lib().orc_policy_bits
+    f.restype, f.argtypes = C.c_uint64, [C.c_uint64] * 3
+    M = (1 << 64) - 1
+
+    def mix(x):
+        x ^= x >> 30; x = (x * 0xBF58476D1CE4E5B9) & M
+        x ^= x >> 27; x = (x * 0x94D049BB133111EB) & M
+        return x ^ (x >> 31)
+
+    rng = np.random.default_rng(0)
+    for seed, env, step in [(0, 0, 0), (1, 2, 3), (M, 1 << 40, (1 << 31) - 1)] + [tuple(int(v) for v in rng.integers(0, 1 << 62, 3)) for _ in range(50)]:
+        want = mix((mix((seed + 0x9E3779B97F4A7C15 * (env + 1)) & M) + 0xD1B54A32D192ED03 * (step + 1)) & M)
+        assert f(seed, env, step) == want == int(policy_bits(seed, env, step))
+
+
+def test_uniform_policy_table_is_uniform():
+    """The action tables `UniformRandom.table` lays out: all actions about equally often, no correlation between neighbouring envs or steps."""
+    from ns_gym_amd.policies import policy_bits
+
+    bits = policy_bits(7, np.arange(4096, dtype=np.uint64)[None, :], np.arange(64, dtype=np.uint64)[:, None])
+    a = ((bits >> np.uint64(32)) * np.uint64(3)) >> np.uint64(32)
+    freq = np.bincount(a.reshape(-1).astype(np.int64), minlength=3) / a.size
+    assert np.all(np.abs(freq - 1 / 3) < 0.01)
+    assert abs(np.corrcoef(a[:, :-1].reshape(-1), a[:, 1:].reshape(-1))[0, 1]) < 0.01
+    assert abs(np.corrcoef(a[:-1].reshape(-1), a[1:].reshape(-1))[0, 1]) < 0.01
