@@ -12,7 +12,7 @@ __version__ = "0.1.0"
 
 _LAZY = {"VecNSEnv": "vec_env", "NSClassicControlWrapper": "wrappers", "NSFrozenLakeWrapper": "wrappers", "NSCliffWalkingWrapper": "wrappers", "NSBridgeWrapper": "wrappers",
          "ConstraintViolationWarning": "wrappers", "functional": None, "vec_env": None, "wrappers": None,
-         "distributed": None, "utils": None, "evaluate": None}
+         "distributed": None, "utils": None, "evaluate": None, "policies": None, "planning": None}
 
 
 def __getattr__(name):

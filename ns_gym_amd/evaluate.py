@@ -6,17 +6,19 @@ then `while not done and not truncated: act, step, append reward, num_steps += 1
 (run_experiment.py:108-129), and streams rows `[total_reward, SARNS, num_steps, seed, sample_id, time]` to a CSV (:133-141,
 206-217).  Here:
 
-  * open-loop action sources - the default uniform-random policy (the rollout policy of MCTS.py:162-181 and of BASELINE's
-    "random-action rollouts") or a caller-supplied `actions[T, N]` table - run through `nsg_rollout`: K wrapper steps per
-    launch with the env state in registers, the per-step outputs landing in `[K, N]` slices;
-  * the alive mask ("this env's episode has not ended yet"), the per-env reward sum and step count are computed ON THE DEVICE
-    from those slices (a cumulative sum over the K done flags): a finished env keeps stepping through the kernel's next-step
-    autoreset and is simply masked out, exactly like an env whose `while` loop has exited;
+  * every action source that looks at nothing but its own env runs INSIDE the stepping kernel (`nsg_rollout_policy`): the default
+    uniform-random policy (the rollout policy of MCTS.py:162-181 and of BASELINE's "random-action rollouts"; in-kernel counter-based
+    draws), a caller-supplied `actions[T, N]` table, and the policy descriptors of `ns_gym_amd.policies` - `TabularPolicy`
+    (tutorial.ipynb cell 12: `action = policy[observation]`), `LinearPolicy` - which are CLOSED loops: K wrapper steps per launch
+    with the env state, the decision and the episode accounts in registers;
+  * the accounts - "this env's episode has not ended yet", the float64 reward sum (`total_reward += reward` on the base MDP's own
+    float64 reward, like the reference's Python float), the step count - are kept by that kernel per env; a finished env keeps
+    stepping through the next-step autoreset and is simply not counted, exactly like an env whose `while` loop has exited;
   * there is NO host synchronisation per step: whether every episode has ended is read back once per K-step chunk, one chunk
     late (the flag is copied to pinned memory asynchronously and looked at after the NEXT chunk has been enqueued), so the
     host never stalls the device;
-  * a closed-loop `policy(state) -> actions` (it needs the observation of step k to choose action k) cannot be fused into a
-    K-step launch; it runs through `step()` with the same device-side masking and the same lagged, chunked end test.
+  * an arbitrary Python callable `policy(state) -> actions` cannot be fused; it runs through `step()` with the same device-side
+    masking and the same lagged, chunked end test.
 
 Rows come out in the reference's column order with the reference's header.
 """
@@ -29,6 +31,7 @@ from typing import Callable, Optional
 import numpy as np
 import torch
 
+from . import _abi as A
 from .utils import type_mismatch_checker  # noqa: F401  (run_experiment.py imports it next to the harness)
 
 CSV_HEADER = ["total_reward", "State-Action-Reward-NextState", "num_steps", "seed", "sample_id", "time"]
@@ -86,55 +89,62 @@ def run_episodes(env, policy: Optional[Callable] = None, seed: int = 0, max_step
     """One episode per env of `env` (a VecNSEnv).
 
     `actions`: open-loop action table `[T, N]` (device tensor; step k of every env takes `actions[k]`), or
-    `policy`: `policy(state_tensor) -> action tensor [N]` (closed loop), or neither: uniform random actions.
+    `policy`: a `ns_gym_amd.policies.Policy` (fused closed loop) or any callable `policy(state_tensor) -> action tensor [N]`
+    (closed loop through `step()`), or neither: uniform random actions (`policies.UniformRandom(seed)`).
     Returns rows `[total_reward, SARNS, num_steps, seed, sample_id, time]` (run_experiment.py:133-141); SARNS is a list of
     (state, action, reward, next_state) tuples per env when `record_sarns`, else [].
     `as_arrays=True`: the same columns as NumPy arrays in a dict (`total_reward`, `num_steps`, `seed`, `sample_id`, `time`) -
     building a million Python rows costs ~1 s of host time where the episodes themselves cost milliseconds of device time."""
+    from .policies import EpisodeAccounts, Policy, UniformRandom
+
     n, dev = env.num_envs, env.device
     limit = max_steps if max_steps is not None else (env.cfg.max_episode_steps or 10_000)
     total_steps = limit + 1                      # the reference breaks at num_steps == max_steps + 1 (run_experiment.py:127-129)
-    source = None                                # open-loop: k -> actions[k, N]
+    fused = None                                 # the in-kernel action source
     if actions is not None:
         assert policy is None, "give either `actions` or `policy`"
-        table = actions.to(dev)
+        table = actions.to(device=dev, dtype=torch.float32 if env.action_is_float else torch.int32)
         assert table.dim() == 2 and table.shape[1] == n and table.shape[0] >= 1
         total_steps = min(total_steps, int(table.shape[0]))
+        fused = _TableSource(table.contiguous())
     elif policy is None:
-        source = _random_actions(env)
-    elif getattr(policy, "_nsg_open_loop", None) is not None:
-        source = policy._nsg_open_loop
+        fused = UniformRandom(seed=int(seed) if np.isscalar(seed) else 0)
+    elif isinstance(policy, Policy):
+        fused = policy
+    elif getattr(policy, "_nsg_open_loop", None) is not None:      # `random_policy(env)`: the same draws, fused
+        fused = UniformRandom(seed=int(seed) if np.isscalar(seed) else 0)
     obs, _ = env.reset(seed=seed)
-    alive = torch.ones(n, dtype=torch.bool, device=dev)
-    total = torch.zeros(n, dtype=torch.float64, device=dev)
-    steps = torch.zeros(n, dtype=torch.int64, device=dev)
     flag = _LaggedFlag(dev)
-    traj = []                                    # record_sarns: (state[K,N,..], action[K,N], reward[K,N], next_state[K,N,..], alive[K,N])
+    traj = []                                    # record_sarns: (state[K,N,..], action[K,N], reward[K,N], next_state[K,N,..], live[K,N])
     t0 = time.time()
     done_steps = 0
-    if actions is not None or source is not None:
-        # ---- open loop: K fused steps per launch (nsg_rollout), masks and sums from the [K, N] slices --------------------
+    if fused is not None:
+        # ---- fused: K steps per launch (nsg_rollout_policy); decision, alive flag, reward sum and step count stay in registers ----
+        acc = EpisodeAccounts(env, gamma=None)
         state = obs["state"].clone() if record_sarns else None
         while done_steps < total_steps:
             k = min(int(chunk), total_steps - done_steps)
-            a = table[done_steps:done_steps + k] if actions is not None else source(k)
-            out = env.rollout(a, record=("obs", "reward", "terminated", "truncated") if record_sarns else ("reward", "terminated", "truncated"))
-            done = out["terminated"] | out["truncated"]                                   # [k, N]
-            ended_before = torch.cumsum(done.to(torch.int32), dim=0) - done.to(torch.int32)  # episodes ended strictly before step j
-            live = alive.unsqueeze(0) & (ended_before == 0)                                 # step j still belongs to the episode
-            total += (out["reward"].to(torch.float64) * live).sum(dim=0)
-            steps += live.sum(dim=0)
+            if isinstance(fused, _TableSource):
+                fused.at(done_steps, k)
+            before = acc.length.clone() if record_sarns else None
+            out = env.rollout_policy(fused, k, record=("obs", "reward") if record_sarns else (), accounts=acc, step0=done_steps,
+                                     record_actions=record_sarns)
             if record_sarns:
                 prev = torch.cat([state.unsqueeze(0), out["obs"][:-1]], dim=0)
-                traj.append((prev.cpu().numpy(), a.cpu().numpy(), out["reward"].cpu().numpy(), out["obs"].cpu().numpy(), live.cpu().numpy()))
+                taken = (acc.length - before).to(torch.int64)                                     # live steps of this chunk, per env
+                live = torch.arange(k, device=dev).unsqueeze(1) < taken.unsqueeze(0)              # [k, N]: they are its first ones
+                traj.append((prev.cpu().numpy(), out["actions"].cpu().numpy(), out["reward"].cpu().numpy(), out["obs"].cpu().numpy(), live.cpu().numpy()))
                 state = out["obs"][-1].clone()
-            alive = alive & ~done.any(dim=0)
             done_steps += k
-            flag.push(alive.any())
+            flag.push(acc.alive.any())
             if flag.previous_says_all_done():
                 break
+        total, steps = acc.ret.cpu().numpy(), acc.length.cpu().numpy().astype(np.int64)      # the one synchronisation the results need
     else:
-        # ---- closed loop: the policy needs step k's observation; step() per step, same device-side masking, lagged end test ----
+        # ---- a Python callable: the policy needs step k's observation on the host side of the launch; step() per step, device-side masking ----
+        alive = torch.ones(n, dtype=torch.bool, device=dev)
+        total_t = torch.zeros(n, dtype=torch.float64, device=dev)
+        steps_t = torch.zeros(n, dtype=torch.int64, device=dev)
         state = obs["state"].clone()
         while done_steps < total_steps:
             k = min(int(chunk), total_steps - done_steps)
@@ -142,8 +152,8 @@ def run_episodes(env, policy: Optional[Callable] = None, seed: int = 0, max_step
                 a = policy(state)
                 obs, r, term, trunc, _info = env.step(a)
                 nxt = obs["state"]
-                total += torch.where(alive, r.to(torch.float64), torch.zeros_like(total))
-                steps += alive.to(torch.int64)
+                total_t += torch.where(alive, r.to(torch.float64), torch.zeros_like(total_t))
+                steps_t += alive.to(torch.int64)
                 if record_sarns:
                     traj.append((state.cpu().numpy()[None], torch.as_tensor(a).cpu().numpy()[None], r.cpu().numpy()[None].copy(),
                                  nxt.cpu().numpy()[None].copy(), alive.cpu().numpy()[None].copy()))
@@ -153,7 +163,7 @@ def run_episodes(env, policy: Optional[Callable] = None, seed: int = 0, max_step
             flag.push(alive.any())
             if flag.previous_says_all_done():
                 break
-    total, steps = total.cpu().numpy(), steps.cpu().numpy()      # the one synchronisation the results need
+        total, steps = total_t.cpu().numpy(), steps_t.cpu().numpy()
     wall = time.time() - t0
     if env.may_raise:
         env.check_errors()
@@ -173,6 +183,21 @@ def run_episodes(env, policy: Optional[Callable] = None, seed: int = 0, max_step
                         sarns.append((np.asarray(s[j, i]).tolist(), np.asarray(a[j, i]).tolist(), float(r[j, i]), np.asarray(s2[j, i]).tolist()))
         rows.append([float(total[i]), sarns, int(steps[i]), int(seeds[i]), ids[i], wall])
     return rows
+
+
+class _TableSource:
+    """A caller's `actions[T, N]` table as the action source of fused chunks (NSG_POL_TABLE over a window of it)."""
+    kind = A.NSG_POL_TABLE
+
+    def __init__(self, table: torch.Tensor):
+        self.table, self.k0 = table, 0
+
+    def at(self, k0: int, k: int) -> None:
+        self.k0 = int(k0)
+
+    def _struct(self, env, step0, actions_out):
+        return A.Policy(kind=self.kind, step0=0, seed=0, index0=0, data=self.table[self.k0:].data_ptr(), n_data=0, reserved0=0,
+                        actions_out=actions_out.data_ptr() if actions_out is not None else None)
 
 
 def write_results_csv(path: str, rows: list) -> None:

@@ -258,3 +258,91 @@ def test_closed_loop_matches_reference_run_episode(name, specialize):
     """`run_episode` (run_experiment.py:91-148) with a linear agent: total reward, number of steps and every action of every
     episode, from ONE launch."""
     run_episode_case(HipSide, name, specialize=specialize)
+
+
+# ---- the harness and the planner-side helper on top of the fused rollouts ----------------------------------------------------
+def test_run_episodes_with_fused_policies_equals_the_step_loop():
+    """`run_episodes` with a policy descriptor (one launch per K-step chunk) returns the rows of the same policy driven through
+    `step()` as a Python callable - totals, step counts and SARNS records."""
+    import torch
+
+    from ns_gym_amd.evaluate import run_episodes
+    from ns_gym_amd.policies import TabularPolicy
+
+    spec = _spec_of("frozenlake_decrement")
+    n = 600
+    rng = np.random.default_rng(3)
+    env = make_env_from_spec(_vec, spec, n=n)
+    pol = TabularPolicy(rng.integers(0, 4, size=env.cfg.nrow * env.cfg.ncol))
+    fused = run_episodes(env, pol, seed=21, record_sarns=True, chunk=16)
+    loop = run_episodes(env, lambda state: pol(state).to(torch.int32), seed=21, record_sarns=True, chunk=16)
+    assert [r[0] for r in fused] == [r[0] for r in loop] and [r[2] for r in fused] == [r[2] for r in loop]
+    for i in (0, 5, n - 1):
+        assert fused[i][1] == loop[i][1] and len(fused[i][1]) == fused[i][2]
+    env.close()
+
+
+def test_default_policy_of_run_episodes_is_the_in_kernel_uniform_source():
+    from ns_gym_amd.evaluate import run_episodes
+    from ns_gym_amd.policies import UniformRandom
+
+    spec = TRAJ_SPECS["c1_cartpole_masspole_inc"]
+    env = make_env_from_spec(_vec, spec, n=2048)
+    a = run_episodes(env, seed=5, as_arrays=True, chunk=32)
+    import torch
+    table = UniformRandom(seed=5).actions(env, 0, 501)
+    b = run_episodes(env, seed=5, actions=table, as_arrays=True, chunk=50)
+    assert a["num_steps"].tolist() == b["num_steps"].tolist() and a["total_reward"].tolist() == b["total_reward"].tolist()
+    assert (a["total_reward"] == a["num_steps"]).all() and a["num_steps"].max() < 200
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["c1_cartpole_masspole_inc", "frozenlake_decrement"])
+def test_simulator_equals_the_loops_it_replaces(name):
+    """planning.Simulator (fork into a standing batch + one fused rollout) against the same simulations made one by one the way
+    MCTS.search makes them: deepcopy, the chance node's step, then the default policy's loop through step()."""
+    import torch
+
+    from ns_gym_amd.planning import Simulator
+    from ns_gym_amd.policies import UniformRandom
+
+    spec = _spec_of(name)
+    R, S, d, gamma = 96, 5, 25, 0.95
+    env = make_env_from_spec(_vec, {**spec, "flags": {**spec["flags"], "change_notification": True, "delta_change_notification": True}}, n=R)
+    env.reset(seed=11)
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        env.step(torch.from_numpy(rng.integers(0, env.n_actions, size=R).astype(np.int32)).cuda())
+    plan = env.get_planning_env()
+    sim = Simulator(plan, sims=S, depth=d, gamma=gamma)
+    first = torch.from_numpy(rng.integers(0, env.n_actions, size=(S, R)).astype(np.int32)).cuda()
+    out = sim.run(seed=77, first_actions=first, entropy=555)
+    pol = UniformRandom(seed=77)
+    # the same, one simulation at a time - with the env streams of both sides set to the same seeds, so that the slip outcomes agree
+    sim.src.fork(theta_mode=0, into=sim.copies, entropy=555)
+    sim.copies.seed_streams(np.arange(S * R, dtype=np.uint64) + np.uint64(1000), which="env")
+    _, r0, te0, tr0, _ = sim.copies.step(first.reshape(-1))
+    r0 = r0.clone()                                  # (step() hands out views of the handle's own rows: the rollout below rewrites them)
+    alive0 = ~(te0 | tr0)
+    sim.acc.restart(alive=alive0)
+    sim.copies.rollout_policy(UniformRandom(seed=77), d, accounts=sim.acc)
+    ret = sim.acc.ret.view(S, R).cpu().numpy()
+    length = sim.acc.length.view(S, R).cpu().numpy()
+    table = pol.table(sim.copies, 0, d).reshape(d, S, R)
+    for s in range(S):
+        c = plan.fork(theta_mode=0, entropy=555)
+        c.seed_streams(np.arange(R, dtype=np.uint64) + np.uint64(1000 + s * R), which="env")
+        _, r, te, tr, _ = c.step(first[s])
+        assert torch.equal(r, r0.view(S, R)[s])
+        tot = np.zeros(R); depth = np.zeros(R, dtype=np.int64); live = ~(te | tr).cpu().numpy()
+        for k in range(d):
+            _, r, te, tr, _ = c.step(torch.from_numpy(table[k, s]).cuda())
+            rr = r.cpu().numpy().astype(np.float64)
+            tot = np.where(live, tot + rr * gamma ** depth, tot)
+            depth = depth + live
+            live = live & ~(te | tr).cpu().numpy()
+        np.testing.assert_array_equal(length[s], depth)
+        np.testing.assert_allclose(ret[s], tot, rtol=1e-12, atol=1e-12)
+        c.close()
+    assert out["ret"].shape == (S, R) and out["first_reward"].shape == (S, R)
+    sim.close(); plan.close(); env.close()
