@@ -610,6 +610,8 @@ int nsg_spec_origin(const nsg_handle* h);
  * the ordered member list (cfgs[k], ns[k]). */
 int nsg_spec_prebuild(const nsg_config* cfg, int64_t n, const char* arch, const char* dir);
 int nsg_spec_prebuild_group(const nsg_config* const* cfgs, const int64_t* ns, int32_t count, const char* arch, const char* dir);
+/* ... and the fused policy rollout's unit (nsg_rollout_policy of a specialised handle of (cfg, n)) */
+int nsg_spec_prebuild_policy(const nsg_config* cfg, int64_t n, const char* arch, const char* dir);
 int nsg_spec_build(const nsg_config* cfg, const char* arch, void** code_out, size_t* size_out);
 /* the same for the unit nsg_step_group uses when every member is specialised: one kernel (nsg_spec_group) for the ordered tuple
  * of the members' configs */

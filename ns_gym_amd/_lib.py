@@ -17,7 +17,7 @@ EXPORTS = [
     "nsg_fork", "nsg_seed_streams", "nsg_resident_start", "nsg_resident_publish", "nsg_resident_demo_policy",
     "nsg_table_prob_dirty", "nsg_compact_done", "nsg_theta_trace", "nsg_theta_trace_stateful", "nsg_rng_fill", "nsg_time_steps", "nsg_calib_copy_f64", "nsg_read_back", "nsg_destroy",
     "nsg_specialize", "nsg_is_specialized", "nsg_spec_origin", "nsg_spec_prebuild", "nsg_spec_prebuild_group", "nsg_spec_build", "nsg_spec_build_group", "nsg_spec_build_resident",
-    "nsg_rollout_policy", "nsg_rollout_policy_kind", "nsg_spec_build_policy", "nsg_policy_bits",
+    "nsg_rollout_policy", "nsg_rollout_policy_kind", "nsg_spec_build_policy", "nsg_spec_prebuild_policy", "nsg_policy_bits",
     "nsg_spec_free",
 ]
 
@@ -102,6 +102,7 @@ def load():
     lib.nsg_spec_origin.argtypes = [C.c_void_p]
     lib.nsg_spec_prebuild.argtypes = [C.c_void_p, i64, C.c_char_p, C.c_char_p]
     lib.nsg_spec_prebuild_group.argtypes = [C.POINTER(C.c_void_p), C.POINTER(i64), i32, C.c_char_p, C.c_char_p]
+    lib.nsg_spec_prebuild_policy.argtypes = [C.c_void_p, i64, C.c_char_p, C.c_char_p]
     if lib.nsg_abi_version() != A.NSG_ABI_VERSION:
         raise NsgError("libnsgym_hip.so ABI version mismatch")
     if (lib.nsg_sizeof_config() != C.sizeof(A.Config) or lib.nsg_sizeof_buffers() != C.sizeof(A.Buffers)

@@ -1498,6 +1498,18 @@ int nsg_spec_prebuild(const nsg_config* cfg, int64_t n, const char* arch, const 
   return write_unit(dir, spec_key(*cfg, pol, arch), code);
 }
 
+int nsg_spec_prebuild_policy(const nsg_config* cfg, int64_t n, const char* arch, const char* dir) {
+  if (!arch || !*arch || !dir || !*dir) return fail(NSG_EINVAL, "arch and dir are required");
+  if (n <= 0 || n > NSG_MAX_ENVS) return fail(NSG_EINVAL, "n must be in [1, 2^27]");
+  int rc = validate(cfg, (size_t)kMaxTableBytes);
+  if (rc) return rc;
+  const SpecPolicy pol = spec_policy(*cfg, n);
+  std::string err;
+  const std::vector<char> code = nsg_spec::policy_compile(*cfg, pol.full, arch, err, pol.inlane, pol.stream_state);
+  if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
+  return write_unit(dir, nsg_spec::fnv1a("policy", 6, spec_key(*cfg, pol, arch)), code);   // the key nsg_rollout_policy looks up
+}
+
 int nsg_spec_prebuild_group(const nsg_config* const* cfgs, const int64_t* ns, int32_t count, const char* arch, const char* dir) {
   if (!cfgs || !ns || count <= 0 || count > NSG_MAX_SEGMENTS || !arch || !*arch || !dir || !*dir) return fail(NSG_EINVAL, "bad arguments");
   bool full[NSG_MAX_SEGMENTS];

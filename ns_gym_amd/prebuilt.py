@@ -37,6 +37,14 @@ SINGLES = [
     ("C4 member Pendulum without episode accounting", "pend", 1 << 18, False),
     ("C4 member Acrobot without episode accounting", "acro", 1 << 18, False),
 ]
+# the fused policy rollouts (nsg_rollout_policy) of the same configurations: closed loops and planner simulations at the BASELINE sizes
+POLICIES = [
+    ("C1 fused policy rollout, 2^20 envs", "c1", 1 << 20, True),
+    ("C2 fused policy rollout, 65 536 envs (closed loop at BASELINE's size)", "c2", 1 << 16, True),
+    ("C3 fused policy rollout, 2^20 envs", "c3", 1 << 20, True),
+    ("C4 member Pendulum, fused policy rollout", "pend", 1 << 18, True),
+    ("C4 member Acrobot, fused policy rollout", "acro", 1 << 18, True),
+]
 GROUPS = [
     ("C4 Pendulum + Acrobot in one launch (nsg_step_group / nsg_rollout_group)", [("pend", 1 << 18), ("acro", 1 << 18)], True),
     ("C4 without episode accounting", [("pend", 1 << 18), ("acro", 1 << 18)], False),
@@ -95,6 +103,13 @@ def build_all(directory: str = DIR, arch: str = ARCH, verbose: bool = False) -> 
         new = set(os.listdir(directory)) - before
         if not new:      # the same key as an earlier entry (the batch size did not change the policy)
             continue
+        inspect(newest(before), tag)
+        if verbose:
+            print("prebuilt", tag, file=sys.stderr)
+    for tag, name, n, track in POLICIES:
+        cfg = _config(name, track)
+        before = set(os.listdir(directory))
+        _lib.check(lib.nsg_spec_prebuild_policy(C.byref(cfg), n, arch.encode(), directory.encode()), f"nsg_spec_prebuild_policy({name}, {n})")
         inspect(newest(before), tag)
         if verbose:
             print("prebuilt", tag, file=sys.stderr)

@@ -63,6 +63,13 @@ p, a = W.build("pend", specialize=True), W.build("acro", specialize=True)
 step_group([p, a], [W.random_actions(p), W.random_actions(a)])
 assert step_group_kind([p, a]) == "specialised (prebuilt)", step_group_kind([p, a])
 rollout_group([p, a], [torch.stack([W.random_actions(e) for _ in range(4)]) for e in (p, a)])
+# the fused policy rollouts of the BASELINE configurations come from the prebuilt directory as well
+from ns_gym_amd.policies import EpisodeAccounts, UniformRandom
+for name in ("c1", "c2", "c3", "pend", "acro"):
+    e = W.build(name, specialize=True)
+    e.rollout_policy(UniformRandom(seed=1), 8, accounts=EpisodeAccounts(e, gamma=0.9))
+    assert e.policy_kernels == "config-specialised", (name, e.policy_kernels)
+    e.close()
 with warnings.catch_warnings(record=True) as w:
     warnings.simplefilter("always")
     other = VecNSEnv(make("CartPole-v1"), {"force_mag": IncrementUpdate(PeriodicScheduler(7), k=0.3)}, 1 << 16)

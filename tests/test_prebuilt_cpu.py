@@ -19,12 +19,12 @@ def units(tmp_path_factory):
 def test_every_listed_unit_is_built_and_clean(units):
     d, manifest = units
     files = sorted(f for f in os.listdir(d) if f.endswith(".hsaco"))
-    assert files == sorted(manifest) and len(files) == len(prebuilt.SINGLES) + len(prebuilt.GROUPS)
+    assert files == sorted(manifest) and len(files) == len(prebuilt.SINGLES) + len(prebuilt.GROUPS) + len(prebuilt.POLICIES)
     kernels = 0
     for f, m in manifest.items():
         assert m["arch"] == "gfx950:sramecc+:xnack-"
         names = set(m["kernels"])
-        assert names in ({"nsg_spec_step", "nsg_spec_rollout"}, {"nsg_spec_group", "nsg_spec_group_rollout"}), names
+        assert names in ({"nsg_spec_step", "nsg_spec_rollout"}, {"nsg_spec_group", "nsg_spec_group_rollout"}, {"nsg_spec_rollout_policy"}), names
         for r in m["kernels"].values():      # the rule of nsg_specialize, asserted on what ships
             assert r["vgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0
             kernels += 1
