@@ -100,6 +100,10 @@ def baseline_configs_at_own_size(dev, c1_step_us, c1_rollout_rate, n_c1):
         rows[tag] = {"envs": env.N, "kernels": env.kernels, "step_us": us, "bytes_per_env_step": w["bytes_per_env_step"],
                      "frac_of_hbm_peak": frac(w["bytes_per_env_step"], env.N, us), "env_steps_per_sec": env.N / (us * 1e-6),
                      "rollout_k64_us_per_step": ru, "rollout_k64_env_steps_per_sec": env.N / (ru * 1e-6)}
+        try:   # the same batch as a CLOSED loop whose policy is evaluated inside the kernel (nsg_rollout_policy, K = 64 per launch)
+            rows[tag].update(_fused_closed_loop_us(env, name))
+        except Exception as e:
+            rows[tag]["fused_closed_loop_error"] = f"{type(e).__name__}: {e}"[:200]
         if env.N <= 1 << 16:
             rows[tag]["regime"] = "one wavefront per SIMD: bound by launch latency + the step's serial chain, not by memory"
             try:   # the same batch as a CLOSED loop without a launch per step (nsg_resident_start + the resident demo policy)
@@ -146,6 +150,33 @@ def baseline_configs_at_own_size(dev, c1_step_us, c1_rollout_rate, n_c1):
                   "bound": "the Acrobot member's float64 vector-ALU issue (RK4: 15 sincos + 12 divisions per step), not HBM"}
     pend.close(); acro.close()
     return rows
+
+
+def _fused_closed_loop_us(env, name, K=64, reps=8):
+    """us per step of a closed loop that never leaves the kernel: a linear policy on the observation (classic control) or a table over
+    the cells (grid envs) decides inside nsg_rollout_policy, the episode accounts stay in registers; K steps per launch."""
+    import numpy as np
+    import torch
+
+    from ns_gym_amd.policies import EpisodeAccounts, LinearPolicy, TabularPolicy
+
+    if env.is_grid:
+        pol, what = TabularPolicy(np.random.default_rng(0).integers(0, env.n_actions, size=env.cfg.nrow * env.cfg.ncol)), "a table over the cells"
+    else:
+        pol, what = LinearPolicy(np.array([[0.3, -0.8, -2.0, -1.1, 0.05], [-0.3, 0.8, 2.0, 1.1, -0.05]], dtype=np.float32)), "a linear policy on the observation"
+    acc = EpisodeAccounts(env, gamma=None)
+    for _ in range(3):
+        env.rollout_policy(pol, K, accounts=acc)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        env.rollout_policy(pol, K, accounts=acc)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * K)
+    return {"fused_closed_loop_us_per_step": us, "fused_closed_loop_env_steps_per_sec": env.N / (us * 1e-6),
+            "fused_closed_loop_policy": f"{what}, evaluated in the kernel ({env.policy_kernels} unit); {K} steps per launch"}
 
 
 def _resident_loop_us(env, a, K=4000):
