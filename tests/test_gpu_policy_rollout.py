@@ -346,3 +346,31 @@ def test_simulator_equals_the_loops_it_replaces(name):
         c.close()
     assert out["ret"].shape == (S, R) and out["first_reward"].shape == (S, R)
     sim.close(); plan.close(); env.close()
+
+
+def test_sharded_policy_rollouts_equal_the_unsharded_job():
+    """Seeds and in-kernel action draws are functions of the GLOBAL env index (`reset(seed=base + i)`, `UniformRandom(index0=...)`):
+    a job cut into shards - one handle per GPU in the multi-GPU layout (ns_gym_amd/distributed.py) - walks the same trajectories and
+    keeps the same accounts as the unsharded batch."""
+    import torch
+
+    from ns_gym_amd.policies import EpisodeAccounts, UniformRandom
+
+    spec = TRAJ_SPECS["c2_cartpole_gravity_rw"]
+    n, K, base = 6144, 80, 40
+    full = make_env_from_spec(_vec, spec, n=n)
+    full.reset(seed=base)
+    acc = EpisodeAccounts(full, gamma=0.99, horizon=K + 1)
+    ref = full.rollout_policy(UniformRandom(seed=3), K, record=("obs", "reward", "terminated"), accounts=acc)
+    cuts = [0, 1024, 4096, n]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        part = make_env_from_spec(_vec, spec, n=hi - lo)
+        part.reset(seed=np.arange(lo, hi, dtype=np.uint64) + np.uint64(base))
+        pacc = EpisodeAccounts(part, gamma=0.99, horizon=K + 1)
+        out = part.rollout_policy(UniformRandom(seed=3, index0=lo), K, record=("obs", "reward", "terminated"), accounts=pacc)
+        for k in out:
+            assert torch.equal(out[k], ref[k][:, lo:hi]), (k, lo)
+        assert torch.equal(pacc.ret, acc.ret[lo:hi]) and torch.equal(pacc.length, acc.length[lo:hi])
+        assert torch.equal(part.theta, full.theta[:, lo:hi])
+        part.close()
+    full.close()

@@ -45,9 +45,11 @@ def rand_actions(e, k):
     return torch.randint(0, e.n_actions, (k, e.num_envs), dtype=torch.int32, device="cuda")
 
 
-def kernel_level(res):
+def kernel_level(res, only=None):
     K = 64
     for name, n in (("c1", 1 << 20), ("c2", 1 << 16), ("c3", 1 << 20), ("pend", 1 << 18), ("acro", 1 << 18)):
+        if only and name not in only:
+            continue
         e = W.build(name, n, specialize=True)
         e.reset(seed=0)
         acts = rand_actions(e, K)
@@ -165,10 +167,11 @@ def planner(res):
 def main():
     res = {"kernel_level": {}, "closed_loop": {}, "planner": {},
            "what": "K = 64 fused steps per launch; times are HIP-event device times, best of 3-5; policy units: config-specialised (hiprtc on first use)"}
-    which = sys.argv[1:] or ["kernel", "closed", "planner"]
+    which = sys.argv[1:] or ["kernel", "closed", "planner"]      # "kernel:c1,acro" restricts the kernel-level part (counter passes)
     t0 = time.time()
-    if "kernel" in which:
-        kernel_level(res)
+    for w in which:
+        if w.startswith("kernel"):
+            kernel_level(res, only=w.split(":")[1].split(",") if ":" in w else None)
     if "closed" in which:
         closed_loops(res)
     if "planner" in which:
