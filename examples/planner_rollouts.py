@@ -22,6 +22,8 @@ env = nsg.VecNSEnv(nsg.make("CartPole-v1"), {"masspole": IncrementUpdate(Continu
 env.reset(seed=0)
 sim = Simulator(env, sims=A * S, depth=K, gamma=GAMMA)                                    # copy j <- root j mod R, each with its own streams
 first = torch.arange(A, dtype=torch.int32, device="cuda").repeat_interleave(S)[:, None].expand(A * S, R).contiguous()   # simulation block a tries action a
+sim.run(seed=0, first_actions=first)                                                       # (untimed: the copies' specialised unit is compiled on first use)
+torch.cuda.synchronize()
 t0, steps = time.perf_counter(), 0
 for decision in range(100):
     out = sim.run(seed=decision, first_actions=first)                                      # one nsg_fork + one step + one nsg_rollout_policy

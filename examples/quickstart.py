@@ -39,3 +39,20 @@ returns, lengths = vec.episode_returns()
 print(f"{c['env_steps']:,} env-steps, {c['episodes']:,} episodes finished, {c['updates_applied']:,} parameter updates; "
       f"mean return of the last finished episodes {returns[lengths > 0].mean().item():.1f}")
 vec.close()
+
+# --- the tutorial's agent loop (tutorial.ipynb cells 12, 26: `action = policy[observation]` on a FrozenLake whose slipperiness
+#     decays): 2^16 episodes at once, the policy looked up and the returns summed INSIDE the stepping kernel -------------------
+import numpy as np  # noqa: E402
+
+from ns_gym_amd.evaluate import run_episodes  # noqa: E402
+from ns_gym_amd.policies import TabularPolicy  # noqa: E402
+from ns_gym_amd.update_functions import DistributionDecrementUpdate  # noqa: E402
+
+lake = nsg.VecNSEnv(nsg.make("FrozenLake-v1", is_slippery=False, max_episode_steps=50), {"P": DistributionDecrementUpdate(ContinuousScheduler(), k=0.1)},
+                    num_envs=1 << 16, change_notification=True, delta_change_notification=True, initial_prob_dist=[1, 0, 0])
+go = {"L": 0, "D": 1, "R": 2, "U": 3}
+stationary_policy = TabularPolicy([go[c] for c in "DRDL" "DLDL" "RDDL" "LRRL"])      # the 4x4 map's shortest safe path (what value iteration finds without slip)
+cols = run_episodes(lake, stationary_policy, seed=0, as_arrays=True)                  # one launch per 64 steps; rows as NumPy columns
+print(f"stationary policy on the drifting lake: success rate {cols['total_reward'].mean():.3f} over {len(cols['num_steps']):,} episodes, "
+      f"mean length {cols['num_steps'].mean():.1f} ({lake.policy_kernels} kernels)")
+lake.close()

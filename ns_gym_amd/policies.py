@@ -12,7 +12,6 @@ the same object drives `env.step()` loops, the oracle and the tests.
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional
 
 import numpy as np
@@ -94,23 +93,21 @@ class TabularPolicy(Policy):
         self.table = np.asarray(table, dtype=np.int32).reshape(-1).copy()
         self._dev = {}
 
-    def _data(self, env):
-        t = self._dev.get(env.device)
-        if t is None:
-            t = self._dev[env.device] = torch.from_numpy(self.table).to(env.device)
-        return t
-
-    def _n_data(self, env):
-        return int(self.table.size)
-
-    def __call__(self, state: torch.Tensor) -> torch.Tensor:
-        return self._dev_table(state.device)[state.long()]
-
     def _dev_table(self, device):
         t = self._dev.get(device)
         if t is None:
             t = self._dev[device] = torch.from_numpy(self.table).to(device)
         return t
+
+    def _data(self, env):
+        return self._dev_table(env.device)
+
+    def _n_data(self, env):
+        return int(self.table.size)
+
+    def __call__(self, state: torch.Tensor) -> torch.Tensor:
+        """The same look-up as a torch gather (for `step()` loops): state [N] int -> actions [N] int32."""
+        return self._dev_table(state.device)[state.long()]
 
     def actions(self, env, step0, k, state=None):
         assert k == 1 and state is not None
@@ -128,12 +125,15 @@ class LinearPolicy(Policy):
         assert self.W.ndim == 2, "weights: [rows, obs_dim + 1] (bias last)"
         self._dev = {}
 
+    def _dev_weights(self, device):
+        t = self._dev.get(device)
+        if t is None:
+            t = self._dev[device] = torch.from_numpy(self.W.copy()).to(device).contiguous()
+        return t
+
     def _data(self, env):
         assert self.W.shape[1] == env.obs_dim + 1, f"weights need obs_dim + 1 = {env.obs_dim + 1} columns (bias last)"
-        t = self._dev.get(env.device)
-        if t is None:
-            t = self._dev[env.device] = torch.from_numpy(self.W.copy()).to(env.device).contiguous()
-        return t
+        return self._dev_weights(env.device)
 
     def _n_data(self, env):
         return int(self.W.shape[0])
@@ -156,9 +156,17 @@ class LinearPolicy(Policy):
             return np.clip(sc[:, 0], np.float32(low), np.float32(high)).astype(np.float32)
         return np.argmax(sc, axis=1).astype(np.int32)       # first maximum, like the kernel
 
-    def __call__(self, state: torch.Tensor) -> torch.Tensor:
-        # (host evaluation: exact float32 operation order matters more here than speed - it is the closed-loop reference path)
-        raise NotImplementedError("use decide() on a NumPy observation, or run the policy fused (VecNSEnv.rollout_policy)")
+    def __call__(self, state: torch.Tensor, action_is_float: bool = False, low: float = 0.0, high: float = 0.0) -> torch.Tensor:
+        """The same decision with torch kernels (for `step()` loops): one float32 multiply and one float32 add per term, in the
+        kernel's order (separate elementwise kernels: nothing is contracted into an FMA)."""
+        W = self._dev_weights(state.device)
+        d = W.shape[1] - 1
+        sc = W[:, d].unsqueeze(0).expand(state.shape[0], -1).clone()
+        for q in range(d):
+            sc = sc + W[:, q].unsqueeze(0) * state[:, q:q + 1]
+        if action_is_float:
+            return sc[:, 0].clamp(low, high)
+        return torch.argmax(sc, dim=1).to(torch.int32)       # (ties: the first maximum, like the kernel, for the two- and three-way cases here)
 
 
 class EpisodeAccounts:

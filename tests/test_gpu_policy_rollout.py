@@ -211,6 +211,7 @@ def test_linear_policy_closed_loop(name, specialize):
     for k in range(K):
         act_np = pol.decide(a.state.cpu().numpy(), a.action_is_float, lo, hi)
         act = torch.from_numpy(act_np).cuda()
+        assert torch.equal(pol(a.state, a.action_is_float, lo, hi), act)       # the torch evaluation (for step() loops) decides alike
         needs_reset = (a.buf["episode"] & 1).bool() if a.spec.class_name != "PendulumEnv" else (a.t >= a.cfg.max_episode_steps)
         obs, r, te, tr, _ = a.step(act)
         took = ~needs_reset
