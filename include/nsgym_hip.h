@@ -430,14 +430,14 @@ typedef struct nsg_episode_acc {
 } nsg_episode_acc;
 int nsg_rollout_policy(nsg_handle* h, const nsg_policy* pol, int32_t k_steps, const nsg_rollout_out* out,
                        const nsg_episode_acc* acc, void* stream);
-/* Which kernel nsg_rollout_policy launches for this handle: 0 the precompiled generic kernel, 1 the handle's specialised unit
- * (valid after the first such rollout of a specialised handle). */
-int nsg_rollout_policy_kind(const nsg_handle* h);
+/* Which kernel nsg_rollout_policy launches for this handle and action source `kind`: 0 the precompiled generic kernel, 1 the handle's
+ * specialised unit of that kind (valid after the first such rollout of a specialised handle). */
+int nsg_rollout_policy_kind(const nsg_handle* h, int32_t kind);
 /* The bits behind NSG_POL_UNIFORM (host-callable; tests and callers that want the same actions elsewhere). */
 uint64_t nsg_policy_bits(uint64_t seed, uint64_t env_index, uint64_t step);
-/* The specialised unit nsg_rollout_policy builds, on first use, for a specialised handle (one kernel: nsg_spec_rollout_policy);
- * no GPU needed, see nsg_spec_build. */
-int nsg_spec_build_policy(const nsg_config* cfg, const char* arch, void** code_out, size_t* size_out);
+/* The specialised unit nsg_rollout_policy builds, on first use, for a specialised handle and the action source `kind` (one kernel,
+ * nsg_spec_rollout_policy, with the kind as a compile-time constant); no GPU needed, see nsg_spec_build. */
+int nsg_spec_build_policy(const nsg_config* cfg, int32_t kind, const char* arch, void** code_out, size_t* size_out);
 
 /* ---- resident stepper: closed loops in the launch-bound regime ---------------------------------------------------------------
  * nsg_step costs a dependent launch per step (4-5 us on this stack before the kernel does anything); a batch of <= 2^17 envs is
@@ -610,8 +610,8 @@ int nsg_spec_origin(const nsg_handle* h);
  * the ordered member list (cfgs[k], ns[k]). */
 int nsg_spec_prebuild(const nsg_config* cfg, int64_t n, const char* arch, const char* dir);
 int nsg_spec_prebuild_group(const nsg_config* const* cfgs, const int64_t* ns, int32_t count, const char* arch, const char* dir);
-/* ... and the fused policy rollout's unit (nsg_rollout_policy of a specialised handle of (cfg, n)) */
-int nsg_spec_prebuild_policy(const nsg_config* cfg, int64_t n, const char* arch, const char* dir);
+/* ... and the fused policy rollout's unit (nsg_rollout_policy of a specialised handle of (cfg, n)) for the action source `kind` */
+int nsg_spec_prebuild_policy(const nsg_config* cfg, int64_t n, int32_t kind, const char* arch, const char* dir);
 int nsg_spec_build(const nsg_config* cfg, const char* arch, void** code_out, size_t* size_out);
 /* the same for the unit nsg_step_group uses when every member is specialised: one kernel (nsg_spec_group) for the ordered tuple
  * of the members' configs */

@@ -89,8 +89,8 @@ def load():
         getattr(lib, f).restype = C.c_int
     lib.nsg_spec_free.restype = None
     lib.nsg_rollout_policy.argtypes = [vp, C.POINTER(A.Policy), i32, C.POINTER(A.RolloutOut), C.POINTER(A.EpisodeAcc), vp]
-    lib.nsg_rollout_policy_kind.argtypes = [vp]
-    lib.nsg_spec_build_policy.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.nsg_rollout_policy_kind.argtypes = [vp, i32]
+    lib.nsg_spec_build_policy.argtypes = [C.c_void_p, i32, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.nsg_policy_bits.restype = C.c_uint64
     lib.nsg_policy_bits.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
     lib.nsg_spec_free.argtypes = [C.c_void_p]
@@ -102,7 +102,7 @@ def load():
     lib.nsg_spec_origin.argtypes = [C.c_void_p]
     lib.nsg_spec_prebuild.argtypes = [C.c_void_p, i64, C.c_char_p, C.c_char_p]
     lib.nsg_spec_prebuild_group.argtypes = [C.POINTER(C.c_void_p), C.POINTER(i64), i32, C.c_char_p, C.c_char_p]
-    lib.nsg_spec_prebuild_policy.argtypes = [C.c_void_p, i64, C.c_char_p, C.c_char_p]
+    lib.nsg_spec_prebuild_policy.argtypes = [C.c_void_p, i64, i32, C.c_char_p, C.c_char_p]
     if lib.nsg_abi_version() != A.NSG_ABI_VERSION:
         raise NsgError("libnsgym_hip.so ABI version mismatch")
     if (lib.nsg_sizeof_config() != C.sizeof(A.Config) or lib.nsg_sizeof_buffers() != C.sizeof(A.Buffers)

@@ -63,8 +63,10 @@ __device__ __forceinline__ void pol_linear(const PolicyArgs& pa, const float* o,
 // `block_rel` / `block_count`: the workgroup's index within, and the size of, the range of workgroups that walks this segment
 // (the whole launch for nsg_rollout; a member's block range for nsg_rollout_group).
 // POL: nsg_rollout_policy - `pa` says where the actions come from and where the episode accounts live; everything else is the same
-// launch (POL = false compiles to exactly the table-driven rollout).
-template <int ENV, bool FULL, bool POL = false>
+// launch (POL = false compiles to exactly the table-driven rollout).  KIND: the action source as a compile-time constant (the
+// specialised units: one small unit per (config, kind), so that a uniform rollout does not carry the linear policy's observation
+// registers across its steps), or -1: read from `pa` (the precompiled kernels).
+template <int ENV, bool FULL, bool POL = false, int KIND = -1>
 __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segment& sg, const void* __restrict__ actions,
                                              int k_steps, const nsg_rollout_out& ro, const int block_rel, const int block_count,
                                              const PolicyArgs* __restrict__ pa = nullptr) {
@@ -101,13 +103,14 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
         acc_alive = ac.alive ? ldg(ac.alive, (uint32_t)ir) != 0 : true;
         if (ac.ret) acc_ret = ldg(ac.ret, (uint32_t)ir * 8u);
         if (ac.length) acc_len = ldg(ac.length, (uint32_t)ir * 4u);
-        if (pa->pol.kind == NSG_POL_LINEAR) {
+        const int kind0 = KIND >= 0 ? KIND : pa->pol.kind;
+        if (kind0 == NSG_POL_LINEAR) {
           if constexpr (!GRID) {
 #pragma unroll
             for (int q = 0; q < D; q++) ls.o[q] = ldg(b.obs, (uint32_t)ir * (uint32_t)(4 * D) + 4u * (uint32_t)q);
           }
         }
-        if (pa->pol.kind == NSG_POL_BY_STATE) {
+        if (kind0 == NSG_POL_BY_STATE) {
           if constexpr (GRID) cell0 = ldg(b.cell, (uint32_t)ir * 4u);
         }
       }
@@ -161,7 +164,7 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
         int ai = 0;
         float af = 0.f;
         if (ir < N) {
-          const int kind = pa->pol.kind;
+          const int kind = KIND >= 0 ? KIND : pa->pol.kind;
           if (kind == NSG_POL_TABLE) {
             if constexpr (FA) af = ldg((const float*)act, (uint32_t)ir * 4u);
             else ai = ldg((const int32_t*)act, (uint32_t)ir * 4u);

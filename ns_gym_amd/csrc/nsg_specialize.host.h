@@ -154,18 +154,18 @@ inline std::string resident_source(const nsg_config& cfg, bool full) {
   return s;
 }
 
-// The fused policy rollout (nsg_rollout_policy) of a specialised handle: its own small unit like the resident stepper's, compiled the
-// first time such a rollout is asked for (with the batch-size policy of the handle's main unit, so that its resets and stores behave
+// The fused policy rollout (nsg_rollout_policy) of a specialised handle: its own small unit like the resident stepper's - one per action
+// source (`kind`, a compile-time constant of the unit) -, compiled the first time such a rollout is asked for (with the batch-size policy of the handle's main unit, so that its resets and stores behave
 // like the handle's nsg_rollout).
-inline std::string policy_source(const nsg_config& cfg, bool full, bool resets_in_lane, bool stream_state) {
+inline std::string policy_source(const nsg_config& cfg, bool full, bool resets_in_lane, bool stream_state, int kind) {
   std::string s = spec_source(cfg, full, resets_in_lane, false, stream_state);
   const size_t cut = s.find("extern \"C\" __global__");
   s.resize(cut);
-  char buf[40];
-  snprintf(buf, sizeof(buf), "%d, %s", (int)cfg.env_type, full ? "true" : "false");
+  char buf[48];
+  snprintf(buf, sizeof(buf), "%d, %s, true, %d", (int)cfg.env_type, full ? "true" : "false", kind);
   s += "extern \"C\" __global__ __launch_bounds__(NSG_BLOCK) void nsg_spec_rollout_policy(const nsg::Segment* __restrict__ seg, int k_steps,\n"
        "                                                                          nsg_rollout_out ro, nsg::PolicyArgs pa) {\n"
-       "  nsg::rollout_body<" + std::string(buf) + ", true>(NSG_SPEC_CFG, *seg, pa.pol.data, k_steps, ro, (int)blockIdx.x, (int)gridDim.x, &pa);\n"
+       "  nsg::rollout_body<" + std::string(buf) + ">(NSG_SPEC_CFG, *seg, pa.pol.data, k_steps, ro, (int)blockIdx.x, (int)gridDim.x, &pa);\n"
        "}\n";
   return s;
 }
@@ -302,9 +302,9 @@ inline std::vector<char> resident_compile(const nsg_config& cfg, bool full, cons
   }
   return code;
 }
-inline std::vector<char> policy_compile(const nsg_config& cfg, bool full, const char* arch, std::string& err, bool resets_in_lane = false,
+inline std::vector<char> policy_compile(const nsg_config& cfg, bool full, int kind, const char* arch, std::string& err, bool resets_in_lane = false,
                                         bool stream_state = false) {
-  std::vector<char> code = compile_source(policy_source(cfg, full, resets_in_lane, stream_state), arch, err);
+  std::vector<char> code = compile_source(policy_source(cfg, full, resets_in_lane, stream_state, kind), arch, err);
   if (!code.empty() && unit_uses_scratch(code) && !allow_spill()) {
     err = "the specialised policy-rollout kernel spills vector registers (scratch memory); such builds are not used (see spec_compile)";
     code.clear();

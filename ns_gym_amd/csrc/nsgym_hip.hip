@@ -135,8 +135,8 @@ struct nsg_handle {
   int device;
   const nsg_spec::Module* spec;  // config-specialised step / rollout kernels (nsg_specialize), or NULL
   const nsg_spec::Module* spec_resident = nullptr;   // ... and its resident stepper (built on the first nsg_resident_start)
-  const nsg_spec::Module* spec_policy_unit = nullptr;   // ... and its fused policy rollout (built on the first nsg_rollout_policy)
-  bool spec_policy_tried = false;
+  const nsg_spec::Module* spec_policy_unit[4] = {nullptr, nullptr, nullptr, nullptr};   // ... and its fused policy rollouts, one unit per action
+  bool spec_policy_tried[4] = {false, false, false, false};                              // source (NSG_POL_*), built on the first nsg_rollout_policy of that kind
   unsigned launches = 0;
   // What nsg_step_group remembers about a member list is keyed on these two: `id` is unique per nsg_create for the life of the
   // process (a new handle at a recycled address is a different member), `generation` counts the launch-relevant changes of
@@ -782,6 +782,11 @@ static const float kActLow[NSG_ENV_COUNT] = {0.f, -2.f, 0.f, 0.f, -1.f, 0.f, 0.f
 static const float kActHigh[NSG_ENV_COUNT] = {0.f, 2.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
 
 uint64_t nsg_policy_bits(uint64_t seed, uint64_t env_index, uint64_t step) { return pol_bits(seed, env_index, step); }
+// key of the policy unit of action source `kind` for the handle whose main unit has key `h0`
+static uint64_t policy_unit_key(uint64_t h0, int kind) {
+  const char tag[8] = {'p', 'o', 'l', 'i', 'c', 'y', (char)('0' + kind), 0};
+  return nsg_spec::fnv1a(tag, 7, h0);
+}
 
 int nsg_rollout_policy(nsg_handle* h, const nsg_policy* pol, int32_t k_steps, const nsg_rollout_out* out, const nsg_episode_acc* acc, void* stream) {
   if (!h) return fail(NSG_EINVAL, "handle is NULL");
@@ -825,20 +830,20 @@ int nsg_rollout_policy(nsg_handle* h, const nsg_policy* pol, int32_t k_steps, co
   const int grid = launch_grid_for(h);
   bool launched = false;
   if (h->spec) {   // a specialised handle: the policy rollout compiled for its configuration (its own unit, built on first use)
-    if (!h->spec_policy_unit && !h->spec_policy_tried) {
-      h->spec_policy_tried = true;
+    const int kind = pol->kind;
+    if (!h->spec_policy_unit[kind] && !h->spec_policy_tried[kind]) {
+      h->spec_policy_tried[kind] = true;
       hipDeviceProp_t prop;
       HIP_TRY(hipGetDeviceProperties(&prop, h->device));
       const SpecPolicy sp = spec_policy(h->host.cfg, h->n);
-      uint64_t h0 = nsg_spec::fnv1a("policy", 6, h->spec->h0);
-      const int grc = get_spec_module(h->device, h0, kUnitPolicy,
-                                      [&](std::string& err) { return nsg_spec::policy_compile(h->host.cfg, sp.full, prop.gcnArchName, err, sp.inlane, sp.stream_state); },
-                                      &h->spec_policy_unit);
-      if (grc) h->spec_policy_unit = nullptr;   // the generic kernel stays in force
+      const int grc = get_spec_module(h->device, policy_unit_key(h->spec->h0, kind), kUnitPolicy,
+                                      [&](std::string& err) { return nsg_spec::policy_compile(h->host.cfg, sp.full, kind, prop.gcnArchName, err, sp.inlane, sp.stream_state); },
+                                      &h->spec_policy_unit[kind]);
+      if (grc) h->spec_policy_unit[kind] = nullptr;   // the generic kernel stays in force
     }
-    if (h->spec_policy_unit) {
+    if (h->spec_policy_unit[kind]) {
       void* args[] = {(void*)&h->dev, (void*)&k_steps, (void*)&o, (void*)&pa};
-      HIP_TRY(hipModuleLaunchKernel(h->spec_policy_unit->rollout_policy, grid, 1, 1, kBlock, 1, 1, (unsigned)rollout_lds, s, args, nullptr));
+      HIP_TRY(hipModuleLaunchKernel(h->spec_policy_unit[kind]->rollout_policy, grid, 1, 1, kBlock, 1, 1, (unsigned)rollout_lds, s, args, nullptr));
       launched = true;
     }
   }
@@ -853,7 +858,7 @@ int nsg_rollout_policy(nsg_handle* h, const nsg_policy* pol, int32_t k_steps, co
   return mirror_last_slice(h, o, k_steps, s);
 }
 /* Which kernel nsg_rollout_policy launches for this handle: 0 generic, 1 the specialised unit (after the first such rollout). */
-int nsg_rollout_policy_kind(const nsg_handle* h) { return h && h->spec_policy_unit ? 1 : 0; }
+int nsg_rollout_policy_kind(const nsg_handle* h, int32_t kind) { return h && kind >= 0 && kind < 4 && h->spec_policy_unit[kind] ? 1 : 0; }
 
 // ---- resident stepper (nsg_rollout.hip.h: resident_body) -----------------------------------------------------------------
 // The waits of the resident kernels are budgets of the device's steady counter (wall_clock64()).  Its rate is MEASURED, once per
@@ -1428,14 +1433,15 @@ int nsg_spec_build_resident(const nsg_config* cfg, const char* arch, void** code
   return NSG_OK;
 }
 
-int nsg_spec_build_policy(const nsg_config* cfg, const char* arch, void** code_out, size_t* size_out) {
+int nsg_spec_build_policy(const nsg_config* cfg, int32_t kind, const char* arch, void** code_out, size_t* size_out) {
   if (!code_out || !size_out) return fail(NSG_EINVAL, "NULL output argument");
+  if (kind < 0 || kind > 3) return fail(NSG_EINVAL, "unknown policy kind %d", kind);
   *code_out = nullptr;
   *size_out = 0;
   int rc = validate(cfg, (size_t)kMaxTableBytes);
   if (rc) return rc;
   std::string err;
-  std::vector<char> code = nsg_spec::policy_compile(*cfg, !cfg_simple_theta(*cfg), arch && *arch ? arch : "gfx950", err);
+  std::vector<char> code = nsg_spec::policy_compile(*cfg, !cfg_simple_theta(*cfg), kind, arch && *arch ? arch : "gfx950", err);
   if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
   void* p = malloc(code.size());
   if (!p) return fail(NSG_ENOMEM, "out of host memory");
@@ -1498,16 +1504,17 @@ int nsg_spec_prebuild(const nsg_config* cfg, int64_t n, const char* arch, const 
   return write_unit(dir, spec_key(*cfg, pol, arch), code);
 }
 
-int nsg_spec_prebuild_policy(const nsg_config* cfg, int64_t n, const char* arch, const char* dir) {
+int nsg_spec_prebuild_policy(const nsg_config* cfg, int64_t n, int32_t kind, const char* arch, const char* dir) {
   if (!arch || !*arch || !dir || !*dir) return fail(NSG_EINVAL, "arch and dir are required");
+  if (kind < 0 || kind > 3) return fail(NSG_EINVAL, "unknown policy kind %d", kind);
   if (n <= 0 || n > NSG_MAX_ENVS) return fail(NSG_EINVAL, "n must be in [1, 2^27]");
   int rc = validate(cfg, (size_t)kMaxTableBytes);
   if (rc) return rc;
   const SpecPolicy pol = spec_policy(*cfg, n);
   std::string err;
-  const std::vector<char> code = nsg_spec::policy_compile(*cfg, pol.full, arch, err, pol.inlane, pol.stream_state);
+  const std::vector<char> code = nsg_spec::policy_compile(*cfg, pol.full, kind, arch, err, pol.inlane, pol.stream_state);
   if (code.empty()) return fail(NSG_EUNSUPPORTED, "%s", err.c_str());
-  return write_unit(dir, nsg_spec::fnv1a("policy", 6, spec_key(*cfg, pol, arch)), code);   // the key nsg_rollout_policy looks up
+  return write_unit(dir, policy_unit_key(spec_key(*cfg, pol, arch), kind), code);   // the key nsg_rollout_policy looks up
 }
 
 int nsg_spec_prebuild_group(const nsg_config* const* cfgs, const int64_t* ns, int32_t count, const char* arch, const char* dir) {

@@ -38,13 +38,15 @@ SINGLES = [
     ("C4 member Acrobot without episode accounting", "acro", 1 << 18, False),
 ]
 # the fused policy rollouts (nsg_rollout_policy) of the same configurations: closed loops and planner simulations at the BASELINE sizes
+# (tag, workload, envs, track_returns, action-source kinds: 1 uniform, 2 by-state, 3 linear - one small unit each)
 POLICIES = [
-    ("C1 fused policy rollout, 2^20 envs", "c1", 1 << 20, True),
-    ("C2 fused policy rollout, 65 536 envs (closed loop at BASELINE's size)", "c2", 1 << 16, True),
-    ("C3 fused policy rollout, 2^20 envs", "c3", 1 << 20, True),
-    ("C4 member Pendulum, fused policy rollout", "pend", 1 << 18, True),
-    ("C4 member Acrobot, fused policy rollout", "acro", 1 << 18, True),
+    ("C1 fused policy rollout, 2^20 envs", "c1", 1 << 20, True, (1, 3)),
+    ("C2 fused policy rollout, 65 536 envs (closed loop at BASELINE's size)", "c2", 1 << 16, True, (1, 3)),
+    ("C3 fused policy rollout, 2^20 envs", "c3", 1 << 20, True, (1, 2)),
+    ("C4 member Pendulum, fused policy rollout", "pend", 1 << 18, True, (1, 3)),
+    ("C4 member Acrobot, fused policy rollout", "acro", 1 << 18, True, (1, 3)),
 ]
+POLICY_KIND_NAMES = {0: "action table", 1: "uniform", 2: "by state", 3: "linear"}
 GROUPS = [
     ("C4 Pendulum + Acrobot in one launch (nsg_step_group / nsg_rollout_group)", [("pend", 1 << 18), ("acro", 1 << 18)], True),
     ("C4 without episode accounting", [("pend", 1 << 18), ("acro", 1 << 18)], False),
@@ -106,13 +108,14 @@ def build_all(directory: str = DIR, arch: str = ARCH, verbose: bool = False) -> 
         inspect(newest(before), tag)
         if verbose:
             print("prebuilt", tag, file=sys.stderr)
-    for tag, name, n, track in POLICIES:
+    for tag, name, n, track, kinds in POLICIES:
         cfg = _config(name, track)
-        before = set(os.listdir(directory))
-        _lib.check(lib.nsg_spec_prebuild_policy(C.byref(cfg), n, arch.encode(), directory.encode()), f"nsg_spec_prebuild_policy({name}, {n})")
-        inspect(newest(before), tag)
-        if verbose:
-            print("prebuilt", tag, file=sys.stderr)
+        for kind in kinds:
+            before = set(os.listdir(directory))
+            _lib.check(lib.nsg_spec_prebuild_policy(C.byref(cfg), n, kind, arch.encode(), directory.encode()), f"nsg_spec_prebuild_policy({name}, {n}, {kind})")
+            inspect(newest(before), f"{tag}: {POLICY_KIND_NAMES[kind]}")
+            if verbose:
+                print("prebuilt", tag, POLICY_KIND_NAMES[kind], file=sys.stderr)
     for tag, members, track in GROUPS:
         cfgs = [_config(name, track) for name, _ in members]
         arr = (C.c_void_p * len(cfgs))(*[C.addressof(c) for c in cfgs])

@@ -324,6 +324,7 @@ class VecNSEnv:
         if record_actions:
             acts = torch.empty((K, N), dtype=torch.float32 if self.action_is_float else torch.int32, device=self.device)
         pol = policy._struct(self, step0, acts)
+        self._last_policy_kind = int(pol.kind)
         acc = accounts._struct() if accounts is not None else None
         with torch.cuda.device(self.device):
             _lib.check(self.lib.nsg_rollout_policy(self._h, C.byref(pol), K, C.byref(ro), C.byref(acc) if acc is not None else None,
@@ -337,8 +338,8 @@ class VecNSEnv:
 
     @property
     def policy_kernels(self) -> str:
-        """Which kernel `rollout_policy` launches: the handle's specialised unit (after the first such rollout) or the generic one."""
-        return "config-specialised" if self.lib.nsg_rollout_policy_kind(self._h) == 1 else "generic"
+        """Which kernel the last `rollout_policy` launched: the handle's specialised unit of that action source or the generic one."""
+        return "config-specialised" if self.lib.nsg_rollout_policy_kind(self._h, int(getattr(self, "_last_policy_kind", 1))) == 1 else "generic"
 
     def _as_actions(self, actions):
         dt = torch.float32 if self.action_is_float else torch.int32
