@@ -838,10 +838,10 @@ def gen_planning(gym, S, U, CC, FL, spec):
     import copy as _copy
 
     env_id = spec["env_id"]
-    is_fl = env_id == "FrozenLake-v1"
+    is_fl = env_id in ("FrozenLake-v1", "CliffWalking-v1")
     cont = env_id in ("Pendulum-v1", "MountainCarContinuous-v0")
     tp = build_params(S, U, spec["params"])
-    Wr = FL if is_fl else CC
+    Wr = _EXTRA_WRAPPERS.get(env_id, FL) if is_fl else CC
     env = Wr(gym.make(env_id, **spec.get("make_kwargs", {})), tp, **spec["flags"], **spec.get("wrapper_kwargs", {}))
     pnames = list(spec["params"].keys())
     T = spec["pre"] + spec["post"]
@@ -854,6 +854,8 @@ def gen_planning(gym, S, U, CC, FL, spec):
         assert not (term or trunc), "pick a seed whose first episode outlives `pre`"
         k += 1
     sim = env.get_planning_env() if spec["kind"] == "planning" else _copy.deepcopy(env)
+    if spec.get("levels", 1) == 2:      # what MCTS.search steps: a deep copy OF the planning env it was given (MCTS.py:131)
+        sim = _copy.deepcopy(sim)
     assert sim.is_sim_env
     out = {"actions": actions, "pre": np.int32(spec["pre"]), "fork_t": np.int32(sim.t)}
     if is_fl:
@@ -1001,6 +1003,9 @@ def main():
         man["user_specs"] = USER_SPECS
         man["noreset_specs"] = NORESET_SPECS
         man["noreset_grid_specs"] = NORESET_GRID_SPECS
+        order = ["numpy", "python", "reference", "base_envs", "scheduler_specs", "scalar_update_specs", "dist_update_specs", "traj_specs",
+                 "user_specs", "noreset_specs", "noreset_grid_specs", "planning_specs", "grid_specs"]   # the full run's key order: either path writes the same bytes
+        man = {**{k: man[k] for k in order if k in man}, **{k: v for k, v in man.items() if k not in order}}
         with open(os.path.join(HERE, "manifest.json"), "w") as f:
             json.dump(man, f, indent=1)
         return

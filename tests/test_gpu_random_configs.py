@@ -169,6 +169,11 @@ def test_random_configuration_planning_copy_matches_oracle(case):
         g.step(acts[k]), o.step(acts[k])
     mode, entropy = int(rng.integers(0, 2)), int(rng.integers(0, 2 ** 62))
     gf, of = GpuView(g.env.fork(theta_mode=mode, entropy=entropy)), OracleView(o.env.fork(theta_mode=mode, entropy=entropy))
+    if case % 3 == 2:      # a copy OF the copy (MCTS.search deep-copies the planning env it is given): which P table, whose theta
+        first = gf.env
+        gf, of = GpuView(first.fork(theta_mode=0, entropy=entropy + 1)), OracleView(of.env.fork(theta_mode=0, entropy=entropy + 1))
+        first.close()
+        tag += " (copy of a copy)"
     compare_views(gf._out(), of._out(), is_grid, tag + " at fork")
     acro = spec["env_id"] == "Acrobot-v1"
     for k in range(pre, pre + post):

@@ -18,7 +18,7 @@ def run_planning(factory, view_cls, name, fork):
 def run_planning_rec(factory, view_cls, spec, rec, fork):
     env = make_env_from_spec(factory, {**spec, "seeds": [spec["seed"]]}, n=1)
     v = view_cls(env)
-    is_fl = spec["env_id"] == "FrozenLake-v1"
+    is_fl = spec["env_id"] in ("FrozenLake-v1", "CliffWalking-v1")
     v.reset(np.array([spec["seed"]], dtype=np.uint64))
     acts = rec["actions"]
     pre = int(rec["pre"])
@@ -26,6 +26,8 @@ def run_planning_rec(factory, view_cls, spec, rec, fork):
         v.step(acts[k:k + 1])
     theta_mode = 1 if (spec["kind"] == "planning" and not spec["flags"].get("delta_change_notification")) else 0
     sim = fork(env, theta_mode)
+    if spec.get("levels", 1) == 2:      # a copy of the copy (MCTS.search: deepcopy(self.env) of the planning env it was given)
+        sim = fork(sim, 0)
     sv = view_cls(sim)
     out = sv._out()
     assert out["t"][0] == rec["fork_t"]

@@ -93,7 +93,7 @@ def test_oracle_planning_copy_matches_the_reference_on_a_random_configuration(re
     flags = {"change_notification": cn, "delta_change_notification": bool(cn and rng.random() < 0.5),
              "in_sim_change": bool(rng.random() < 0.5), "persistent_params": bool(rng.random() < 0.2)}
     spec = {"env_id": env_id, "params": params, "flags": flags, "kind": str(rng.choice(["planning", "deepcopy"])),
-            "pre": int(rng.integers(1, 7)), "post": 30}
+            "pre": int(rng.integers(1, 7)), "post": 30, "levels": int(rng.integers(1, 3))}
     for seed in rng.integers(0, 2 ** 31, size=20):      # a seed whose first episode outlives `pre`
         spec["seed"] = int(seed)
         try:
@@ -127,7 +127,7 @@ def test_oracle_frozenlake_planning_copy_matches_the_reference_on_a_random_confi
             "wrapper_kwargs": {"initial_prob_dist": [1.0, 0.0, 0.0] if rng.random() < 0.5 else [0.8, 0.1, 0.1]},
             "flags": {"change_notification": cn, "delta_change_notification": bool(cn and rng.random() < 0.5),
                       "in_sim_change": bool(rng.random() < 0.5)},
-            "kind": str(rng.choice(["planning", "deepcopy"])), "pre": int(rng.integers(1, 6)), "post": 30}
+            "kind": str(rng.choice(["planning", "deepcopy"])), "pre": int(rng.integers(1, 6)), "post": 30, "levels": int(rng.integers(1, 3))}
     for seed in rng.integers(0, 2 ** 31, size=40):
         spec["seed"] = int(seed)
         try:
@@ -137,4 +137,32 @@ def test_oracle_frozenlake_planning_copy_matches_the_reference_on_a_random_confi
             continue
     else:
         pytest.skip("no seed kept the first episode alive")
+    run_planning_rec(OracleVecEnv, OracleView, spec, rec, lambda env, mode: env.fork(theta_mode=mode, entropy=99))
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("NSG_LIVE_PLANNING_CLIFF_CASES", "16"))))
+def test_oracle_cliffwalking_planning_copy_matches_the_reference_on_a_random_configuration(ref, case):
+    """CliffWalking's variant of the planning-copy semantics (toy_text.py:212-253): a copy's own table AND its base env's are the source's
+    own table, get_planning_env() without delta notification overwrites the base env's - and a copy of THAT copy takes the source's own,
+    still current, table again.  One- and two-level copies on random deterministic distribution updates."""
+    from oracle.oracle import OracleVecEnv
+    from tests.test_gpu_random_configs import SCHED_KINDS
+    from tests.test_oracle_planning import run_planning_rec
+    from tests.util import OracleView
+
+    G, (gym, S, U, CC, FL) = ref
+    rng = np.random.default_rng(97_000 + case)
+    det_scheds = [k for k in SCHED_KINDS if not k.startswith("random")]
+    kind = str(rng.choice(["d_decrement", "d_increment", "d_uniformdrift", "d_noupdate"]))
+    upd = {"d_decrement": ["DistributionDecrementUpdate", {"k": 0.07}], "d_increment": ["DistributionIncrementUpdate", {"k": 0.05}],
+           "d_uniformdrift": ["UniformDrift", {"rate": 0.1}], "d_noupdate": ["DistributionNoUpdate", {}]}[kind]
+    cn = bool(rng.random() < 0.8)
+    spec = {"env_id": "CliffWalking-v1", "make_kwargs": {},
+            "params": {"P": {"scheduler": G.SCHEDULER_SPECS[str(rng.choice(det_scheds))], "update": upd}},
+            "wrapper_kwargs": {"initial_prob_dist": [1.0, 0.0, 0.0, 0.0] if rng.random() < 0.5 else [0.7, 0.1, 0.1, 0.1]},
+            "flags": {"change_notification": cn, "delta_change_notification": bool(cn and rng.random() < 0.5),
+                      "in_sim_change": bool(rng.random() < 0.5)},
+            "kind": str(rng.choice(["planning", "deepcopy"])), "pre": int(rng.integers(1, 6)), "post": 30, "levels": int(rng.integers(1, 3)),
+            "seed": int(rng.integers(0, 2 ** 31))}
+    rec = G.gen_planning(gym, S, U, CC, FL, spec)
     run_planning_rec(OracleVecEnv, OracleView, spec, rec, lambda env, mode: env.fork(theta_mode=mode, entropy=99))
