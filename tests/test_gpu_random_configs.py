@@ -235,3 +235,66 @@ def test_random_configuration_fused_rollout_matches_oracle(case):
     c = env.counters()
     assert [c["episodes"], c["updates_applied"], c["constraint_violations"], c["env_steps"]] == [int(x) for x in o.env.a["counters"].sum(axis=1)[:4]], tag
     env.close()
+
+
+@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("NSG_SWEEP_POLICY_CASES", "48"))))
+def test_random_configuration_policy_rollout_matches_oracle(case):
+    """The sweep through nsg_rollout_policy: a random configuration, a random in-kernel action source (uniform draws, a table over the
+    cells, a linear policy on the observation), discounted accounts, two launches - against the oracle's restatement of the same loop
+    (orc_rollout_policy): the actions taken, the float64 accounts and the final rows."""
+    import torch
+
+    from ns_gym_amd import _abi as A
+    from ns_gym_amd.envs import make
+    from ns_gym_amd.policies import EpisodeAccounts, LinearPolicy, TabularPolicy, UniformRandom
+    from ns_gym_amd.spec import build_tunable_params
+    from ns_gym_amd.vec_env import VecNSEnv
+    from oracle.oracle import OracleVecEnv
+
+    rng = np.random.default_rng(50_000 + case)
+    spec = random_spec(rng)
+    if spec["env_id"] == "Acrobot-v1":      # (chaotic under closed loops: a last-ulp difference flips a decision; its open loops are swept above)
+        spec["env_id"], spec["params"] = "MountainCar-v0", {"force": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": scalar_fn_spec(rng, "increment", 0.001)}}
+    n = int(rng.choice([1, 64, 65, 300, 513]))
+    K1, K2 = int(rng.integers(1, 30)), int(rng.integers(1, 40))
+    kw = {**spec["flags"], **_decode(spec)}
+    env = VecNSEnv(make(spec["env_id"], **spec["make_kwargs"]), build_tunable_params(spec["params"]), n, specialize=bool(case % 2), **kw)
+    o = OracleView(OracleVecEnv(make(spec["env_id"], **spec["make_kwargs"]), build_tunable_params(spec["params"]), n, **kw))
+    g = GpuView(env)
+    seeds = rng.integers(0, 2 ** 40, size=n).astype(np.uint64)
+    is_grid = spec["env_id"] in GRID
+    g.reset(seeds), o.reset(seeds)
+    which = int(rng.integers(0, 2))
+    if which == 0:
+        pol = UniformRandom(seed=int(rng.integers(0, 2 ** 62)), index0=int(rng.integers(0, 2 ** 30)))
+        okind, odata, okw = A.NSG_POL_UNIFORM, None, {"seed": pol.seed, "index0": pol.index0}
+    elif is_grid:
+        pol = TabularPolicy(rng.integers(0, 4, size=env.cfg.nrow * env.cfg.ncol))
+        okind, odata, okw = A.NSG_POL_BY_STATE, pol.table, {}
+    else:
+        pol = LinearPolicy(rng.normal(size=(1 if env.action_is_float else env.n_actions, env.obs_dim + 1)).astype(np.float32))
+        okind, odata, okw = A.NSG_POL_LINEAR, pol.W, {}
+    gamma = float(rng.choice([1.0, 0.99, 0.9]))
+    tag = f"policy case {case}: {spec} kind {okind} gamma {gamma}"
+    acc = EpisodeAccounts(env, gamma=gamma, horizon=K1 + K2 + 1)
+    oacc = {"ret": np.zeros(n), "length": np.zeros(n, dtype=np.int32), "alive": np.ones(n, dtype=np.uint8),
+            "discount": np.array([gamma ** j for j in range(K1 + K2 + 1)], dtype=np.float64)}
+    k = 0
+    smooth = spec["env_id"] in ("Pendulum-v1", "MountainCarContinuous-v0")     # float64 rewards through sin / cos or the float action
+    for K in (K1, K2):
+        out = env.rollout_policy(pol, K, accounts=acc, step0=k, record_actions=True)
+        oa, _, _ = o.env.rollout_policy(okind, K, data=odata, step0=k, accounts=oacc, **okw)
+        ga = out["actions"].cpu().numpy()
+        if smooth and okind == A.NSG_POL_LINEAR:
+            np.testing.assert_allclose(ga, oa, rtol=0, atol=2e-5, err_msg=tag)
+        else:
+            np.testing.assert_array_equal(ga, oa, err_msg=tag)
+        k += K
+        compare_views(g._out(), o._out(), is_grid, tag + f" after {k} steps")
+        np.testing.assert_array_equal(acc.length.cpu().numpy(), oacc["length"], err_msg=tag)
+        np.testing.assert_array_equal(acc.alive.cpu().numpy(), oacc["alive"], err_msg=tag)
+        if smooth:
+            np.testing.assert_allclose(acc.ret.cpu().numpy(), oacc["ret"], rtol=1e-6, atol=1e-6, err_msg=tag)
+        else:
+            np.testing.assert_array_equal(acc.ret.cpu().numpy(), oacc["ret"], err_msg=tag)
+    env.close()
