@@ -314,6 +314,8 @@ struct IoMode {  // wave-uniform
                     // actions read past it (agent-scope loads) - so that the hand-over needs no L2-wide writeback / invalidate:
                     // with 32 workgroups per XCD each issuing its own pair of cache-wide fences a resident step cost 20 us
                     // (profiles/NOTEBOOK.md, round 4)
+  bool opt_out = false;   // fused rollouts, every step but the last: a step output whose pointer is NULL is not stored at all (the caller does
+                          // not record that row; the handle's own row is written by the launch's last step)
   bool act_lane = false;  // fused policy rollouts (nsg_rollout_policy): the action comes from the lane's own registers (LaneState::ai / af,
                           // GridLane::ai), and the step leaves its observation, float64 reward and flags there for the next decision
 };
@@ -487,8 +489,8 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
         // rows 0/1 live in registers across fused steps: written when this step stores (always then,
         // because earlier fused steps may have changed them without a store)
         if (p > 1 ? fin != c : (io.store && (fin != c || io.dirty))) stg(b.theta + (int64_t)p * N, o8, fin);
-        stg_o(io.coh, out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
-        stg_o(io.coh, out.delta_change + (int64_t)p * N, o4, (float)delta);
+        if (!io.opt_out || out.env_change) stg_o(io.coh, out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
+        if (!io.opt_out || out.delta_change) stg_o(io.coh, out.delta_change + (int64_t)p * N, o4, (float)delta);
         if (cfg.flags & NSG_F_VIOLATION_MASK) stg(b.violation + (int64_t)p * N, o1, (uint8_t)(rejected && do_step ? 1 : 0));
       }
       n_fired += fired ? 1u : 0u;
@@ -552,8 +554,8 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
         // rows 0/1 live in registers across fused steps: written when this step stores (always then,
         // because earlier fused steps may have changed them without a store)
         if (p > 1 ? fin != c : (io.store && (fin != c || io.dirty))) stg(b.theta + (int64_t)p * N, o8, fin);
-        stg_o(io.coh, out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
-        stg_o(io.coh, out.delta_change + (int64_t)p * N, o4, (float)delta);
+        if (!io.opt_out || out.env_change) stg_o(io.coh, out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
+        if (!io.opt_out || out.delta_change) stg_o(io.coh, out.delta_change + (int64_t)p * N, o4, (float)delta);
         if (cfg.flags & NSG_F_VIOLATION_MASK) stg(b.violation + (int64_t)p * N, o1, (uint8_t)(rejected && do_step ? 1 : 0));
       }
       n_fired += fired ? 1u : 0u;
@@ -698,7 +700,7 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
     }
     float o[T::OBS];
     env_obs<ENV>(s, o);
-    store_obs<ENV>(out.obs, i, o, io.coh);
+    if (!io.opt_out || out.obs) store_obs<ENV>(out.obs, i, o, io.coh);
     if (io.act_lane) {
 #pragma unroll
       for (int k = 0; k < T::OBS; k++) ls.o[k] = o[k];
@@ -706,9 +708,9 @@ __device__ __forceinline__ void step_chunk(const nsg_config& cfg, const nsg_buff
       ls.fl = (term ? 1u : 0u) | (trunc ? 2u : 0u) | (do_step ? 4u : 0u);
     }
     if (io.store) stg(b.t, o4, tnew);
-    stg_o(io.coh, out.reward, o4, (float)reward);
-    stg_o(io.coh, out.terminated, o1, (uint8_t)(term ? 1 : 0));
-    stg_o(io.coh, out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
+    if (!io.opt_out || out.reward) stg_o(io.coh, out.reward, o4, (float)reward);
+    if (!io.opt_out || out.terminated) stg_o(io.coh, out.terminated, o1, (uint8_t)(term ? 1 : 0));
+    if (!io.opt_out || out.truncated) stg_o(io.coh, out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
     if (io.store && (!reset_from_t || do_reset || io.lds_rng)) stg(b.episode, o4, (int32_t)stw);
     if (track) {  // the episode length is the wrapper time t: only the return needs a running row
       if constexpr (kReturnFromT) {
@@ -913,8 +915,8 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       }
     }
     if (active) {
-      stg_o(io.coh, out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
-      stg_o(io.coh, out.delta_change + (int64_t)p * N, o4, (float)delta);
+      if (!io.opt_out || out.env_change) stg_o(io.coh, out.env_change + (int64_t)p * N, o1, (uint8_t)(fired ? 1 : 0));
+      if (!io.opt_out || out.delta_change) stg_o(io.coh, out.delta_change + (int64_t)p * N, o4, (float)delta);
     }
     n_fired += fired ? 1u : 0u;
   }
@@ -993,9 +995,9 @@ __device__ __forceinline__ void step_grid(const nsg_config& cfg, const nsg_buffe
       gl.fl = (term ? 1u : 0u) | (trunc ? 2u : 0u) | (do_step ? 4u : 0u);
     }
     if (out.obs) stg_o(io.coh, (int32_t*)out.obs, o4, cell);  // trajectory slice (rollout); NULL for nsg_step: cell[] is the obs
-    stg_o(io.coh, out.reward, o4, (float)reward);
-    stg_o(io.coh, out.terminated, o1, (uint8_t)(term ? 1 : 0));
-    stg_o(io.coh, out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
+    if (!io.opt_out || out.reward) stg_o(io.coh, out.reward, o4, (float)reward);
+    if (!io.opt_out || out.terminated) stg_o(io.coh, out.terminated, o1, (uint8_t)(term ? 1 : 0));
+    if (!io.opt_out || out.truncated) stg_o(io.coh, out.truncated, o1, (uint8_t)(trunc ? 1 : 0));
     if (track) {
       float er = return_is_last_reward ? (float)reward : do_reset ? 0.f : gl.er + (float)reward;
       if (done) {

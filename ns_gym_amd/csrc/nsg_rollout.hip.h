@@ -151,12 +151,14 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
         out = dflt;
         if (GRID) out.obs = nullptr;
       } else {
-      out.obs = ro.obs ? ro.obs + (int64_t)k * N * D : (GRID ? nullptr : dflt.obs);
-      out.reward = ro.reward ? ro.reward + (int64_t)k * N : dflt.reward;
-      out.terminated = ro.terminated ? ro.terminated + (int64_t)k * N : dflt.terminated;
-      out.truncated = ro.truncated ? ro.truncated + (int64_t)k * N : dflt.truncated;
-      out.env_change = ro.env_change ? ro.env_change + (int64_t)k * P * N : dflt.env_change;
-      out.delta_change = ro.delta_change ? ro.delta_change + (int64_t)k * P * N : dflt.delta_change;
+      // a row the caller does not record is not stored by the steps before the last (IoMode::opt_out): 27 B per CartPole env-step that
+      // the next step would only overwrite
+      out.obs = ro.obs ? ro.obs + (int64_t)k * N * D : nullptr;
+      out.reward = ro.reward ? ro.reward + (int64_t)k * N : nullptr;
+      out.terminated = ro.terminated ? ro.terminated + (int64_t)k * N : nullptr;
+      out.truncated = ro.truncated ? ro.truncated + (int64_t)k * N : nullptr;
+      out.env_change = ro.env_change ? ro.env_change + (int64_t)k * P * N : nullptr;
+      out.delta_change = ro.delta_change ? ro.delta_change + (int64_t)k * P * N : nullptr;
       }
       const void* act = FA ? (const void*)((const float*)actions + (int64_t)k * N) : (const void*)((const int32_t*)actions + (int64_t)k * N);
       if constexpr (POL) {
@@ -186,11 +188,11 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
         unsigned fl;
         if constexpr (GRID) {
           gl.ai = ai;
-          step_grid<ENV, FULL>(cfg, b, N, tb, zg, act, out, ir, ir < N, wc, gl, IoMode{k == 0, k == k_steps - 1, k > 0, false, false, false, true});
+          step_grid<ENV, FULL>(cfg, b, N, tb, zg, act, out, ir, ir < N, wc, gl, IoMode{k == 0, k == k_steps - 1, k > 0, false, false, false, !last, true});
           rw = gl.rw; fl = gl.fl;
         } else {
           ls.ai = ai; ls.af = af;
-          step_chunk<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, k == k_steps - 1, k > 0, true, false, false, true});
+          step_chunk<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, k == k_steps - 1, k > 0, true, false, false, !last, true});
           rw = ls.rw; fl = ls.fl;
         }
         // ---- the accounts: tot_reward += reward * gamma ** depth (MCTS.py:179), total_reward += reward (run_experiment.py:117) ----
@@ -202,9 +204,9 @@ __device__ __forceinline__ void rollout_body(const nsg_config& cfg, const Segmen
         }
       } else if constexpr (GRID) {
         const int64_t ig = c * kBlock + threadIdx.x;
-        step_grid<ENV, FULL>(cfg, b, N, tb, zg, act, out, ig, ig < N, wc, gl, IoMode{k == 0, k == k_steps - 1, k > 0, false});
+        step_grid<ENV, FULL>(cfg, b, N, tb, zg, act, out, ig, ig < N, wc, gl, IoMode{k == 0, k == k_steps - 1, k > 0, false, false, false, !last});
       } else {
-        step_chunk<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, k == k_steps - 1, k > 0, true});
+        step_chunk<ENV, FULL>(cfg, b, N, tb, zg, act, out, c * kBlock, parity, lds, wc, ls, IoMode{k == 0, k == k_steps - 1, k > 0, true, false, false, !last});
       }
       parity ^= 1;
     }
