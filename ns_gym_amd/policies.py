@@ -40,6 +40,29 @@ def policy_bits(seed: int, env_index, step) -> np.ndarray:
         return _mix(a + np.uint64(0xD1B54A32D192ED03) * (k + np.uint64(1)))
 
 
+def _as_i64(c: int) -> int:
+    return c - (1 << 64) if c >= (1 << 63) else c
+
+
+def _lsr(x: torch.Tensor, s: int) -> torch.Tensor:
+    """Logical right shift of int64 bit patterns (torch shifts arithmetically)."""
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def policy_bits_torch(seed: int, env_index: torch.Tensor, step: torch.Tensor) -> torch.Tensor:
+    """`policy_bits` with torch int64 arithmetic (wrap-around products are the unsigned ones' bit patterns): the same 64 bits, as
+    int64, on whatever device the index tensors live on - action tables for 2^20 envs without a host round trip."""
+    def mix(x):
+        x = x ^ _lsr(x, 30)
+        x = x * _as_i64(0xBF58476D1CE4E5B9)
+        x = x ^ _lsr(x, 27)
+        x = x * _as_i64(0x94D049BB133111EB)
+        return x ^ _lsr(x, 31)
+
+    a = mix(_as_i64(seed & _M64) + _as_i64(0x9E3779B97F4A7C15) * (env_index.to(torch.int64) + 1))
+    return mix(a + _as_i64(0xD1B54A32D192ED03) * (step.to(torch.int64) + 1))
+
+
 class Policy:
     """Base of the in-kernel policies.  `kind` is the `nsg_policy.kind`; `_data(env)` the device tensor the kernel reads."""
     kind = -1
@@ -82,7 +105,15 @@ class UniformRandom(Policy):
         return (((bits >> np.uint64(32)) * np.uint64(env.n_actions)) >> np.uint64(32)).astype(np.int32)
 
     def actions(self, env, step0: int, k: int, state=None) -> torch.Tensor:
-        return torch.from_numpy(self.table(env, step0, k)).to(env.device)
+        """The same [k, N] table computed on the env's device."""
+        dev = env.device
+        bits = policy_bits_torch(self.seed, (self.index0 + torch.arange(env.num_envs, device=dev))[None, :],
+                                 (step0 + torch.arange(k, device=dev))[:, None])
+        if env.action_is_float:
+            lo, hi = float(env.spec.env_type.action_low), float(env.spec.env_type.action_high)
+            u = _lsr(bits, 40).to(torch.float32) * 5.9604644775390625e-08
+            return torch.tensor(lo, dtype=torch.float32, device=dev) + torch.tensor(hi - lo, dtype=torch.float32, device=dev) * u
+        return ((_lsr(bits, 32) * env.n_actions) >> 32).to(torch.int32)
 
 
 class TabularPolicy(Policy):

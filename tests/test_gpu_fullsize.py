@@ -353,3 +353,67 @@ def test_c4_group_rollout_at_full_size_equals_group_steps():
         assert a.counters() == b.counters(), nm
     for e in fused + stepped:
         e.close()
+
+
+def test_fused_policy_rollouts_at_full_size():
+    """BASELINE's sizes through the fused closed loops (nsg_rollout_policy), by properties that do not need an oracle run:
+      * C1's config, 2^20 envs x 200 steps, uniform in-kernel actions: every row equals nsg_rollout over the same action table
+        (computed on the device by the torch mirror of the draw), and CartPole's accounts have a closed form - the discounted
+        return of an episode of L steps is the L-th sequential partial sum of the discount table, bit for bit;
+      * C3's config, 2^20 envs x 200 steps, a tabular policy decided in the kernel: equals 200 single steps whose actions a torch
+        gather looks up in the same table; a FrozenLake account is gamma ** (L - 1) if the episode reached the goal, else 0."""
+    import torch
+
+    from ns_gym_amd.policies import EpisodeAccounts, TabularPolicy, UniformRandom
+
+    K, chunks, gamma = 50, 4, 0.99
+    disc = np.array([gamma ** j for j in range(K * chunks + 1)])
+    # ---- C1 ----
+    spec = TRAJ_SPECS["c1_cartpole_masspole_inc"]
+    a, b = make_env_from_spec(_vec, spec, n=N), make_env_from_spec(_vec, spec, n=N)
+    a.reset(seed=7); b.reset(seed=7)
+    pol = UniformRandom(seed=99)
+    acc = EpisodeAccounts(b, gamma=gamma, horizon=K * chunks + 1)
+    for c in range(chunks):
+        table = pol.actions(a, c * K, K)
+        if c == 0:
+            assert np.array_equal(table[:3, :4096].cpu().numpy(), pol.table(a, 0, 3)[:, :4096])     # the torch mirror IS the NumPy one
+        ra = a.rollout(table, record=("reward", "terminated"))
+        rb = b.rollout_policy(pol, K, record=("reward", "terminated"), accounts=acc, step0=c * K)
+        assert torch.equal(ra["reward"], rb["reward"]) and torch.equal(ra["terminated"], rb["terminated"])
+    for row in ("theta", "t", "state", "phys"):
+        assert torch.equal(getattr(a, row), getattr(b, row)), row
+    assert torch.equal(a.buf["episode"], b.buf["episode"]) and a.counters() == b.counters()
+    length = acc.length.cpu().numpy()
+    assert length.min() >= 8 and length.max() <= K * chunks and not acc.alive.cpu().numpy()[length < K * chunks].any()
+    partial = np.zeros(K * chunks + 1)
+    s = 0.0
+    for j in range(K * chunks):          # tot_reward += 1.0 * gamma ** depth, one addition at a time
+        s = s + 1.0 * disc[j]
+        partial[j + 1] = s
+    np.testing.assert_array_equal(acc.ret.cpu().numpy(), partial[length])
+    a.close(); b.close()
+    # ---- C3 ----
+    spec = TRAJ_SPECS["c3_frozenlake_step50"]
+    a, b = make_env_from_spec(_vec, spec, n=N), make_env_from_spec(_vec, spec, n=N)
+    a.reset(seed=3); b.reset(seed=3)
+    tab = TabularPolicy(np.random.default_rng(1).integers(0, 4, size=64))
+    acc = EpisodeAccounts(b, gamma=gamma, horizon=K * chunks + 1)
+    reached = torch.zeros(N, dtype=torch.bool, device="cuda")
+    live = torch.ones(N, dtype=torch.bool, device="cuda")
+    for c in range(chunks):
+        b.rollout_policy(tab, K, accounts=acc, step0=c * K)
+        for _ in range(K):
+            needs_reset = (a.buf["status"] & 1).bool()
+            _, r, te, tr, _ = a.step(tab(a.state).to(torch.int32))
+            took = live & ~needs_reset
+            reached |= took & (r > 0)
+            live &= ~(took & (te | tr))
+    for row in ("theta", "t", "state"):
+        assert torch.equal(getattr(a, row), getattr(b, row)), row
+    assert torch.equal(a.buf["status"], b.buf["status"]) and torch.equal(a.buf["rng_env"], b.buf["rng_env"]) and a.counters() == b.counters()
+    assert torch.equal(acc.alive.bool(), live)
+    length = acc.length.cpu().numpy()
+    want = np.where(reached.cpu().numpy(), 1.0 * disc[np.maximum(length, 1) - 1], 0.0)
+    np.testing.assert_array_equal(acc.ret.cpu().numpy(), want)
+    a.close(); b.close()
