@@ -141,7 +141,15 @@ def baseline_configs_at_own_size(dev, c1_step_us, c1_rollout_rate, n_c1):
     torch.cuda.synchronize()
     group_rollout_us = r0.elapsed_time(r1) * 1e3 / (8 * K)
     by = W.WORKLOADS["pend"]["bytes_per_env_step"] + W.WORKLOADS["acro"]["bytes_per_env_step"]
-    rows["C4"] = {"envs": [pend.N, acro.N], "launch": "one nsg_step_group launch (" + step_group_kind([pend, acro]) + " unit)",
+    fused = {}
+    try:   # C4 as CLOSED loops with in-kernel policies: one nsg_rollout_policy launch per member per 64 steps
+        fp, fa = _fused_closed_loop_us(pend, "pend"), _fused_closed_loop_us(acro, "acro")
+        fused = {"fused_closed_loop_us_per_step": fp["fused_closed_loop_us_per_step"] + fa["fused_closed_loop_us_per_step"],
+                 "fused_closed_loop_members_us_per_step": [fp["fused_closed_loop_us_per_step"], fa["fused_closed_loop_us_per_step"]],
+                 "fused_closed_loop_policy": "a linear policy per member, evaluated in the kernel; two launches (one per member) per 64 steps"}
+    except Exception as e:
+        fused = {"fused_closed_loop_error": f"{type(e).__name__}: {e}"[:200]}
+    rows["C4"] = {**fused, "envs": [pend.N, acro.N], "launch": "one nsg_step_group launch (" + step_group_kind([pend, acro]) + " unit)",
                   "step_us": best, "bytes_per_env_pair_step": by, "frac_of_hbm_peak": frac(by, pend.N, best),
                   "env_steps_per_sec": (pend.N + acro.N) / (best * 1e-6),
                   "rollout_k64_us_per_step": group_rollout_us, "rollout_k64_env_steps_per_sec": (pend.N + acro.N) / (group_rollout_us * 1e-6),
@@ -162,8 +170,11 @@ def _fused_closed_loop_us(env, name, K=64, reps=8):
 
     if env.is_grid:
         pol, what = TabularPolicy(np.random.default_rng(0).integers(0, env.n_actions, size=env.cfg.nrow * env.cfg.ncol)), "a table over the cells"
-    else:
+    elif env.obs_dim == 4 and env.n_actions == 2:
         pol, what = LinearPolicy(np.array([[0.3, -0.8, -2.0, -1.1, 0.05], [-0.3, 0.8, 2.0, 1.1, -0.05]], dtype=np.float32)), "a linear policy on the observation"
+    else:   # any other classic-control env type: fixed pseudo-random weights of the right shape
+        rows = 1 if env.action_is_float else env.n_actions
+        pol, what = LinearPolicy(np.random.default_rng(0).normal(size=(rows, env.obs_dim + 1)).astype(np.float32)), "a linear policy on the observation"
     acc = EpisodeAccounts(env, gamma=None)
     for _ in range(3):
         env.rollout_policy(pol, K, accounts=acc)
