@@ -12,11 +12,30 @@
 #pragma once
 #include "nsgym_hip.h"
 #include "nsg_math.hip.h"
+#include "nsg_libm.hip.h"
 #include "nsg_rng.hip.h"
 
 namespace nsg {
 
 #define NSG_PI 3.141592653589793238462643383279502884
+
+// The integrators' sin / cos.  NSG_LIBM_EXACT 0 (the precompiled kernels, and every unit of a config without NSG_F_LIBM_EXACT): the
+// kernels' own fdlibm-derived sincos - < 1 ulp, float32 state within 1e-5 of the reference's until an unstable or chaotic plant has
+// amplified the last ulp (Acrobot, a balanced CartPole after ~270 steps: profiles/NOTEBOOK.md).  1 (the specialised units of a config
+// with NSG_F_LIBM_EXACT): libm's own algorithm with libm's own roundings (nsg_libm.hip.h) - what np.sin / np.cos return in the
+// reference, bit for bit, so that the float64 STATE of every classic-control env equals the reference's for as long as one cares to
+// step it.  The price (measured, profiles/NOTEBOOK.md): C1 +4 %, Pendulum +60 % per step - its angle spreads the lanes of a
+// wavefront over all of libm's argument ranges.
+#ifndef NSG_LIBM_EXACT
+#define NSG_LIBM_EXACT 0
+#endif
+#if NSG_LIBM_EXACT
+__device__ static const unsigned long long kLibmSincosTab[NSG_SINCOS_TAB_WORDS] = {
+#include "nsg_sincos_tab.inc"
+};
+__device__ __forceinline__ double env_sin(double x) { return nsg_sin_libm(LibmTab{reinterpret_cast<const double*>(kLibmSincosTab)}, x); }
+__device__ __forceinline__ double env_cos(double x) { return nsg_cos_libm(LibmTab{reinterpret_cast<const double*>(kLibmSincosTab)}, x); }
+#endif
 
 // Polynomial form of each env type's sincos (nsg_math.hip.h, nsg_sincos_t<POLY>).  Acrobot is bound by float64 vector-ALU issue
 // (15 sincos per step): the fused form with SGPR addends (2) takes its step from 59.6 to 55.0 us at 2^20 envs, its fused rollout
@@ -83,12 +102,20 @@ template <int ENV> __device__ __forceinline__ void env_obs(const double* s, floa
     for (int k = 0; k < 4; k++) o[k] = (float)s[k];
   } else if constexpr (ENV == NSG_ENV_PENDULUM) {
     double sn, cs;
+#if NSG_LIBM_EXACT
+    cs = env_cos(s[0]); sn = env_sin(s[0]);
+#else
     nsg_sincos_t<kLightPoly>(s[0], &sn, &cs);
+#endif
     o[0] = (float)cs; o[1] = (float)sn; o[2] = (float)s[1];
   } else if constexpr (ENV == NSG_ENV_ACROBOT) {
     double s0, c0, s1, c1;
+#if NSG_LIBM_EXACT
+    c0 = env_cos(s[0]); s0 = env_sin(s[0]); c1 = env_cos(s[1]); s1 = env_sin(s[1]);
+#else
     nsg_sincos_t<kAcroPoly>(s[0], &s0, &c0);
     nsg_sincos_t<kAcroPoly>(s[1], &s1, &c1);
+#endif
     o[0] = (float)c0; o[1] = (float)s0; o[2] = (float)c1; o[3] = (float)s1; o[4] = (float)s[2]; o[5] = (float)s[3];
   } else {
     o[0] = (float)s[0]; o[1] = (float)s[1];
@@ -143,12 +170,18 @@ __device__ __forceinline__ void acrobot_dsdt(const double* th, const double* y, 
   const double m1 = th[3], m2 = th[4], l1 = th[1], lc1 = th[5], lc2 = th[6], I1 = th[7], I2 = th[7], g = 9.8;
   const double theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
   double sin2, cos2;
+#if NSG_LIBM_EXACT
+  cos2 = env_cos(theta2); sin2 = env_sin(theta2);
+  const double cos12 = env_cos(theta1 + theta2 - NSG_PI / 2.0), cos1 = env_cos(theta1 - NSG_PI / 2);
+#else
   nsg_sincos_t<kAcroPoly>(theta2, &sin2, &cos2);
+  const double cos12 = nsg_cos_t<kAcroPoly>(theta1 + theta2 - NSG_PI / 2.0), cos1 = nsg_cos_t<kAcroPoly>(theta1 - NSG_PI / 2);
+#endif
   double d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * cos2) + I1 + I2;
   double d2 = m2 * (lc2 * lc2 + l1 * lc2 * cos2) + I2;
-  double phi2 = m2 * lc2 * g * nsg_cos_t<kAcroPoly>(theta1 + theta2 - NSG_PI / 2.0);
+  double phi2 = m2 * lc2 * g * cos12;
   double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * sin2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * sin2 +
-                (m1 * lc1 + m2 * l1) * g * nsg_cos_t<kAcroPoly>(theta1 - NSG_PI / 2) + phi2;
+                (m1 * lc1 + m2 * l1) * g * cos1 + phi2;
   double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * sin2 - phi2) /
                     (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
   double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
@@ -166,7 +199,11 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
     double x = s[0], x_dot = s[1], theta = s[2], theta_dot = s[3];
     double force = ai == 1 ? force_mag : -force_mag;
     double sintheta, costheta;
+#if NSG_LIBM_EXACT
+    costheta = env_cos(theta); sintheta = env_sin(theta);
+#else
     nsg_sincos(theta, &sintheta, &costheta);
+#endif
     double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
     double thetaacc = (gravity * sintheta - costheta * temp) /
                       (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
@@ -187,7 +224,12 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
     if (u > 2.0) u = 2.0;
     const double an = nsg_pymod_pos(t0 + NSG_PI, 2 * NSG_PI) - NSG_PI;  // angle_normalize: ((x + pi) % (2 pi)) - pi [UPSTREAM]
     double costs = an * an + 0.1 * (thdot * thdot) + 0.001 * (u * u);
-    double newthdot = thdot + (3 * g / (2 * l) * nsg_sin_t<kLightPoly>(t0) + 3.0 / (m * (l * l)) * u) * dt;
+#if NSG_LIBM_EXACT
+    const double sin_t0 = env_sin(t0);
+#else
+    const double sin_t0 = nsg_sin_t<kLightPoly>(t0);
+#endif
+    double newthdot = thdot + (3 * g / (2 * l) * sin_t0 + 3.0 / (m * (l * l)) * u) * dt;
     if (newthdot < -8.0) newthdot = -8.0;
     if (newthdot > 8.0) newthdot = 8.0;
     double newth = t0 + newthdot * dt;
@@ -212,22 +254,33 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
 #pragma unroll
     for (int k = 0; k < 4; k++) ns[k] = y0[k] + dt / 6.0 * (k1[k] + 2 * k2[k] + 2 * k3[k] + k4[k]);
 #pragma unroll
-    for (int k = 0; k < 2; k++) {  // wrap(x, -pi, pi): bounded trip count (|dθ| <= 9π per 0.2 s step)
+    for (int k = 0; k < 2; k++) {  // wrap(x, -pi, pi) [UPSTREAM]: `while x > M: x = x - diff` - one rounded subtraction per turn, so the result
+      // is NOT fmod's and the turns have to be taken.  A healthy step needs at most two (|dθ| <= 9π per 0.2 s step); a step whose RK4 stages
+      // blew up (C4's LINK_MASS_2 growing: one env in 262 144 by step 114, 5131 rad = 817 turns) needs as many as the reference takes.  The
+      // bound is the kernel's exit condition for inf / NaN, where the reference's loop never returns
       const double diff = NSG_PI - -NSG_PI;
-      for (int it = 0; it < 64 && ns[k] > NSG_PI; it++) ns[k] = ns[k] - diff;
-      for (int it = 0; it < 64 && ns[k] < -NSG_PI; it++) ns[k] = ns[k] + diff;
+      for (int it = 0; it < (1 << 20) && ns[k] > NSG_PI; it++) ns[k] = ns[k] - diff;
+      for (int it = 0; it < (1 << 20) && ns[k] < -NSG_PI; it++) ns[k] = ns[k] + diff;
     }
     const double mv1 = 4 * NSG_PI, mv2 = 9 * NSG_PI;
     ns[2] = fmin(fmax(ns[2], -mv1), mv1);
     ns[3] = fmin(fmax(ns[3], -mv2), mv2);
 #pragma unroll
     for (int k = 0; k < 4; k++) s[k] = ns[k];
+#if NSG_LIBM_EXACT
+    bool term = (-env_cos(s[0]) - env_cos(s[1] + s[0])) > 1.0;
+#else
     bool term = (-nsg_cos_t<kAcroPoly>(s[0]) - nsg_cos_t<kAcroPoly>(s[1] + s[0])) > 1.0;
+#endif
     reward = term ? 0.0 : -1.0;
     return term;
   } else if constexpr (ENV == NSG_ENV_MOUNTAINCAR) {
     double position = s[0], velocity = s[1];
+#if NSG_LIBM_EXACT
+    velocity += (double)(ai - 1) * th[1] + env_cos(3 * position) * (-th[0]);
+#else
     velocity += (double)(ai - 1) * th[1] + nsg_cos_t<kLightPoly>(3 * position) * (-th[0]);
+#endif
     if (velocity < -0.07) velocity = -0.07;
     if (velocity > 0.07) velocity = 0.07;
     position += velocity;
@@ -241,7 +294,11 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
     double position = s[0], velocity = s[1];
     double a0 = (double)af;
     double force = fmin(fmax(a0, -1.0), 1.0);
+#if NSG_LIBM_EXACT
+    velocity += force * th[0] - 0.0025 * env_cos(3 * position);
+#else
     velocity += force * th[0] - 0.0025 * nsg_cos_t<kLightPoly>(3 * position);
+#endif
     if (velocity > 0.07) velocity = 0.07;
     if (velocity < -0.07) velocity = -0.07;
     position += velocity;

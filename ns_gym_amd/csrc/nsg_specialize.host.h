@@ -26,6 +26,8 @@
           "\"\n.byte 0\n.size " #sym ", .-" #sym "\n.popsection\n")
 NSG_EMBED(nsg_src_abi, "../../include/nsgym_hip.h");
 NSG_EMBED(nsg_src_math, "nsg_math.hip.h");
+NSG_EMBED(nsg_src_libm, "nsg_libm.hip.h");
+NSG_EMBED(nsg_src_sincos_tab, "../../include/nsg_sincos_tab.inc");
 NSG_EMBED(nsg_src_rng, "nsg_rng.hip.h");
 NSG_EMBED(nsg_src_theta, "nsg_theta.hip.h");
 NSG_EMBED(nsg_src_envs, "nsg_envs.hip.h");
@@ -33,8 +35,8 @@ NSG_EMBED(nsg_src_kernels, "nsg_kernels.hip.h");
 NSG_EMBED(nsg_src_rollout, "nsg_rollout.hip.h");
 #endif
 extern "C" {
-extern const char nsg_src_abi[], nsg_src_math[], nsg_src_rng[], nsg_src_theta[], nsg_src_envs[], nsg_src_kernels[],
-    nsg_src_rollout[];
+extern const char nsg_src_abi[], nsg_src_math[], nsg_src_libm[], nsg_src_sincos_tab[], nsg_src_rng[], nsg_src_theta[], nsg_src_envs[],
+    nsg_src_kernels[], nsg_src_rollout[];
 }
 
 namespace nsg_spec {
@@ -104,6 +106,7 @@ inline std::string spec_source(const nsg_config& cfg, bool full, bool resets_in_
       "typedef unsigned long size_t;\n"
       "#define NSG_SPEC_BUILD 1\n";
   if (resets_in_lane) s += "#define NSG_CARTPOLE_INLANE 1\n";   // batch-size policy of nsg_specialize (nsg_envs.hip.h)
+  if (cfg.flags & NSG_F_LIBM_EXACT) s += "#define NSG_LIBM_EXACT 1\n";   // the integrators' sin / cos: libm's, bit for bit (nsg_libm.hip.h)
   if (stream_state) s += "#ifndef NSG_STREAM_STATE\n#define NSG_STREAM_STATE 1\n#endif\n";   // likewise (nsg_rng.hip.h: stg)
   // a classic-control config without a table blob (no schedule bit table, no value list): the step kernel reads the ziggurat tables
   // where they are instead of staging them per workgroup (nsg_kernels.hip.h: stage_tables<DIRECT>)
@@ -332,11 +335,12 @@ inline std::vector<char> compile_source(const std::string& src, const char* arch
     err = "libhiprtc.so could not be loaded (config specialisation needs the ROCm runtime compiler)";
     return code;
   }
-  const char* headers[] = {nsg_src_abi, nsg_src_math, nsg_src_rng, nsg_src_theta, nsg_src_envs, nsg_src_kernels, nsg_src_rollout};
-  const char* names[] = {"nsgym_hip.h",    "nsg_math.hip.h",    "nsg_rng.hip.h",    "nsg_theta.hip.h",
-                         "nsg_envs.hip.h", "nsg_kernels.hip.h", "nsg_rollout.hip.h"};
+  const char* headers[] = {nsg_src_abi, nsg_src_math, nsg_src_libm, nsg_src_sincos_tab, nsg_src_rng, nsg_src_theta, nsg_src_envs, nsg_src_kernels,
+                           nsg_src_rollout};
+  const char* names[] = {"nsgym_hip.h",   "nsg_math.hip.h",  "nsg_libm.hip.h",    "nsg_sincos_tab.inc", "nsg_rng.hip.h",
+                         "nsg_theta.hip.h", "nsg_envs.hip.h", "nsg_kernels.hip.h", "nsg_rollout.hip.h"};
   rtcProgram prog = nullptr;
-  if (r->create(&prog, src.c_str(), "nsg_spec.hip", 7, headers, names) != 0) {
+  if (r->create(&prog, src.c_str(), "nsg_spec.hip", 9, headers, names) != 0) {
     err = "hiprtcCreateProgram failed";
     return code;
   }

@@ -153,7 +153,7 @@ namespace {
 
 uint64_t spec_source_hash() {
   uint64_t h1 = 0x9e3779b97f4a7c15ull;
-  for (const char* src : {nsg_src_abi, nsg_src_math, nsg_src_rng, nsg_src_theta, nsg_src_envs, nsg_src_kernels, nsg_src_rollout})
+  for (const char* src : {nsg_src_abi, nsg_src_math, nsg_src_libm, nsg_src_sincos_tab, nsg_src_rng, nsg_src_theta, nsg_src_envs, nsg_src_kernels, nsg_src_rollout})
     h1 = nsg_spec::fnv1a(src, strlen(src), h1);
   if (const char* e = getenv("NSG_SPEC_FLAGS")) h1 = nsg_spec::fnv1a(e, strlen(e), h1);  // extra compile options are part of the key
   if (nsg_spec::allow_spill()) h1 = nsg_spec::fnv1a("allow-spill", 11, h1);              // a diagnostic build never shares a cache entry
@@ -712,10 +712,20 @@ static int next_traversal(nsg_handle* h) {
   return alternate ? (int)(h->launches++ & 1u) : 0;
 }
 
+// NSG_F_LIBM_EXACT lives in the specialised units only (the precompiled kernels carry the fast sincos): a launch that would fall back to
+// them is refused instead of silently stepping in the other arithmetic.
+static int exact_needs_unit(const nsg_handle* h, const void* unit, const char* what) {
+  if ((h->host.cfg.flags & NSG_F_LIBM_EXACT) && !unit)
+    return fail(NSG_EUNSUPPORTED, "%s: this handle was created with NSG_F_LIBM_EXACT, which runs on its specialised unit only "
+                                  "(nsg_specialize first; it needs the runtime compiler or a prebuilt unit)", what);
+  return NSG_OK;
+}
+
 int nsg_step(nsg_handle* h, const void* actions_dev, void* stream) {
   if (!h) return fail(NSG_EINVAL, "handle is NULL");
   if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
   if (!actions_dev) return fail(NSG_EINVAL, "actions_dev is NULL");
+  if (int rc = exact_needs_unit(h, h->spec, "nsg_step")) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int grid = step_grid_for(h);
   const size_t lds = (size_t)lds_bytes_for(h->host.table_bytes, h->host.uses_normal, h->host.uses_exp);
@@ -756,6 +766,7 @@ int nsg_rollout(nsg_handle* h, const void* actions_dev, int32_t k_steps, const n
   if (!h) return fail(NSG_EINVAL, "handle is NULL");
   if (!h->bound) return fail(NSG_ENOTBOUND, "nsg_bind() has not been called");
   if (!actions_dev || k_steps <= 0) return fail(NSG_EINVAL, "bad rollout arguments");
+  if (int rc = exact_needs_unit(h, h->spec, "nsg_rollout")) return rc;
   nsg_rollout_out o;
   memset(&o, 0, sizeof(o));
   if (out) o = *out;
@@ -848,6 +859,7 @@ int nsg_rollout_policy(nsg_handle* h, const nsg_policy* pol, int32_t k_steps, co
     }
   }
   if (!launched) {
+    if (int rc = exact_needs_unit(h, nullptr, "nsg_rollout_policy")) return rc;
     if (h->host.simple_theta) {
       DISPATCH_ENV(e, hipLaunchKernelGGL((rollout_policy_kernel<E, false>), dim3(grid), dim3(kBlock), rollout_lds, s, h->dev, k_steps, o, pa));
     } else {
@@ -937,6 +949,7 @@ int nsg_resident_start(nsg_handle* h, const void* actions_dev, nsg_mailbox* mb_d
       return NSG_OK;
     }
   }
+  if (int rc = exact_needs_unit(h, nullptr, "nsg_resident_start")) return rc;
   if (h->host.simple_theta) {
     DISPATCH_ENV(h->host.cfg.env_type, hipLaunchKernelGGL((resident_kernel<E, false>), dim3(grid), dim3(kBlock), lds, s, h->dev, actions_dev, ra));
   } else {
@@ -1117,6 +1130,9 @@ static int check_group_members(nsg_handle* const* hs, int32_t n_handles) {
   for (int k = 0; k < n_handles; k++) {
     if (!hs[k] || !hs[k]->bound) return fail(NSG_ENOTBOUND, "group member %d is not bound", k);
     if (hs[k]->device != hs[0]->device) return fail(NSG_EINVAL, "group member %d lives on device %d, member 0 on device %d", k, hs[k]->device, hs[0]->device);
+    if (hs[k]->host.cfg.flags & NSG_F_LIBM_EXACT)
+      return fail(NSG_EUNSUPPORTED, "group member %d was created with NSG_F_LIBM_EXACT: such handles step on their own specialised unit (nsg_step / nsg_rollout), "
+                                    "heterogeneous launches carry the fast sincos only", k);
     for (int j = 0; j < k; j++)
       if (hs[j] == hs[k]) return fail(NSG_EINVAL, "group member %d is listed twice", k);
   }

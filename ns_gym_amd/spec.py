@@ -43,7 +43,7 @@ def compile_config(env, tunable_params: dict, **kwargs):
 
 def _compile_once(env, tunable_params: dict, *, change_notification=False, delta_change_notification=False,
                   in_sim_change=False, scalar_reward=True, persistent_params=False, track_returns=False, initial_prob_dist=None, modified_rewards=None, is_sim_env=False, terminal_cliff=False, violation_mask=False,
-                  table_horizon=None, horizon_factor=2, autoreset=True):
+                  table_horizon=None, horizon_factor=2, autoreset=True, libm_exact=False):
     from . import extension
 
     spec: BaseEnvSpec = from_gym_env(env)
@@ -83,6 +83,8 @@ def _compile_once(env, tunable_params: dict, *, change_notification=False, delta
         flags |= A.F_VIOLATION_MASK
     if not autoreset:
         flags |= A.F_NO_AUTORESET
+    if libm_exact and et.env_type not in A.GRID_ENVS:      # (the grid envs' path is integer arithmetic: nothing to choose)
+        flags |= A.F_LIBM_EXACT
     tables = TableBuilder()
     tables.nd = nd
     if is_fl:

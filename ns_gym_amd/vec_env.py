@@ -50,12 +50,18 @@ class VecNSEnv:
     def __init__(self, env, tunable_params: dict, num_envs: int, change_notification: bool = False,
                  delta_change_notification: bool = False, in_sim_change: bool = False, scalar_reward: bool = True,
                  persistent_params: bool = False, track_returns: bool = False, device=None, is_sim_env: bool = False,
-                 violation_mask: bool = False, specialize: bool | None = None, autoreset: bool = True, _compiled=None,
-                 **kwargs):
+                 violation_mask: bool = False, specialize: bool | None = None, autoreset: bool = True, libm_exact: bool = False,
+                 _compiled=None, **kwargs):
         """`specialize=True` compiles config-specialised step / rollout kernels for this batch (hiprtc, once per
         distinct configuration, ~0.6 s; the code objects persist in `NSG_SPEC_CACHE=<dir>`, default the user's cache directory): same results bit
         for bit, 10-35 % less time per step.  `False`: the precompiled generic kernels.  `None` (default): specialise
         batches of >= 65 536 envs when the runtime compiler is available, silently stay generic otherwise.
+
+        `libm_exact=True` (classic control): the integrators evaluate sin / cos with libm's own algorithm and roundings (glibc 2.35's FMA
+        build - what `np.sin` / `np.cos` resolve to in the reference), so the float64 state EQUALS the reference's, bit for bit, for
+        as long as the batch is stepped - also where an unstable or chaotic plant (a balanced CartPole, Acrobot) would otherwise
+        amplify the last ulp of the kernels' own < 1-ulp sincos into a different trajectory a few hundred steps later.  It runs on
+        the batch's specialised unit (implies `specialize=True`) and costs 4-60 % more time per step, by env type.
 
         `autoreset=True` (default): gymnasium's next-step vector autoreset - the step after an episode ended resets that env
         (reward 0, flags clear, relative_time 0, streams continue).  `autoreset=False`: nothing resets inside `step()`; a finished
@@ -75,7 +81,7 @@ class VecNSEnv:
                 env, tunable_params, change_notification=change_notification,
                 delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
                 scalar_reward=scalar_reward, persistent_params=persistent_params, track_returns=track_returns,
-                is_sim_env=is_sim_env, violation_mask=violation_mask, autoreset=autoreset, **kwargs)
+                is_sim_env=is_sim_env, violation_mask=violation_mask, autoreset=autoreset, libm_exact=libm_exact, **kwargs)
         else:
             # a planning copy (fork): the SOURCE's compiled configuration with the copy's own flags and TimeLimit.  Nothing is
             # compiled again - sampled schedules (CustomScheduler, user-defined subclasses: ns_gym_amd.extension) must be the very
@@ -90,7 +96,7 @@ class VecNSEnv:
         self._ctor = dict(env=env, tunable_params=tunable_params, num_envs=num_envs, change_notification=change_notification,
                           delta_change_notification=delta_change_notification, in_sim_change=in_sim_change,
                           scalar_reward=scalar_reward, persistent_params=persistent_params, track_returns=track_returns,
-                          device=device, violation_mask=violation_mask, specialize=specialize, autoreset=autoreset, **kwargs)
+                          device=device, violation_mask=violation_mask, specialize=specialize, autoreset=autoreset, libm_exact=libm_exact, **kwargs)
         self.tunable_params = tunable_params
         self.change_notification = change_notification
         self.delta_change_notification = delta_change_notification
@@ -98,6 +104,9 @@ class VecNSEnv:
         self.scalar_reward = scalar_reward
         self.persistent_params = persistent_params
         self.autoreset = bool(autoreset)
+        self.libm_exact = bool(self.cfg.flags & A.F_LIBM_EXACT)
+        if self.libm_exact:
+            specialize = True            # the exact arithmetic lives in the specialised units only
         self.frozen = False
         self.is_sim_env = bool(is_sim_env)
         self.has_reset = False

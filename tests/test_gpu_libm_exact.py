@@ -1,0 +1,135 @@
+"""`libm_exact=True` (NSG_F_LIBM_EXACT): the integrators evaluate sin / cos with libm's own algorithm and roundings
+(ns_gym_amd/csrc/nsg_libm.hip.h), so the float64 STATE of a classic-control batch equals the oracle's - and, the oracle's state
+being the reference's bit for bit (tests/test_oracle_vs_reference_live.py), the reference's - in every bit, for as long as it is
+stepped.  No tolerance and no allowance anywhere in this file: open loops with autoreset, a CLOSED loop on the unstable plant that
+separates the default arithmetic from libm's after ~270 steps (profiles/NOTEBOOK.md), Acrobot at C4's size over its full horizon."""
+import numpy as np
+import pytest
+
+from tests.util import TRAJ_SPECS, make_env_from_spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _vec(*a, **k):
+    from ns_gym_amd.vec_env import VecNSEnv
+
+    return VecNSEnv(*a, **k)
+
+
+def _orc(*a, **k):
+    from oracle.oracle import OracleVecEnv
+
+    return OracleVecEnv(*a, **k)
+
+
+def _same_state(env, orc, tag):
+    F = orc.a["phys"].shape[0]
+    got = env.phys.cpu().numpy()
+    assert np.array_equal(got.view(np.uint64), orc.a["phys"][:got.shape[0]].view(np.uint64)), tag + ": float64 state"
+    assert np.array_equal(env.state.cpu().numpy().view(np.uint32), orc.a["obs"].view(np.uint32)), tag + ": float32 observation"
+    assert np.array_equal(env.t.cpu().numpy(), orc.a["t"]), tag + ": t"
+    assert np.array_equal(env.theta.cpu().numpy().view(np.uint64), orc.a["theta"][:env.theta.shape[0]].view(np.uint64)), tag + ": theta"
+    assert np.array_equal(env.buf["reward"].cpu().numpy().view(np.uint32), orc.a["reward"].view(np.uint32)), tag + ": reward"
+    assert np.array_equal(env.buf["terminated"].cpu().numpy(), orc.a["terminated"]) and np.array_equal(env.buf["truncated"].cpu().numpy(), orc.a["truncated"]), tag
+
+
+@pytest.mark.parametrize("name,T", [("c1_cartpole_masspole_inc", 300), ("c2_cartpole_gravity_rw", 300), ("cartpole_two_params", 200),
+                                    ("c4_pendulum_m_inc", 450), ("c4_acrobot_mass2_inc", 300), ("acrobot_constraints", 25), ("mountaincar", 450)])
+def test_open_loop_state_equals_oracle_bit_for_bit(name, T):
+    # (acrobot_constraints: short - its drifting link parameters blow RK4 up after ~40 steps, and gymnasium's unbounded wrap() loop, which the
+    # oracle restates as written, then never returns)
+    import torch
+
+    from tests.golden.make_golden import make_actions
+
+    spec = TRAJ_SPECS[name]
+    n = 4096
+    env = make_env_from_spec(_vec, spec, n=n, libm_exact=True)
+    assert env.libm_exact and env.specialized
+    orc = make_env_from_spec(_orc, spec, n=n)
+    env.reset(seed=21); orc.reset(seed=21)
+    acts = make_actions(spec["env_id"], T, n)
+    for k in range(T):
+        env.step(torch.from_numpy(acts[k]).cuda())
+        orc.step(acts[k])
+        if k % 25 == 24 or k == T - 1:
+            _same_state(env, orc, f"{name} step {k}")
+    # the fused rollout and the fused policy rollout are the same arithmetic
+    if T >= 100:
+        env.rollout(torch.from_numpy(acts[:40]).cuda(), record=("reward",))
+        for k in range(40):
+            orc.step(acts[k])
+        _same_state(env, orc, f"{name} after a fused rollout")
+    env.close()
+
+
+def test_closed_loop_on_the_unstable_plant_stays_exact():
+    """C2's config under the balancing linear policy: the case in which the default sincos and libm's part ways after ~270 steps
+    (0.4 % of the envs within 4000 steps).  With libm's arithmetic: every env, every row, every account, 3000 steps."""
+    from ns_gym_amd import _abi as A
+    from ns_gym_amd.policies import EpisodeAccounts, LinearPolicy
+
+    spec = TRAJ_SPECS["c2_cartpole_gravity_rw"]
+    n, K, chunks = 8192, 500, 6
+    env = make_env_from_spec(_vec, spec, n=n, libm_exact=True)
+    orc = make_env_from_spec(_orc, spec, n=n)
+    env.reset(seed=11); orc.reset(seed=11)
+    Wm = np.array([[0.3, -0.8, -2.0, -1.1, 0.05], [-0.3, 0.8, 2.0, 1.1, -0.05]], dtype=np.float32)
+    pol = LinearPolicy(Wm)
+    acc = EpisodeAccounts(env, gamma=None)
+    oacc = {"ret": np.zeros(n), "length": np.zeros(n, dtype=np.int32), "alive": np.ones(n, dtype=np.uint8), "discount": None}
+    for c in range(chunks):
+        out = env.rollout_policy(pol, K, accounts=acc, step0=c * K, record_actions=True)
+        oacts, _, _ = orc.rollout_policy(A.NSG_POL_LINEAR, K, data=Wm, step0=c * K, accounts=oacc)
+        assert np.array_equal(out["actions"].cpu().numpy(), oacts), f"chunk {c}: actions"
+        _same_state(env, orc, f"closed loop after {(c + 1) * K} steps")
+        assert np.array_equal(acc.ret.cpu().numpy(), oacc["ret"]) and np.array_equal(acc.length.cpu().numpy(), oacc["length"])
+    assert env.counters()["episodes"] >= n * 5      # the policy does keep most poles up to the TimeLimit, again and again
+    env.close()
+
+
+def test_acrobot_at_c4_size_full_horizon_without_an_allowance():
+    """C4's Acrobot member, 262 144 envs x 200 steps: the chaotic system for which the default arithmetic carries a stated allowance
+    (tests/test_gpu_fullsize.py).  With libm's sin / cos every float64 state of every env equals the oracle's, at every check."""
+    import os
+
+    import torch
+
+    from ns_gym_amd import make, workloads as W
+    from tests.golden.make_golden import make_actions
+
+    n, T = 1 << 18, 200
+    w = W.WORKLOADS["acro"]
+    env = W.build("acro", n, track_returns=False, libm_exact=True, seed=None)
+    orc = _orc(make(w["env_id"]), w["params"](), n, change_notification=True, delta_change_notification=True)
+    env.reset(seed=5); orc.reset(seed=5)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    acts = torch.randint(0, 3, (T, n), dtype=torch.int32, device="cuda", generator=g)
+    host = acts.cpu().numpy()
+    threads = min(16, os.cpu_count() or 1)
+    for k in range(T):
+        env.step(acts[k])
+        orc.step_mt(host[k], threads)
+        if k % 20 == 19:
+            _same_state(env, orc, f"acrobot step {k}")
+    env.close()
+
+
+def test_exact_mode_is_refused_where_it_cannot_run():
+    import torch
+
+    from ns_gym_amd._lib import NsgError
+    from ns_gym_amd import workloads as W
+    from ns_gym_amd.vec_env import step_group
+
+    p, a = W.build("pend", 4096, libm_exact=True), W.build("acro", 4096)
+    with pytest.raises(NsgError, match="NSG_F_LIBM_EXACT"):
+        step_group([p, a], [W.random_actions(p), W.random_actions(a)])
+    p.step(W.random_actions(p))      # on its own unit it steps
+    torch.cuda.synchronize()
+    p.close(); a.close()
+    # the grid envs have nothing to choose: the flag is not even set for them
+    fl = W.build("c3", 4096, libm_exact=True)
+    assert not fl.libm_exact
+    fl.close()

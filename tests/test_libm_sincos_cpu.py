@@ -1,0 +1,115 @@
+"""ns_gym_amd/csrc/nsg_libm.hip.h restates libm's sin / cos (glibc 2.35, the FMA build its x86-64 entry points dispatch to) - the
+functions np.sin / np.cos resolve to in the reference - with every rounding where libm has it.  The header is plain C++ under
+NSG_HD: compiled for the host here and compared with libm itself, bit for bit, over every argument range of the algorithm.
+(`sin` and `cos` are called through volatile pointers: gcc merges sin(x) + cos(x) into sincos(x), and glibc's sincos is NOT the
+FMA build - its results differ from sin / cos in the last bit for 0.06 % of arguments, which is also why the oracle is built with
+-fno-builtin-sin -fno-builtin-cos.)"""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SRC = r'''
+#include <cmath>
+#include <cstring>
+#include "%(root)s/ns_gym_amd/csrc/nsg_libm.hip.h"
+static const unsigned long long TABW[NSG_SINCOS_TAB_WORDS] = {
+#include "%(root)s/include/nsg_sincos_tab.inc"
+};
+static double (*volatile psin)(double) = sin;
+static double (*volatile pcos)(double) = cos;
+extern "C" {
+// returns how many of the n arguments give a sin or a cos that differs from libm's in any bit
+long t_compare(const double* x, long n, double* first_bad) {
+  double tab[NSG_SINCOS_TAB_WORDS];
+  memcpy(tab, TABW, sizeof(tab));
+  const nsg::LibmTab tb{tab};
+  long bad = 0;
+  for (long i = 0; i < n; i++) {
+    const double s = nsg::nsg_sin_libm(tb, x[i]), c = nsg::nsg_cos_libm(tb, x[i]), ls = psin(x[i]), lc = pcos(x[i]);
+    if (memcmp(&s, &ls, 8) || memcmp(&c, &lc, 8)) { if (!bad) *first_bad = x[i]; bad++; }
+  }
+  return bad;
+}
+long t_merged_sincos_differs(const double* x, long n) {   // what gcc's sincos() merge would have compared against
+  long bad = 0;
+  for (long i = 0; i < n; i++) { double s, c; sincos(x[i], &s, &c); const double ls = psin(x[i]), lc = pcos(x[i]); if (s != ls || c != lc) bad++; }
+  return bad;
+}
+}
+''' % {"root": ROOT}
+
+
+@pytest.fixture(scope="module")
+def m():
+    d = tempfile.mkdtemp()
+    src, so = os.path.join(d, "m.cpp"), os.path.join(d, "m.so")
+    open(src, "w").write(SRC)
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-mfma", "-fPIC", "-shared", "-o", so, src])
+    lib = C.CDLL(so)
+    lib.t_compare.restype = C.c_long
+    lib.t_merged_sincos_differs.restype = C.c_long
+    return lib
+
+
+def _bad(m, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    first = C.c_double(0.0)
+    n = m.t_compare(x.ctypes.data_as(C.c_void_p), C.c_long(x.size), C.byref(first))
+    return n, first.value
+
+
+def _fma_libm():
+    flags = open("/proc/cpuinfo").read()
+    return " fma " in flags and " avx2 " in flags
+
+
+@pytest.mark.skipif(not _fma_libm(), reason="libm dispatches to its FMA build only on CPUs with FMA + AVX2; the restatement is of that build")
+def test_sin_and_cos_equal_libm_bit_for_bit(m):
+    rng = np.random.default_rng(0)
+    total = 0
+    for r in (1e-9, 1e-6, 0.13, 0.3, 0.9, 2.5, 8.0, 100.0, 1e4, 1e6, 1.05e8):      # every branch of __sin / __cos below 105414336
+        x = rng.uniform(-r, r, 1_500_000)
+        n, first = _bad(m, x)
+        assert n == 0, (r, n, first)
+        total += x.size
+    # around the multiples of pi/2 and around every threshold of the algorithm
+    k = np.arange(-3000, 3001)[:, None] * (np.pi / 2)
+    near = k + np.arange(-40, 41)[None, :] * np.spacing(np.abs(k) + 1e-300)
+    edges = np.array([0.126, 0.855469, 2.426265, 2.0 ** -26, 2.0 ** -27, np.pi / 4, 1 / 128, 0.859375, 105414330.0])      # (the last range ends at 105414336.0 = high word 0x419921fb)
+    around = (edges[:, None] * np.array([1.0, -1.0])[None, :]).ravel()[:, None] + np.arange(-3000, 3001)[None, :] * np.spacing(np.abs(edges).repeat(2))[:, None]
+    for x in (near.ravel(), around.ravel()):
+        n, first = _bad(m, x)
+        assert n == 0, (n, first)
+        total += x.size
+    assert total > 1.6e7
+
+
+@pytest.mark.skipif(not _fma_libm(), reason="needs the FMA build")
+def test_gccs_sincos_merge_is_not_libms_sin_and_cos(m):
+    """Documents why the oracle is compiled with -fno-builtin-sin -fno-builtin-cos: sincos() differs from sin() / cos() in the last bit."""
+    x = np.random.default_rng(1).uniform(-3.0, 3.0, 2_000_000)
+    n = m.t_merged_sincos_differs(x.ctypes.data_as(C.c_void_p), C.c_long(x.size))
+    assert 100 < n < 20_000, n
+
+
+def test_table_is_libms_and_numpy_resolves_to_libm():
+    """The shipped table is the installed libm's own; NumPy's float64 sin / cos ARE libm's on this image (what the restatement rests on)."""
+    import math
+    import struct
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import extract_libm_sincos_table as E
+
+    out = os.path.join(tempfile.mkdtemp(), "tab.inc")
+    E.main(out)
+    assert open(out).read() == open(os.path.join(ROOT, "include", "nsg_sincos_tab.inc")).read()
+    x = np.random.default_rng(2).uniform(-40.0, 40.0, 100_000)
+    assert np.array_equal(np.sin(x), np.array([math.sin(v) for v in x])) and np.array_equal(np.cos(x), np.array([math.cos(v) for v in x]))
+    assert np.array_equal(np.array([float(np.cos(float(v))) for v in x[:20_000]]), np.array([math.cos(v) for v in x[:20_000]]))   # the scalar path gymnasium takes
