@@ -35,6 +35,18 @@ __device__ static const unsigned long long kLibmSincosTab[NSG_SINCOS_TAB_WORDS] 
 };
 __device__ __forceinline__ double env_sin(double x) { return nsg_sin_libm(LibmTab{reinterpret_cast<const double*>(kLibmSincosTab)}, x); }
 __device__ __forceinline__ double env_cos(double x) { return nsg_cos_libm(LibmTab{reinterpret_cast<const double*>(kLibmSincosTab)}, x); }
+// `x ** 2` on a float64 / float32 SCALAR is libm's pow / powf in the reference (Acrobot's _dsdt, Pendulum's step), not the product
+__device__ static const unsigned long long kLibmPowTab[NSG_POW_TAB_WORDS] = {
+#include "nsg_pow_tab.inc"
+};
+__device__ static const unsigned long long kLibmPowfTab[NSG_POWF_TAB_WORDS] = {
+#include "nsg_powf_tab.inc"
+};
+__device__ __forceinline__ double env_sq(double x) { return nsg_sq_libm(PowTab{kLibmPowTab}, x); }
+__device__ __forceinline__ double env_sqf(double x) { return (double)nsg_sqf_libm(PowTab{kLibmPowfTab}, (float)x); }
+#else
+__device__ __forceinline__ double env_sq(double x) { return x * x; }
+__device__ __forceinline__ double env_sqf(double x) { return x * x; }
 #endif
 
 // Polynomial form of each env type's sincos (nsg_math.hip.h, nsg_sincos_t<POLY>).  Acrobot is bound by float64 vector-ALU issue
@@ -177,13 +189,14 @@ __device__ __forceinline__ void acrobot_dsdt(const double* th, const double* y, 
   nsg_sincos_t<kAcroPoly>(theta2, &sin2, &cos2);
   const double cos12 = nsg_cos_t<kAcroPoly>(theta1 + theta2 - NSG_PI / 2.0), cos1 = nsg_cos_t<kAcroPoly>(theta1 - NSG_PI / 2);
 #endif
-  double d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * cos2) + I1 + I2;
-  double d2 = m2 * (lc2 * lc2 + l1 * lc2 * cos2) + I2;
+  const double lc2sq = env_sq(lc2);
+  double d1 = m1 * env_sq(lc1) + m2 * (env_sq(l1) + lc2sq + 2 * l1 * lc2 * cos2) + I1 + I2;
+  double d2 = m2 * (lc2sq + l1 * lc2 * cos2) + I2;
   double phi2 = m2 * lc2 * g * cos12;
-  double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * sin2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * sin2 +
+  double phi1 = -m2 * l1 * lc2 * env_sq(dtheta2) * sin2 - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * sin2 +
                 (m1 * lc1 + m2 * l1) * g * cos1 + phi2;
-  double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * sin2 - phi2) /
-                    (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+  double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * env_sq(dtheta1) * sin2 - phi2) /
+                    (m2 * lc2sq + I2 - env_sq(d2) / d1);
   double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
   d[0] = dtheta1; d[1] = dtheta2; d[2] = ddtheta1; d[3] = ddtheta2;
 }
@@ -223,13 +236,13 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
     if (u < -2.0) u = -2.0;
     if (u > 2.0) u = 2.0;
     const double an = nsg_pymod_pos(t0 + NSG_PI, 2 * NSG_PI) - NSG_PI;  // angle_normalize: ((x + pi) % (2 pi)) - pi [UPSTREAM]
-    double costs = an * an + 0.1 * (thdot * thdot) + 0.001 * (u * u);
+    double costs = env_sq(an) + 0.1 * env_sq(thdot) + 0.001 * env_sqf(u);   // `u ** 2`: a float32 scalar power upstream
 #if NSG_LIBM_EXACT
     const double sin_t0 = env_sin(t0);
 #else
     const double sin_t0 = nsg_sin_t<kLightPoly>(t0);
 #endif
-    double newthdot = thdot + (3 * g / (2 * l) * sin_t0 + 3.0 / (m * (l * l)) * u) * dt;
+    double newthdot = thdot + (3 * g / (2 * l) * sin_t0 + 3.0 / (m * env_sq(l)) * u) * dt;
     if (newthdot < -8.0) newthdot = -8.0;
     if (newthdot > 8.0) newthdot = 8.0;
     double newth = t0 + newthdot * dt;
@@ -254,14 +267,7 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
 #pragma unroll
     for (int k = 0; k < 4; k++) ns[k] = y0[k] + dt / 6.0 * (k1[k] + 2 * k2[k] + 2 * k3[k] + k4[k]);
 #pragma unroll
-    for (int k = 0; k < 2; k++) {  // wrap(x, -pi, pi) [UPSTREAM]: `while x > M: x = x - diff` - one rounded subtraction per turn, so the result
-      // is NOT fmod's and the turns have to be taken.  A healthy step needs at most two (|dθ| <= 9π per 0.2 s step); a step whose RK4 stages
-      // blew up (C4's LINK_MASS_2 growing: one env in 262 144 by step 114, 5131 rad = 817 turns) needs as many as the reference takes.  The
-      // bound is the kernel's exit condition for inf / NaN, where the reference's loop never returns
-      const double diff = NSG_PI - -NSG_PI;
-      for (int it = 0; it < (1 << 20) && ns[k] > NSG_PI; it++) ns[k] = ns[k] - diff;
-      for (int it = 0; it < (1 << 20) && ns[k] < -NSG_PI; it++) ns[k] = ns[k] + diff;
-    }
+    for (int k = 0; k < 2; k++) ns[k] = nsg_wrap_pi(ns[k]);   // wrap(x, -pi, pi) [UPSTREAM]: rounded turn by turn (nsg_math.hip.h)
     const double mv1 = 4 * NSG_PI, mv2 = 9 * NSG_PI;
     ns[2] = fmin(fmax(ns[2], -mv1), mv1);
     ns[3] = fmin(fmax(ns[3], -mv2), mv2);
@@ -308,7 +314,7 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
     bool term = position >= 0.45 && velocity >= 0;
     double r = 0;
     if (term) r = 100.0;
-    r -= (a0 * a0) * 0.1;
+    r -= env_sq(a0) * 0.1;   // math.pow(action[0], 2)
     s[0] = (double)(float)position; s[1] = (double)(float)velocity;  // state stored as float32 upstream
     reward = r;
     return term;

@@ -138,4 +138,105 @@ NSG_HD double nsg_cos_libm(const LibmTab tb, double x) {
   return c;
 }
 
+// ---- x ** 2 ----------------------------------------------------------------------------------------------------------------------
+// gymnasium writes Acrobot's and Pendulum's squares as `x ** 2` on float64 SCALARS; NumPy's scalar power and CPython's float power
+// both call libm's pow(x, 2.0) [UPSTREAM glibc 2.35 sysdeps/ieee754/dbl-64/e_pow.c, from ARM's optimized-routines: log_inline,
+// exp_inline], which is within 0.52 ulp but not always the correctly rounded product: 0.08 % of arguments differ from x * x in the
+// last bit (np.square and array ** 2 ARE the product - CartPole uses those).  This is pow's main path specialised to y = 2, with
+// every fused multiply-add where the image's libm.so.6 (__pow_fma) has one; tools/extract_libm_pow_tables.py documents the tables.
+// Valid for 2^-368 <= |x| < 2^368 (there |2 log|x|| < 512 and pow takes no special case but x = +-1); outside it answers x * x,
+// which IS pow's answer for 0, inf and NaN, and which no integrator's state reaches otherwise.
+#define NSG_POW_TAB_WORDS 657
+
+struct PowTab {
+  const unsigned long long* w;   // NSG_POW_TAB_WORDS bit patterns, layout in include/nsg_pow_tab.inc
+};
+
+NSG_HD double nsg_sq_libm(const PowTab tb, double x) {
+  const unsigned long long* W = tb.w;
+  const unsigned long long ix = (unsigned long long)lm_bits(x) & 0x7fffffffffffffffULL;
+  const unsigned top = (unsigned)(ix >> 52);
+  if (top - 655u >= 736u) return x * x;
+  // log_inline(ix): |x| = 2^k z, z in [OFF, 2 OFF), subinterval i of 128; log|x| = lhi + llo
+  const unsigned long long tmp = ix - 0x3fe6955500000000ULL;
+  const int i = (int)((tmp >> 45) & 127u);
+  const double kd = (double)(int)((long long)tmp >> 52);
+  const double z = lm_from_bits(ix - (tmp & 0xfff0000000000000ULL));
+  const double ln2hi = lm_from_bits(W[0]), ln2lo = lm_from_bits(W[1]);
+  const double invc = lm_from_bits(W[17 + 3 * i]), logc = lm_from_bits(W[18 + 3 * i]), logctail = lm_from_bits(W[19 + 3 * i]);
+  const double t1 = __builtin_fma(kd, ln2hi, logc);
+  const double r = __builtin_fma(z, invc, -1.0);
+  const double ar = r * lm_from_bits(W[2]);
+  const double lo1 = __builtin_fma(kd, ln2lo, logctail);
+  const double p12 = __builtin_fma(r, lm_from_bits(W[4]), lm_from_bits(W[3]));
+  const double p34 = __builtin_fma(r, lm_from_bits(W[6]), lm_from_bits(W[5]));
+  const double t2 = r + t1;
+  const double ar2 = r * ar;
+  const double ar3 = r * ar2;
+  const double lo3 = __builtin_fma(ar, r, -ar2);
+  const double lo2 = (t1 - t2) + r;
+  const double p56 = __builtin_fma(r, lm_from_bits(W[8]), lm_from_bits(W[7]));
+  const double hi = t2 + ar2;
+  const double lo4 = (t2 - hi) + ar2;
+  const double pp = __builtin_fma(ar2, __builtin_fma(p56, ar2, p34), p12);
+  const double lo = __builtin_fma(pp, ar3, ((lo1 + lo2) + lo3) + lo4);
+  const double lhi = hi + lo;
+  const double llo = (hi - lhi) + lo;
+  // y log|x| = ehi + elo, y = 2
+  const double ehi = 2.0 * lhi;
+  const double elo = __builtin_fma(2.0, llo, __builtin_fma(lhi, 2.0, -ehi));
+  // exp_inline(ehi, elo)
+  const unsigned abstop = (unsigned)((unsigned long long)lm_bits(ehi) >> 52) & 0x7ffu;
+  if (abstop - 0x3c9u >= 0x3fu) return 1.0 + ehi;   // |ehi| < 2^-54 (x = +-1; the range check above excludes |ehi| >= 512)
+  const double shift = lm_from_bits(W[10]);
+  const double kk = __builtin_fma(ehi, lm_from_bits(W[9]), shift);
+  const unsigned long long ki = (unsigned long long)lm_bits(kk);
+  const double kn = kk - shift;
+  double rr = __builtin_fma(kn, lm_from_bits(W[12]), __builtin_fma(kn, lm_from_bits(W[11]), ehi));
+  rr = elo + rr;
+  const int j = 2 * (int)(ki & 127u);
+  const double tail = lm_from_bits(W[401 + j]);
+  const double scale = lm_from_bits(W[402 + j] + (ki << 45));
+  const double c23 = __builtin_fma(rr, lm_from_bits(W[14]), lm_from_bits(W[13]));
+  const double tr = rr + tail;
+  const double r2 = rr * rr;
+  const double c45 = __builtin_fma(rr, lm_from_bits(W[16]), lm_from_bits(W[15]));
+  const double u = __builtin_fma(c23, r2, tr);
+  const double v = __builtin_fma(c45, r2 * r2, u);
+  return __builtin_fma(v, scale, scale);
+}
+
+// float32 x ** 2: powf(x, 2.0f) [UPSTREAM glibc 2.35 sysdeps/ieee754/flt-32/e_powf.c, __powf_fma] - Pendulum's `u ** 2`, a float32
+// scalar power in the reference.  log2 by a 16-entry table and a degree-4 polynomial in float64, exp2 by a 32-entry table and a
+// degree-3 polynomial, ONE rounding to float32 at the end (0.09 % of arguments differ from the float32 product).  Valid for
+// 2^-62 <= |x| < 2^62; outside it answers x * x (pow's answer for 0, inf, NaN; the clipped torque is within [-2, 2]).
+#define NSG_POWF_TAB_WORDS 73
+
+NSG_HD float nsg_sqf_libm(const PowTab tb, float x) {
+  const unsigned long long* W = tb.w;
+  const unsigned ix = __builtin_bit_cast(unsigned, x) & 0x7fffffffu;
+  if ((ix >> 23) - 65u >= 124u) return x * x;
+  const unsigned tmp = ix - 0x3f330000u;
+  const int i = (int)((tmp >> 19) & 15u);
+  const unsigned top = tmp & 0xff800000u;
+  const double z = (double)__builtin_bit_cast(float, ix - top);
+  const double k = (double)((int)top >> 23);
+  const double r = __builtin_fma(z, lm_from_bits(W[36 + 2 * i]), -1.0);
+  const double y0 = k + lm_from_bits(W[37 + 2 * i]);
+  const double p01 = __builtin_fma(r, lm_from_bits(W[68]), lm_from_bits(W[69]));
+  const double p23 = __builtin_fma(r, lm_from_bits(W[70]), lm_from_bits(W[71]));
+  const double r2 = r * r;
+  const double q = __builtin_fma(r, lm_from_bits(W[72]), y0);
+  const double logx = __builtin_fma(p01, r2 * r2, __builtin_fma(r2, p23, q));
+  const double ylogx = 2.0 * logx;
+  const double shift = lm_from_bits(W[32]);
+  const double kd = ylogx + shift;
+  const unsigned long long ki = (unsigned long long)lm_bits(kd);
+  const double rr = ylogx - (kd - shift);
+  const double s = lm_from_bits(W[ki & 31u] + (ki << 47));
+  const double zz = __builtin_fma(rr, lm_from_bits(W[33]), lm_from_bits(W[34]));
+  const double yy = __builtin_fma(rr, lm_from_bits(W[35]), 1.0);
+  return (float)(__builtin_fma(zz, rr * rr, yy) * s);
+}
+
 }  // namespace nsg

@@ -177,6 +177,34 @@ NSG_HD double nsg_pymod_pos(double x, double m) {
   return r;
 }
 
+// gymnasium's wrap(x, -pi, pi) [UPSTREAM acrobot.py wrap]: `while x > M: x = x - diff`, `while x < m: x = x + diff` with diff = 2 pi - ONE
+// ROUNDED subtraction per turn, so the result is not fmod's and depends on the turns taken.  A healthy Acrobot step needs at most
+// two; a step whose RK4 stages blew up (C4's LINK_MASS_2 growing: one env in 262 144 at step 114 came out at 5131 rad) needs as
+// many as the reference takes - 817 there, 1.6e8 at 1e9 rad.  Taking them one by one would let one lane hold its wavefront for
+// milliseconds, so the turns of a whole binade are taken at once, EXACTLY:
+//   in [2^e, 2^(e+1)) every double is a multiple of u = 2^(e-52); for a on that grid with a - D >= 2^e the rounded difference is
+//   a - RN_u(D) (round-to-nearest is translation invariant on the grid; a tie needs D mod u = u/2, which for D = 0x401921FB54442D18
+//   - lowest set bit 2^-47 - happens in [64, 128) only), so n turns inside one binade subtract n * RN_u(D): a product and a
+//   difference of grid multiples below 2^(e+1), both exact.  The last three turns of a binade, the crossing into the next and
+//   everything below 128 are taken as the reference takes them.
+// From 2^56 on, a - D == a: the reference's loop never returns; this one returns x as it came (so does it for inf; NaN fails the
+// loop's test in both).  tests/test_math_cpu.py compares it with the loop itself.
+NSG_HD double nsg_wrap_pi(double x) {
+  const double PI = 3.141592653589793, D = PI - -PI;
+  double a = __builtin_fabs(x);
+  if (!(a > PI)) return x;
+  if (!(a < 72057594037927936.0)) return x;   // 2^56
+  while (a >= 128.0) {     // one binade per pass, at most 49 passes
+    const double m = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, a) & 0xfff0000000000000ULL);   // 2^e
+    const double step = (m + D) - m;          // RN_u(D)
+    const double n = floor((a - m) / step) - 3.0;
+    if (n > 0.0) a = a - n * step;
+    while (a >= m) a = a - D;                 // <= 5 turns: leaves the binade the way the reference does
+  }
+  while (a > PI) a = a - D;                   // <= 21 turns
+  return x < 0.0 ? -a : a;
+}
+
 NSG_HD void nsg_sincos(double x, double* sn, double* cs) { nsg_sincos_t<NSG_SINCOS_FMA>(x, sn, cs); }
 NSG_HD double nsg_sin(double x) { double s, c; nsg_sincos(x, &s, &c); return s; }
 NSG_HD double nsg_cos(double x) { double s, c; nsg_sincos(x, &s, &c); return c; }

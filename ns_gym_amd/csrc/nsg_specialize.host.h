@@ -28,6 +28,8 @@ NSG_EMBED(nsg_src_abi, "../../include/nsgym_hip.h");
 NSG_EMBED(nsg_src_math, "nsg_math.hip.h");
 NSG_EMBED(nsg_src_libm, "nsg_libm.hip.h");
 NSG_EMBED(nsg_src_sincos_tab, "../../include/nsg_sincos_tab.inc");
+NSG_EMBED(nsg_src_pow_tab, "../../include/nsg_pow_tab.inc");
+NSG_EMBED(nsg_src_powf_tab, "../../include/nsg_powf_tab.inc");
 NSG_EMBED(nsg_src_rng, "nsg_rng.hip.h");
 NSG_EMBED(nsg_src_theta, "nsg_theta.hip.h");
 NSG_EMBED(nsg_src_envs, "nsg_envs.hip.h");
@@ -35,7 +37,7 @@ NSG_EMBED(nsg_src_kernels, "nsg_kernels.hip.h");
 NSG_EMBED(nsg_src_rollout, "nsg_rollout.hip.h");
 #endif
 extern "C" {
-extern const char nsg_src_abi[], nsg_src_math[], nsg_src_libm[], nsg_src_sincos_tab[], nsg_src_rng[], nsg_src_theta[], nsg_src_envs[],
+extern const char nsg_src_abi[], nsg_src_math[], nsg_src_libm[], nsg_src_sincos_tab[], nsg_src_pow_tab[], nsg_src_powf_tab[], nsg_src_rng[], nsg_src_theta[], nsg_src_envs[],
     nsg_src_kernels[], nsg_src_rollout[];
 }
 
@@ -335,12 +337,12 @@ inline std::vector<char> compile_source(const std::string& src, const char* arch
     err = "libhiprtc.so could not be loaded (config specialisation needs the ROCm runtime compiler)";
     return code;
   }
-  const char* headers[] = {nsg_src_abi, nsg_src_math, nsg_src_libm, nsg_src_sincos_tab, nsg_src_rng, nsg_src_theta, nsg_src_envs, nsg_src_kernels,
-                           nsg_src_rollout};
-  const char* names[] = {"nsgym_hip.h",   "nsg_math.hip.h",  "nsg_libm.hip.h",    "nsg_sincos_tab.inc", "nsg_rng.hip.h",
+  const char* headers[] = {nsg_src_abi, nsg_src_math, nsg_src_libm, nsg_src_sincos_tab, nsg_src_pow_tab, nsg_src_powf_tab, nsg_src_rng, nsg_src_theta,
+                           nsg_src_envs, nsg_src_kernels, nsg_src_rollout};
+  const char* names[] = {"nsgym_hip.h",   "nsg_math.hip.h",  "nsg_libm.hip.h",    "nsg_sincos_tab.inc", "nsg_pow_tab.inc", "nsg_powf_tab.inc", "nsg_rng.hip.h",
                          "nsg_theta.hip.h", "nsg_envs.hip.h", "nsg_kernels.hip.h", "nsg_rollout.hip.h"};
   rtcProgram prog = nullptr;
-  if (r->create(&prog, src.c_str(), "nsg_spec.hip", 9, headers, names) != 0) {
+  if (r->create(&prog, src.c_str(), "nsg_spec.hip", 11, headers, names) != 0) {
     err = "hiprtcCreateProgram failed";
     return code;
   }

@@ -153,7 +153,7 @@ namespace {
 
 uint64_t spec_source_hash() {
   uint64_t h1 = 0x9e3779b97f4a7c15ull;
-  for (const char* src : {nsg_src_abi, nsg_src_math, nsg_src_libm, nsg_src_sincos_tab, nsg_src_rng, nsg_src_theta, nsg_src_envs, nsg_src_kernels, nsg_src_rollout})
+  for (const char* src : {nsg_src_abi, nsg_src_math, nsg_src_libm, nsg_src_sincos_tab, nsg_src_pow_tab, nsg_src_powf_tab, nsg_src_rng, nsg_src_theta, nsg_src_envs, nsg_src_kernels, nsg_src_rollout})
     h1 = nsg_spec::fnv1a(src, strlen(src), h1);
   if (const char* e = getenv("NSG_SPEC_FLAGS")) h1 = nsg_spec::fnv1a(e, strlen(e), h1);  // extra compile options are part of the key
   if (nsg_spec::allow_spill()) h1 = nsg_spec::fnv1a("allow-spill", 11, h1);              // a diagnostic build never shares a cache entry

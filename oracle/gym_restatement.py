@@ -328,10 +328,10 @@ class PendulumEnv(Env):
         g, m, l, dt = self.g, self.m, self.l, self.dt
         u = float(np.clip(np.asarray(u, dtype=np.float64).reshape(-1), -self.max_torque, self.max_torque)[0])
         self.last_u = u
-        # (one line that is NOT the NumPy-1.26 reading the class docstring fixes: upstream `u` is still a float32 scalar here, so
-        # `u**2` rounds to float32 before the `0.001 *`; this file squares in float64.  |difference| <= 2.4e-10 on the cost, three
-        # orders below the float32 reward's resolution - the reward the wrappers return is float(...) of it, compared at 1e-5)
-        costs = angle_normalize(th) ** 2 + 0.1 * thdot**2 + 0.001 * (u**2)
+        # upstream `u` is still a float32 scalar here: `u**2` is a float32 scalar power (libm powf, rounded to float32) and, under the
+        # NumPy-1.26 promotion the class docstring fixes, `0.001 *` of it is a float64 product.  (`th`, `thdot` are float64 scalars,
+        # `l` a Python float: their `** 2` are libm pow, which is not always the correctly rounded product.)
+        costs = angle_normalize(th) ** 2 + 0.1 * thdot**2 + 0.001 * float(np.float32(u) ** 2)
         newthdot = thdot + (3 * g / (2 * l) * np.sin(th) + 3.0 / (m * l**2) * u) * dt
         newthdot = np.clip(newthdot, -self.max_speed, self.max_speed)
         newth = th + newthdot * dt

@@ -508,17 +508,53 @@ static double py_fmod_pos(double x, double m) { /* Python float % for m > 0 */
   return r;
 }
 
+/* `x ** 2` on a float64 SCALAR [UPSTREAM gymnasium acrobot.py _dsdt, pendulum.py step; NumPy scalar power and CPython float_pow both
+ * call libm's pow]: pow(x, 2.0) is within 0.52 ulp but not always the correctly rounded product - 0.08 % of arguments differ from
+ * x * x in the last bit (checked against NumPy here).  The file is built with -fno-builtin-pow -fno-builtin-powf so that gcc does not
+ * fold these calls into products.  (np.square and array ** 2 ARE products: CartPole.) */
+static double sq_pow(double x) { return pow(x, 2.0); }
+
+/* wrap(x, -pi, pi) [UPSTREAM gymnasium acrobot.py wrap]: `while x > M: x = x - diff; while x < m: x = x + diff` - the loop itself, one
+ * rounded subtraction per turn, for every |x| below 2^22 (667 544 turns).  A step whose RK4 stages blew up can come out far
+ * beyond that (the reference then loops for minutes, from 2^56 on for ever: x - diff == x).  So that a test run ends, larger
+ * values are first brought down binade by binade with the SAME result: inside [2^e, 2^(e+1)), e >= 7, every turn subtracts
+ * diff rounded to the binade's grid (exact argument in ns_gym_amd/csrc/nsg_math.hip.h, nsg_wrap_pi; tests/test_math_cpu.py
+ * compares both with the plain loop up to 3e10).  From 2^56 on, and for inf, x is returned as it came. */
+static double wrap_pi(double x) {
+  const double M = M_PI, m = -M_PI, diff = M - m;
+  double a = fabs(x);
+  if (!(a < 72057594037927936.0)) return x;
+  if (a >= 4194304.0) {
+    while (a >= 4194304.0) {
+      int e;
+      (void)frexp(a, &e);
+      const double floor2 = ldexp(1.0, e - 1); /* 2^e' <= a */
+      volatile double up = floor2 + diff;
+      const double step = up - floor2;
+      const double n = floor((a - floor2) / step) - 3.0;
+      if (n > 0.0) a = a - n * step;
+      while (a >= floor2) a = a - diff;
+    }
+    x = x < 0 ? -a : a;
+  }
+  while (x > M) x = x - diff;
+  while (x < m) x = x + diff;
+  return x;
+}
+
+double orc_wrap_pi(double x) { return wrap_pi(x); } /* (for tests/test_math_cpu.py) */
+
 static void acrobot_dsdt(const double* th, const double* y, double a, double* d) {
   /* AcrobotEnv._dsdt, "book" variant. th: dt L1 L2 M1 M2 C1 C2 MOI */
   double m1 = th[3], m2 = th[4], l1 = th[1], lc1 = th[5], lc2 = th[6], I1 = th[7], I2 = th[7], g = 9.8;
   double theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
-  double d1 = m1 * (lc1 * lc1) + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * cos(theta2)) + I1 + I2;
-  double d2 = m2 * (lc2 * lc2 + l1 * lc2 * cos(theta2)) + I2;
+  double d1 = m1 * sq_pow(lc1) + m2 * (sq_pow(l1) + sq_pow(lc2) + 2 * l1 * lc2 * cos(theta2)) + I1 + I2;
+  double d2 = m2 * (sq_pow(lc2) + l1 * lc2 * cos(theta2)) + I2;
   double phi2 = m2 * lc2 * g * cos(theta1 + theta2 - M_PI / 2.0);
-  double phi1 = -m2 * l1 * lc2 * (dtheta2 * dtheta2) * sin(theta2) - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * sin(theta2) +
+  double phi1 = -m2 * l1 * lc2 * sq_pow(dtheta2) * sin(theta2) - 2 * m2 * l1 * lc2 * dtheta2 * dtheta1 * sin(theta2) +
                 (m1 * lc1 + m2 * l1) * g * cos(theta1 - M_PI / 2) + phi2;
-  double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * (dtheta1 * dtheta1) * sin(theta2) - phi2) /
-                    (m2 * (lc2 * lc2) + I2 - (d2 * d2) / d1);
+  double ddtheta2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * sq_pow(dtheta1) * sin(theta2) - phi2) /
+                    (m2 * sq_pow(lc2) + I2 - sq_pow(d2) / d1);
   double ddtheta1 = -(d2 * ddtheta2 + phi1) / d1;
   d[0] = dtheta1; d[1] = dtheta2; d[2] = ddtheta1; d[3] = ddtheta2; d[4] = 0.0;
 }
@@ -552,8 +588,10 @@ static int env_step(int env, const double* th, double* s, int ai, float af, doub
       if (u < -2.0) u = -2.0;
       if (u > 2.0) u = 2.0;
       double an = py_fmod_pos(t0 + M_PI, 2 * M_PI) - M_PI;
-      double costs = an * an + 0.1 * (thdot * thdot) + 0.001 * (u * u);
-      double newthdot = thdot + (3 * g / (2 * l) * sin(t0) + 3.0 / (m * (l * l)) * u) * dt;
+      /* `u` is a float32 scalar there (np.clip(u, ...)[0]): `u ** 2` is powf, rounded to float32, before the float64 `0.001 *` (NumPy
+       * 1.26.4 scalar promotion, the reference's pin) */
+      double costs = sq_pow(an) + 0.1 * sq_pow(thdot) + 0.001 * (double)powf((float)u, 2.0f);
+      double newthdot = thdot + (3 * g / (2 * l) * sin(t0) + 3.0 / (m * sq_pow(l)) * u) * dt;
       if (newthdot < -8.0) newthdot = -8.0;
       if (newthdot > 8.0) newthdot = 8.0;
       double newth = t0 + newthdot * dt;
@@ -574,11 +612,7 @@ static int env_step(int env, const double* th, double* s, int ai, float af, doub
       acrobot_dsdt(th, y, y[4], k4);
       double ns[4];
       for (int k = 0; k < 4; k++) ns[k] = y0[k] + dt / 6.0 * (k1[k] + 2 * k2[k] + 2 * k3[k] + k4[k]);
-      for (int k = 0; k < 2; k++) { /* wrap(x, -pi, pi) */
-        double diff = M_PI - -M_PI;
-        while (ns[k] > M_PI) ns[k] = ns[k] - diff;
-        while (ns[k] < -M_PI) ns[k] = ns[k] + diff;
-      }
+      for (int k = 0; k < 2; k++) ns[k] = wrap_pi(ns[k]);
       double mv1 = 4 * M_PI, mv2 = 9 * M_PI;
       ns[2] = fmin(fmax(ns[2], -mv1), mv1);
       ns[3] = fmin(fmax(ns[3], -mv2), mv2);
@@ -614,7 +648,7 @@ static int env_step(int env, const double* th, double* s, int ai, float af, doub
       int term = position >= 0.45 && velocity >= 0;
       double r = 0;
       if (term) r = 100.0;
-      r -= (a0 * a0) * 0.1;
+      r -= pow(a0, 2.0) * 0.1; /* math.pow(action[0], 2) */
       s[0] = (double)(float)position; s[1] = (double)(float)velocity; /* state kept as float32 upstream */
       *reward = r;
       return term;

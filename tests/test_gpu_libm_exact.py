@@ -1,5 +1,5 @@
-"""`libm_exact=True` (NSG_F_LIBM_EXACT): the integrators evaluate sin / cos with libm's own algorithm and roundings
-(ns_gym_amd/csrc/nsg_libm.hip.h), so the float64 STATE of a classic-control batch equals the oracle's - and, the oracle's state
+"""`libm_exact=True` (NSG_F_LIBM_EXACT): the integrators evaluate sin / cos - and the `x ** 2` the reference hands to libm's pow -
+with libm's own algorithms and roundings (ns_gym_amd/csrc/nsg_libm.hip.h), so the float64 STATE of a classic-control batch equals the oracle's - and, the oracle's state
 being the reference's bit for bit (tests/test_oracle_vs_reference_live.py), the reference's - in every bit, for as long as it is
 stepped.  No tolerance and no allowance anywhere in this file: open loops with autoreset, a CLOSED loop on the unstable plant that
 separates the default arithmetic from libm's after ~270 steps (profiles/NOTEBOOK.md), Acrobot at C4's size over its full horizon."""
@@ -35,15 +35,21 @@ def _same_state(env, orc, tag):
 
 
 @pytest.mark.parametrize("name,T", [("c1_cartpole_masspole_inc", 300), ("c2_cartpole_gravity_rw", 300), ("cartpole_two_params", 200),
-                                    ("c4_pendulum_m_inc", 450), ("c4_acrobot_mass2_inc", 300), ("acrobot_constraints", 25), ("mountaincar", 450)])
+                                    ("c4_pendulum_m_inc", 450), ("pendulum_l_and_g", 300), ("c4_acrobot_mass2_inc", 300), ("acrobot_constraints", 25),
+                                    ("mountaincar", 450)])
 def test_open_loop_state_equals_oracle_bit_for_bit(name, T):
-    # (acrobot_constraints: short - its drifting link parameters blow RK4 up after ~40 steps, and gymnasium's unbounded wrap() loop, which the
-    # oracle restates as written, then never returns)
+    # (acrobot_constraints: short - its drifting link parameters blow RK4 up after ~40 steps, into angles of 1e60 rad and beyond, where
+    # gymnasium's wrap() loop never returns and there is no reference behaviour left to equal)
     import torch
 
     from tests.golden.make_golden import make_actions
 
-    spec = TRAJ_SPECS[name]
+    from tests.golden.make_golden import SCHEDULER_SPECS
+
+    spec = TRAJ_SPECS[name] if name in TRAJ_SPECS else {      # (`l ** 2` in the pendulum's acceleration is a scalar power too)
+        "env_id": "Pendulum-v1", "params": {"g": {"scheduler": SCHEDULER_SPECS["periodic3"], "update": ["RandomWalk", {"sigma": 2.0}]},
+                                            "l": {"scheduler": SCHEDULER_SPECS["continuous"], "update": ["OscillatingUpdate", {"delta": 0.05}]}},
+        "flags": {"change_notification": True, "delta_change_notification": True}}
     n = 4096
     env = make_env_from_spec(_vec, spec, n=n, libm_exact=True)
     assert env.libm_exact and env.specialized
@@ -90,8 +96,8 @@ def test_closed_loop_on_the_unstable_plant_stays_exact():
 
 
 def test_acrobot_at_c4_size_full_horizon_without_an_allowance():
-    """C4's Acrobot member, 262 144 envs x 200 steps: the chaotic system for which the default arithmetic carries a stated allowance
-    (tests/test_gpu_fullsize.py).  With libm's sin / cos every float64 state of every env equals the oracle's, at every check."""
+    """C4's Acrobot member, 262 144 envs x 500 steps (every episode to its TimeLimit, LINK_MASS_2 grown from 1 to 6): the chaotic system for which the default arithmetic carries a stated allowance
+    (tests/test_gpu_fullsize.py).  With libm's sin / cos / pow every float64 state of every env equals the oracle's, at every check."""
     import os
 
     import torch
@@ -99,7 +105,7 @@ def test_acrobot_at_c4_size_full_horizon_without_an_allowance():
     from ns_gym_amd import make, workloads as W
     from tests.golden.make_golden import make_actions
 
-    n, T = 1 << 18, 200
+    n, T = 1 << 18, 500
     w = W.WORKLOADS["acro"]
     env = W.build("acro", n, track_returns=False, libm_exact=True, seed=None)
     orc = _orc(make(w["env_id"]), w["params"](), n, change_notification=True, delta_change_notification=True)
@@ -111,7 +117,7 @@ def test_acrobot_at_c4_size_full_horizon_without_an_allowance():
     for k in range(T):
         env.step(acts[k])
         orc.step_mt(host[k], threads)
-        if k % 20 == 19:
+        if k % 50 == 49:
             _same_state(env, orc, f"acrobot step {k}")
     env.close()
 

@@ -21,6 +21,14 @@ SRC = r'''
 static const unsigned long long TABW[NSG_SINCOS_TAB_WORDS] = {
 #include "%(root)s/include/nsg_sincos_tab.inc"
 };
+static const unsigned long long POWW[NSG_POW_TAB_WORDS] = {
+#include "%(root)s/include/nsg_pow_tab.inc"
+};
+static const unsigned long long POWFW[NSG_POWF_TAB_WORDS] = {
+#include "%(root)s/include/nsg_powf_tab.inc"
+};
+static double (*volatile ppow)(double, double) = pow;
+static float (*volatile ppowf)(float, float) = powf;
 static double (*volatile psin)(double) = sin;
 static double (*volatile pcos)(double) = cos;
 extern "C" {
@@ -33,6 +41,27 @@ long t_compare(const double* x, long n, double* first_bad) {
   for (long i = 0; i < n; i++) {
     const double s = nsg::nsg_sin_libm(tb, x[i]), c = nsg::nsg_cos_libm(tb, x[i]), ls = psin(x[i]), lc = pcos(x[i]);
     if (memcmp(&s, &ls, 8) || memcmp(&c, &lc, 8)) { if (!bad) *first_bad = x[i]; bad++; }
+  }
+  return bad;
+}
+// x ** 2 on a float64 scalar: how many differ from libm's pow(x, 2.0); *not_product counts where pow itself is not x * x
+long t_compare_sq(const double* x, long n, double* first_bad, long* not_product) {
+  const nsg::PowTab tb{POWW};
+  long bad = 0;
+  for (long i = 0; i < n; i++) {
+    const double a = nsg::nsg_sq_libm(tb, x[i]), w = ppow(x[i], 2.0);
+    if (memcmp(&a, &w, 8) && !(a != a && w != w)) { if (!bad) *first_bad = x[i]; bad++; }
+    if (w != x[i] * x[i]) ++*not_product;
+  }
+  return bad;
+}
+long t_compare_sqf(const float* x, long n, float* first_bad, long* not_product) {
+  const nsg::PowTab tb{POWFW};
+  long bad = 0;
+  for (long i = 0; i < n; i++) {
+    const float a = nsg::nsg_sqf_libm(tb, x[i]), w = ppowf(x[i], 2.0f);
+    if (memcmp(&a, &w, 4) && !(a != a && w != w)) { if (!bad) *first_bad = x[i]; bad++; }
+    if (w != x[i] * x[i]) ++*not_product;
   }
   return bad;
 }
@@ -54,6 +83,8 @@ def m():
     lib = C.CDLL(so)
     lib.t_compare.restype = C.c_long
     lib.t_merged_sincos_differs.restype = C.c_long
+    lib.t_compare_sq.restype = C.c_long
+    lib.t_compare_sqf.restype = C.c_long
     return lib
 
 
@@ -113,3 +144,65 @@ def test_table_is_libms_and_numpy_resolves_to_libm():
     x = np.random.default_rng(2).uniform(-40.0, 40.0, 100_000)
     assert np.array_equal(np.sin(x), np.array([math.sin(v) for v in x])) and np.array_equal(np.cos(x), np.array([math.cos(v) for v in x]))
     assert np.array_equal(np.array([float(np.cos(float(v))) for v in x[:20_000]]), np.array([math.cos(v) for v in x[:20_000]]))   # the scalar path gymnasium takes
+
+
+@pytest.mark.skipif(not _fma_libm(), reason="needs the FMA build")
+def test_scalar_square_equals_libm_pow_bit_for_bit(m):
+    """`x ** 2` on a float64 scalar is libm's pow(x, 2.0) in the reference (checked below), not the product; nsg_sq_libm restates it."""
+    rng = np.random.default_rng(3)
+    total = nots = 0
+    for r in (1e-30, 1e-12, 1e-6, 0.1, 1.0, 1.0001, 2.0, 30.0, 1e3, 1e6, 1e30, 1e100):
+        x = rng.uniform(-r, r, 1_000_000)
+        first, notp = C.c_double(0.0), C.c_long(0)
+        n = m.t_compare_sq(x.ctypes.data_as(C.c_void_p), C.c_long(x.size), C.byref(first), C.byref(notp))
+        assert n == 0, (r, n, first.value)
+        total += x.size
+        nots += notp.value
+    assert 2e-4 < nots / total < 3e-3, nots          # pow(x, 2) is NOT x * x for ~0.08 % of arguments: why this function exists
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-200, 1e200, 5e-324, 2.0 ** -368, 2.0 ** 368, np.nextafter(2.0 ** 368, 0), np.nextafter(2.0 ** -368, 0)])
+    first, notp = C.c_double(0.0), C.c_long(0)
+    assert m.t_compare_sq(sp.ctypes.data_as(C.c_void_p), C.c_long(sp.size), C.byref(first), C.byref(notp)) == 0, first.value
+
+
+@pytest.mark.skipif(not _fma_libm(), reason="needs the FMA build")
+def test_float32_scalar_square_equals_libm_powf_bit_for_bit(m):
+    """Pendulum's `u ** 2` (a float32 scalar): every float32 of [-2, 2] down to 2^-20 in magnitude, and a sample of the rest."""
+    e = np.arange(107, 129, dtype=np.uint32)[:, None] << 23
+    pos = (e | np.arange(0, 1 << 23, dtype=np.uint32)[None, :]).ravel()
+    rest = ((np.arange(65, 189, dtype=np.uint32)[:, None] << 23) | np.arange(0, 1 << 23, 97, dtype=np.uint32)[None, :]).ravel()
+    nots = total = 0
+    for bits in (pos, pos | np.uint32(1 << 31), rest, rest | np.uint32(1 << 31)):
+        x = np.ascontiguousarray(bits).view(np.float32)
+        first, notp = C.c_float(0.0), C.c_long(0)
+        n = m.t_compare_sqf(x.ctypes.data_as(C.c_void_p), C.c_long(x.size), C.byref(first), C.byref(notp))
+        assert n == 0, (n, first.value)
+        total += x.size
+        nots += notp.value
+    assert 1e-4 < nots / total < 1e-2, nots
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, 1e-30, 1e30, 1e-45], dtype=np.float32)
+    first, notp = C.c_float(0.0), C.c_long(0)
+    assert m.t_compare_sqf(sp.ctypes.data_as(C.c_void_p), C.c_long(sp.size), C.byref(first), C.byref(notp)) == 0, first.value
+
+
+def test_pow_tables_are_libms_and_scalar_power_resolves_to_libm():
+    import ctypes
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import extract_libm_pow_tables as E
+
+    d = tempfile.mkdtemp()
+    E.main(os.path.join(d, "nsg_pow_tab.inc"))
+    for f in ("nsg_pow_tab.inc", "nsg_powf_tab.inc"):
+        assert open(os.path.join(d, f)).read() == open(os.path.join(ROOT, "include", f)).read(), f
+    libm = ctypes.CDLL("libm.so.6")
+    libm.pow.restype, libm.pow.argtypes = ctypes.c_double, [ctypes.c_double] * 2
+    libm.powf.restype, libm.powf.argtypes = ctypes.c_float, [ctypes.c_float] * 2
+    x = np.random.default_rng(4).uniform(-30.0, 30.0, 60_000)
+    want = np.array([libm.pow(float(v), 2.0) for v in x])
+    assert np.array_equal(np.array([float(np.float64(v) ** 2) for v in x]), want)      # NumPy's scalar power (Acrobot's dtheta ** 2)
+    assert np.array_equal(np.array([float(v) ** 2 for v in x]), want)                  # CPython's float power (lc1 ** 2)
+    assert (want != x * x).sum() > 5                                                   # ... and neither is the product
+    assert np.array_equal(np.square(x), x * x) and np.array_equal(x ** 2, x * x)       # np.square / array power ARE (CartPole)
+    xf = x.astype(np.float32)[:30_000]
+    assert np.array_equal(np.array([np.float32(v) ** 2 for v in xf], dtype=np.float32), np.array([libm.powf(float(v), 2.0) for v in xf], dtype=np.float32))

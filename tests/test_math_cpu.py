@@ -21,6 +21,12 @@ void t_sincos_poly2(const double* x, double* s, double* c, long n) { for (long i
 void t_pymod(const double* x, double m, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_pymod_pos(x[i], m); }
 void t_exp(const double* x, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_exp(x[i]); }
 void t_log1p(const double* x, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_log1p(x[i]); }
+void t_wrap(const double* x, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_wrap_pi(x[i]); }
+// gymnasium's wrap(x, -pi, pi) as written: the definition the closed form is measured against
+void t_wrap_loop(const double* x, double* y, long n) {
+  const double M = 3.141592653589793, m = -M, diff = M - m;
+  for (long i = 0; i < n; i++) { double v = x[i]; while (v > M) v = v - diff; while (v < m) v = v + diff; y[i] = v; }
+}
 }
 ''' % ROOT
 
@@ -102,3 +108,41 @@ def test_pymod_equals_python_float_mod_bit_for_bit(m):
         assert np.array_equal(y[:200_000], want)
         want_np = np.mod(xs, mod)                                     # NumPy's floor-mod agrees with Python's for floats
         assert np.array_equal(y, want_np) or np.array_equal(y[want_np != mod], want_np[want_np != mod])
+
+
+def _wrap_cases():
+    rng = np.random.default_rng(5)
+    parts = [rng.uniform(-r, r, c) for r, c in ((3.2, 200_000), (7, 200_000), (70, 200_000), (130, 200_000), (600, 200_000), (5000, 200_000),
+                                                 (1e5, 20_000), (1e6, 4000), (3e7, 300), (5e9, 6))]
+    # both sides of every binade edge, and arguments a few turns above one (where the bulk hands over to single turns)
+    e = np.arange(2, 25)
+    edges = (2.0 ** e)[:, None] + np.arange(-300, 301)[None, :] * (2.0 ** (e - 53))[:, None]
+    above = (2.0 ** np.arange(7, 23))[:, None] + np.arange(0, 400)[None, :] * (2 * np.pi) * (1 + 1e-13 * np.arange(0, 400)[None, :])
+    parts += [edges.ravel(), -edges.ravel(), above.ravel(), -above.ravel(), np.array([0.0, -0.0, np.pi, -np.pi, np.nextafter(np.pi, 4), -np.nextafter(np.pi, 4)])]
+    return np.concatenate(parts)
+
+
+def test_wrap_pi_equals_the_reference_loop_turn_for_turn(m):
+    """`nsg_wrap_pi` takes the turns of a whole binade at once; the result is the loop's, in every bit, up to 5e9 rad (8e8 turns)."""
+    x = _wrap_cases()
+    (got,), (want,) = _call(m.t_wrap, x), _call(m.t_wrap_loop, x)
+    bad = np.flatnonzero(got.view(np.uint64) != want.view(np.uint64))
+    assert bad.size == 0, (bad.size, x[bad[:3]], got[bad[:3]], want[bad[:3]])
+    # where the reference's loop never returns (x - diff == x) the argument comes back as it came; NaN fails the loop's test
+    for v in (2.0 ** 56, -2.0 ** 60, 1e300, np.inf, -np.inf):
+        assert _call(m.t_wrap, np.array([v]))[0][0] == v
+    assert np.isnan(_call(m.t_wrap, np.array([np.nan]))[0][0])
+
+
+def test_oracle_wrap_equals_the_reference_loop(m):
+    """The oracle runs the loop itself below 2^22 and brings larger values down binade by binade first: same results as the loop."""
+    import ctypes
+
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libnsgym_oracle.so"))
+    lib.orc_wrap_pi.restype = ctypes.c_double
+    lib.orc_wrap_pi.argtypes = [ctypes.c_double]
+    rng = np.random.default_rng(6)
+    x = np.concatenate([rng.uniform(-1e7, 1e7, 400), rng.uniform(-3e8, 3e8, 40), rng.uniform(-5e9, 5e9, 4), [4194304.0, -4194304.0, 4194303.9999, 8388608.0]])
+    (want,) = _call(m.t_wrap_loop, x)
+    got = np.array([lib.orc_wrap_pi(float(v)) for v in x])
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
