@@ -19,36 +19,6 @@ namespace nsg {
 
 #define NSG_PI 3.141592653589793238462643383279502884
 
-// The integrators' sin / cos.  NSG_LIBM_EXACT 0 (the precompiled kernels, and every unit of a config without NSG_F_LIBM_EXACT): the
-// kernels' own fdlibm-derived sincos - < 1 ulp, float32 state within 1e-5 of the reference's until an unstable or chaotic plant has
-// amplified the last ulp (Acrobot, a balanced CartPole after ~270 steps: profiles/NOTEBOOK.md).  1 (the specialised units of a config
-// with NSG_F_LIBM_EXACT): libm's own algorithm with libm's own roundings (nsg_libm.hip.h) - what np.sin / np.cos return in the
-// reference, bit for bit, so that the float64 STATE of every classic-control env equals the reference's for as long as one cares to
-// step it.  The price (measured, profiles/NOTEBOOK.md): C1 +4 %, Pendulum +60 % per step - its angle spreads the lanes of a
-// wavefront over all of libm's argument ranges.
-#ifndef NSG_LIBM_EXACT
-#define NSG_LIBM_EXACT 0
-#endif
-#if NSG_LIBM_EXACT
-__device__ static const unsigned long long kLibmSincosTab[NSG_SINCOS_TAB_WORDS] = {
-#include "nsg_sincos_tab.inc"
-};
-__device__ __forceinline__ double env_sin(double x) { return nsg_sin_libm(LibmTab{reinterpret_cast<const double*>(kLibmSincosTab)}, x); }
-__device__ __forceinline__ double env_cos(double x) { return nsg_cos_libm(LibmTab{reinterpret_cast<const double*>(kLibmSincosTab)}, x); }
-// `x ** 2` on a float64 / float32 SCALAR is libm's pow / powf in the reference (Acrobot's _dsdt, Pendulum's step), not the product
-__device__ static const unsigned long long kLibmPowTab[NSG_POW_TAB_WORDS] = {
-#include "nsg_pow_tab.inc"
-};
-__device__ static const unsigned long long kLibmPowfTab[NSG_POWF_TAB_WORDS] = {
-#include "nsg_powf_tab.inc"
-};
-__device__ __forceinline__ double env_sq(double x) { return nsg_sq_libm(PowTab{kLibmPowTab}, x); }
-__device__ __forceinline__ double env_sqf(double x) { return (double)nsg_sqf_libm(PowTab{kLibmPowfTab}, (float)x); }
-#else
-__device__ __forceinline__ double env_sq(double x) { return x * x; }
-__device__ __forceinline__ double env_sqf(double x) { return x * x; }
-#endif
-
 // Polynomial form of each env type's sincos (nsg_math.hip.h, nsg_sincos_t<POLY>).  Acrobot is bound by float64 vector-ALU issue
 // (15 sincos per step): the fused form with SGPR addends (2) takes its step from 59.6 to 55.0 us at 2^20 envs, its fused rollout
 // from 50.4 to 44.6 us per step, C4's mixed launch from 23.4 to 21.7 us, at unchanged occupancy.  Pendulum and the MountainCars

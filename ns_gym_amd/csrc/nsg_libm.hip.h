@@ -146,8 +146,6 @@ NSG_HD double nsg_cos_libm(const LibmTab tb, double x) {
 // every fused multiply-add where the image's libm.so.6 (__pow_fma) has one; tools/extract_libm_pow_tables.py documents the tables.
 // Valid for 2^-368 <= |x| < 2^368 (there |2 log|x|| < 512 and pow takes no special case but x = +-1); outside it answers x * x,
 // which IS pow's answer for 0, inf and NaN, and which no integrator's state reaches otherwise.
-#define NSG_POW_TAB_WORDS 657
-
 struct PowTab {
   const unsigned long long* w;   // NSG_POW_TAB_WORDS bit patterns, layout in include/nsg_pow_tab.inc
 };
@@ -238,5 +236,32 @@ NSG_HD float nsg_sqf_libm(const PowTab tb, float x) {
   const double yy = __builtin_fma(rr, lm_from_bits(W[35]), 1.0);
   return (float)(__builtin_fma(zz, rr * rr, yy) * s);
 }
+
+// ---- the units of a config with NSG_F_LIBM_EXACT -----------------------------------------------------------------------------------
+// NSG_LIBM_EXACT 0 (the precompiled kernels, and every unit of a config without the flag): the kernels' own fdlibm-derived sincos
+// (< 1 ulp) and plain products - float32 state within 1e-5 of the reference's until an unstable or chaotic plant has amplified the last
+// ulp (Acrobot, a balanced CartPole after ~270 steps: profiles/NOTEBOOK.md).  1: libm's own algorithms with libm's own roundings for
+// every sin / cos / scalar power of the integrators and of the θ-engine - what the reference's host evaluates, bit for bit, so that
+// the float64 STATE of every classic-control env equals the reference's for as long as one cares to step it.  The price is in
+// DESIGN.md section 4 (C1 +4 % per step ... Acrobot x 2.1).  (exp and log1p are libm's in every build: nsg_math.hip.h.)
+#ifndef NSG_LIBM_EXACT
+#define NSG_LIBM_EXACT 0
+#endif
+#if NSG_LIBM_EXACT
+__device__ static const unsigned long long kLibmSincosTab[NSG_SINCOS_TAB_WORDS] = {
+#include "nsg_sincos_tab.inc"
+};
+__device__ static const unsigned long long kLibmPowfTab[NSG_POWF_TAB_WORDS] = {
+#include "nsg_powf_tab.inc"
+};
+__device__ __forceinline__ double env_sin(double x) { return nsg_sin_libm(LibmTab{reinterpret_cast<const double*>(kLibmSincosTab)}, x); }
+__device__ __forceinline__ double env_cos(double x) { return nsg_cos_libm(LibmTab{reinterpret_cast<const double*>(kLibmSincosTab)}, x); }
+// `x ** 2` on a float64 / float32 SCALAR is libm's pow / powf in the reference (Acrobot's _dsdt, Pendulum's step), not the product
+__device__ __forceinline__ double env_sq(double x) { return nsg_sq_libm(PowTab{kNsgPowTab}, x); }
+__device__ __forceinline__ double env_sqf(double x) { return (double)nsg_sqf_libm(PowTab{kLibmPowfTab}, (float)x); }
+#else
+NSG_HD double env_sq(double x) { return x * x; }
+NSG_HD double env_sqf(double x) { return x * x; }
+#endif
 
 }  // namespace nsg

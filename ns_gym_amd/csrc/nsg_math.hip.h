@@ -215,10 +215,81 @@ template <int POLY> NSG_HD double nsg_sin_t(double x) { double s, c; nsg_sincos_
 
 namespace nsg {
 
-// ---- float64 exp / log1p with a small register footprint (fdlibm algorithms, < 1 ulp) -------
-// Used by the "full" θ-engine: ExponentialDecay / SigmoidTransition (np.exp, single_param.py:286,
-// 384) and the ziggurat wedge / tail tests of NumPy's normal sampler (exp, log1p).  The device
-// library's versions cost ~60 VGPRs more, which costs the RandomWalk kernels a wave of occupancy.
+// ---- float64 exp / log1p ------------------------------------------------------------------------------------------------------
+// Used by the "full" θ-engine: ExponentialDecay / SigmoidTransition (np.exp, single_param.py:286, 384) and by NumPy's samplers,
+// which run in C and call libm (the ziggurat's wedge tests: exp; its tails and geometric: log1p).  The device library's versions cost
+// ~60 VGPRs more, which costs the RandomWalk kernels a wave of occupancy.
+//   nsg_log1p      glibc 2.35's log1p [UPSTREAM sysdeps/ieee754/dbl-64/s_log1p.c] operation for operation, in every build: the
+//                  normal variates of a ziggurat tail and the geometric waits equal NumPy's in every bit (rounds 1-3 carried fdlibm's
+//                  original, equal to libm's for all but 0.08 % of arguments).
+//   nsg_exp_libm   glibc 2.35's exp [UPSTREAM e_exp.c, __exp_fma, from ARM's optimized-routines: 128-entry table, degree-5
+//                  polynomial] with every fused multiply-add where the image's libm.so.6 has one.  The table is __exp_data, extracted
+//                  from the image's libm by tools/extract_libm_pow_tables.py (words 401..656 of include/nsg_pow_tab.inc; the log
+//                  side of the same file serves nsg_sq_libm).  What nsg_exp IS in a unit built with NSG_LIBM_EXACT.
+//   nsg_exp_fdlibm fdlibm's exp (< 1 ulp), what nsg_exp is everywhere else (why: below).
+// tests/test_math_cpu.py holds nsg_log1p and nsg_exp_libm equal to libm itself, subnormal results and special values included.
+// (np.exp on a scalar or an array is NumPy's own SIMD kernel on an AVX-512 host, 1 ulp off libm's for 4.6 % of arguments: an
+// ExponentialDecay theta is host-dependent in the reference itself.  libm's is what the oracle - plain C - calls, and what a host
+// without AVX-512 gets.)
+#define NSG_POW_TAB_WORDS 657
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ static const unsigned long long kNsgPowTab[NSG_POW_TAB_WORDS] = {
+#else
+static const unsigned long long kNsgPowTab[NSG_POW_TAB_WORDS] = {
+#endif
+#include "nsg_pow_tab.inc"
+};
+
+NSG_HD double nsg_exp_libm(double x) {
+  // __exp_data's eight scalars as literals (words 9..16 of the table file; tests/test_math_cpu.py asserts they ARE those words): in
+  // registers they are scalar operands, as loads they were vector registers the RandomWalk kernels do not have to spare
+  const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p+52, NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47,
+               C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
+  const unsigned long long bx = __builtin_bit_cast(unsigned long long, x);
+  unsigned abstop = (unsigned)(bx >> 52) & 0x7ffu;
+  if (abstop - 0x3c9u >= 0x3fu) {
+    if ((int)(abstop - 0x3c9u) < 0) return 1.0 + x;                       // |x| < 2^-54
+    if (abstop >= 0x409u) {                                                 // |x| >= 1024, inf, NaN
+      if (bx == 0xfff0000000000000ULL) return 0.0;
+      if (abstop >= 0x7ffu) return 1.0 + x;
+      return (bx >> 63) ? 0.0 : __builtin_inf();
+    }
+    abstop = 0;                                                             // 512 <= |x| < 1024: the scale may leave the normal range
+  }
+  const double kk = __builtin_fma(x, InvLn2N, Shift);
+  const unsigned ki = (unsigned)__builtin_bit_cast(unsigned long long, kk);   // (the low word holds every bit that is used)
+  const double kn = kk - Shift;
+  const double r = __builtin_fma(kn, NegLn2loN, __builtin_fma(kn, NegLn2hiN, x));
+  const unsigned long long* T = kNsgPowTab + 401 + 2 * (ki & 127u);
+  const unsigned long long sbits = T[1] + ((unsigned long long)ki << 45);
+  const double tr = r + __builtin_bit_cast(double, T[0]);
+  const double r2 = r * r;
+  const double tmp = __builtin_fma(r2 * r2, __builtin_fma(r, C5, C4), __builtin_fma(__builtin_fma(r, C3, C2), r2, tr));
+  if (abstop == 0) {                                                        // specialcase()
+    if ((ki & 0x80000000u) == 0) {                                          // k > 0: the exponent of scale may have overflowed
+      const double scale = __builtin_bit_cast(double, sbits - (1009ULL << 52));
+      return 0x1p1009 * __builtin_fma(scale, tmp, scale);
+    }
+    const double scale = __builtin_bit_cast(double, sbits + (1022ULL << 52));   // k < 0: round once, in the subnormal range
+    const double st = scale * tmp;
+    double y = scale + st;
+    if (y < 1.0) {
+      double lo = (scale - y) + st;
+      const double hi = 1.0 + y;
+      lo = ((1.0 - hi) + y) + lo;
+      y = (hi + lo) - 1.0;
+      if (y == 0.0) y = 0.0;
+    }
+    return 0x1p-1022 * y;
+  }
+  const double scale = __builtin_bit_cast(double, sbits);
+  return __builtin_fma(scale, tmp, scale);
+}
+
+// fdlibm's exp (< 1 ulp; no table, 4-8 vector registers less than the one above inside the RandomWalk kernels - a wavefront of
+// occupancy for C2's fused rollout: 90 -> 98 VGPRs measured).  What every build WITHOUT NSG_LIBM_EXACT evaluates: there exp decides the
+// ziggurat's wedge test (an ulp of exp changes an accept / reject once in ~1e16 draws) and feeds ExponentialDecay / SigmoidTransition
+// thetas, compared at 1e-12.  A unit built with NSG_LIBM_EXACT evaluates libm's.
 NSG_HD double nsg_ldexp_norm(double y, int k) {  // y * 2^k for the k range exp() produces
   // two-step scaling keeps subnormal results correctly rounded once
   union { double d; unsigned long long u; } a;
@@ -237,7 +308,7 @@ NSG_HD double nsg_ldexp_norm(double y, int k) {  // y * 2^k for the k range exp(
   return y * a.d;
 }
 
-NSG_HD double nsg_exp(double x) {
+NSG_HD double nsg_exp_fdlibm(double x) {
   const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
                invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
                P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
@@ -256,44 +327,73 @@ NSG_HD double nsg_exp(double x) {
   return k == 0 ? y : nsg_ldexp_norm(y, k);
 }
 
+#ifndef NSG_LIBM_EXACT
+#define NSG_LIBM_EXACT 0
+#endif
+NSG_HD double nsg_exp(double x) {
+#if NSG_LIBM_EXACT
+  return nsg_exp_libm(x);
+#else
+  return nsg_exp_fdlibm(x);
+#endif
+}
+
 NSG_HD double nsg_log1p(double x) {
+  // glibc 2.35's log1p [UPSTREAM sysdeps/ieee754/dbl-64/s_log1p.c: fdlibm's algorithm with the polynomial split in four] operation for
+  // operation - the function NumPy's generators call (ziggurat tails, geometric) - so that the streams equal NumPy's in every bit:
+  // branch tests on the HIGH WORD as upstream has them (they are not the double comparisons they approximate), the |x| < 2^-29 and
+  // |f| < 2^-20 shortcuts, R = ((z Lp1 + z^2 (Lp2 + z Lp3)) + z^4 (Lp4 + z Lp5)) + z^6 (Lp6 + z Lp7).  The x86-64 build has no FMA
+  // variant of this function.  tests/test_math_cpu.py: equal to libm on 6 M arguments over every branch.
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
                Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
                Lp7 = 1.479819860511658591e-01;
-  if (x != x) return x;
-  if (x < -1.0) return __builtin_nan("");
-  if (x == -1.0) return -__builtin_inf();
-  if (x == __builtin_inf()) return x;
-  const double ax = fabs(x);
-  if (ax < 5.55111512312578270212e-17) return x;  // |x| < 2^-54
-  int k = 1;
+  const unsigned long long bx = __builtin_bit_cast(unsigned long long, x);
+  const int hx = (int)(bx >> 32), ax = hx & 0x7fffffff;
+  int k = 1, hu = 0;
   double f = x, c = 0.0;
-  if (x > -0.2928932188134524 && x < 0.41421356237309515) {
-    k = 0;  // sqrt(2)/2 - 1 < x < sqrt(2) - 1: no reduction
-  } else {
-    union { double d; unsigned long long u; } uu;
-    const double u1 = 1.0 + x;
-    uu.d = u1;
-    k = (int)((uu.u >> 52) & 0x7ff) - 1023;
-    // correction term for the rounding of 1 + x
-    c = (k > 0) ? 1.0 - (u1 - x) : x - (u1 - 1.0);
-    c /= u1;
-    unsigned long long m = uu.u & 0x000fffffffffffffULL;
-    if (m < 0x6a09e667f3bcdULL) {
-      uu.u = m | 0x3ff0000000000000ULL;  // normalise u
+  if (hx < 0x3FDA827A) {                       // x < 0.41422
+    if (ax >= 0x3ff00000) return x == -1.0 ? -__builtin_inf() : __builtin_nan("");
+    if (ax < 0x3e200000) return ax < 0x3c900000 ? x : x - x * x * 0.5;      // |x| < 2^-29 (2^-54)
+    if (hx > 0 || hx < (int)0xbfd2bec4) { k = 0; hu = 1; }                    // sqrt(2)/2 - 1 < x < sqrt(2) - 1, by high word
+  } else if (hx >= 0x7ff00000) {
+    return x + x;
+  }
+  if (k != 0) {
+    double u;
+    if (hx < 0x43400000) {
+      u = 1.0 + x;
+      hu = (int)(__builtin_bit_cast(unsigned long long, u) >> 32);
+      k = (hu >> 20) - 1023;
+      c = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);   // correction term for the rounding of 1 + x
+      c /= u;
+    } else {
+      u = x;
+      hu = hx;
+      k = (hu >> 20) - 1023;
+    }
+    hu &= 0x000fffff;
+    const unsigned long long lo = __builtin_bit_cast(unsigned long long, u) & 0xffffffffULL;
+    if (hu < 0x6a09e) {
+      u = __builtin_bit_cast(double, ((unsigned long long)(unsigned)(hu | 0x3ff00000) << 32) | lo);   // normalise u
     } else {
       k += 1;
-      uu.u = m | 0x3fe0000000000000ULL;  // normalise u/2
+      u = __builtin_bit_cast(double, ((unsigned long long)(unsigned)(hu | 0x3fe00000) << 32) | lo);   // normalise u/2
+      hu = (0x00100000 - hu) >> 2;
     }
-    f = uu.d - 1.0;
+    f = u - 1.0;
   }
   const double hfsq = 0.5 * f * f;
-  const double s = f / (2.0 + f);
-  const double z = s * s;
-  const double R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
-  if (k == 0) return f - (hfsq - s * (hfsq + R));
   const double kd = (double)k;
+  if (hu == 0) {                               // |f| < 2^-20
+    if (f == 0.0) return k == 0 ? 0.0 : kd * ln2_hi + (c + kd * ln2_lo);
+    const double R = hfsq * (1.0 - 0.66666666666666666 * f);
+    return k == 0 ? f - R : kd * ln2_hi - ((R - (kd * ln2_lo + c)) - f);
+  }
+  const double s = f / (2.0 + f);
+  const double z = s * s, z2 = z * z, z4 = z2 * z2, z6 = z4 * z2;
+  const double R = ((z * Lp1 + z2 * (Lp2 + z * Lp3)) + z4 * (Lp4 + z * Lp5)) + z6 * (Lp6 + z * Lp7);
+  if (k == 0) return f - (hfsq - s * (hfsq + R));
   return kd * ln2_hi - ((hfsq - (s * (hfsq + R) + (kd * ln2_lo + c))) - f);
 }
 

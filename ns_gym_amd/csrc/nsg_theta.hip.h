@@ -15,6 +15,7 @@
 #pragma once
 #include "nsgym_hip.h"
 #include "nsg_rng.hip.h"
+#include "nsg_libm.hip.h"
 
 namespace nsg {
 
@@ -113,7 +114,11 @@ __device__ inline double upd_scalar(const nsg_param_cfg& pc, const Tables& tb, c
     }
     case NSG_UPD_GEOMETRIC: return th * u[0];
     case NSG_UPD_EXPDECAY: if constexpr (FULL) return th * nsg_exp(-u[0] * td); else return th;
+#if NSG_LIBM_EXACT
+    case NSG_UPD_OSCILLATING: if constexpr (FULL) return th + u[0] * env_sin(td); else return th;   // np.sin(t): libm's
+#else
     case NSG_UPD_OSCILLATING: if constexpr (FULL) return th + u[0] * nsg_sin(td); else return th;
+#endif
     case NSG_UPD_SIGMOID: {
       if constexpr (FULL) {
         double sg = 1.0 / (1.0 + nsg_exp(-u[2] * (td - u[3])));

@@ -6,7 +6,7 @@ separates the default arithmetic from libm's after ~270 steps (profiles/NOTEBOOK
 import numpy as np
 import pytest
 
-from tests.util import TRAJ_SPECS, make_env_from_spec
+from tests.util import TRAJ_SPECS, GpuView, check_trajectory, load, make_env_from_spec
 
 pytestmark = pytest.mark.gpu
 
@@ -32,6 +32,19 @@ def _same_state(env, orc, tag):
     assert np.array_equal(env.theta.cpu().numpy().view(np.uint64), orc.a["theta"][:env.theta.shape[0]].view(np.uint64)), tag + ": theta"
     assert np.array_equal(env.buf["reward"].cpu().numpy().view(np.uint32), orc.a["reward"].view(np.uint32)), tag + ": reward"
     assert np.array_equal(env.buf["terminated"].cpu().numpy(), orc.a["terminated"]) and np.array_equal(env.buf["truncated"].cpu().numpy(), orc.a["truncated"]), tag
+
+
+@pytest.mark.parametrize("name", [n for n in sorted(TRAJ_SPECS) if TRAJ_SPECS[n]["env_id"].split("-")[0] in
+                                  ("CartPole", "Pendulum", "Acrobot", "MountainCar", "MountainCarContinuous")])
+def test_committed_reference_trajectories_bit_for_bit(name):
+    """Straight against the numbers the reference's wrappers produced (tests/golden/traj_*.npz), no oracle in between and no tolerance:
+    float32 observation, reward and float64 theta of every step in every bit - update functions through sin / exp and RandomWalk's
+    normal variates included (pendulum_all_params, the c2 / shared-RandomWalk CartPoles)."""
+    spec = TRAJ_SPECS[name]
+    env = make_env_from_spec(_vec, spec, libm_exact=True)
+    assert env.libm_exact and env.specialized
+    check_trajectory(GpuView(env), spec, load(f"traj_{name}.npz"), strict=True)
+    env.close()
 
 
 @pytest.mark.parametrize("name,T", [("c1_cartpole_masspole_inc", 300), ("c2_cartpole_gravity_rw", 300), ("cartpole_two_params", 200),

@@ -21,9 +21,6 @@ SRC = r'''
 static const unsigned long long TABW[NSG_SINCOS_TAB_WORDS] = {
 #include "%(root)s/include/nsg_sincos_tab.inc"
 };
-static const unsigned long long POWW[NSG_POW_TAB_WORDS] = {
-#include "%(root)s/include/nsg_pow_tab.inc"
-};
 static const unsigned long long POWFW[NSG_POWF_TAB_WORDS] = {
 #include "%(root)s/include/nsg_powf_tab.inc"
 };
@@ -46,7 +43,7 @@ long t_compare(const double* x, long n, double* first_bad) {
 }
 // x ** 2 on a float64 scalar: how many differ from libm's pow(x, 2.0); *not_product counts where pow itself is not x * x
 long t_compare_sq(const double* x, long n, double* first_bad, long* not_product) {
-  const nsg::PowTab tb{POWW};
+  const nsg::PowTab tb{nsg::kNsgPowTab};
   long bad = 0;
   for (long i = 0; i < n; i++) {
     const double a = nsg::nsg_sq_libm(tb, x[i]), w = ppow(x[i], 2.0);
@@ -79,7 +76,7 @@ def m():
     d = tempfile.mkdtemp()
     src, so = os.path.join(d, "m.cpp"), os.path.join(d, "m.so")
     open(src, "w").write(SRC)
-    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-mfma", "-fPIC", "-shared", "-o", so, src])
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-mfma", "-I", os.path.join(ROOT, "include"), "-fPIC", "-shared", "-o", so, src])
     lib = C.CDLL(so)
     lib.t_compare.restype = C.c_long
     lib.t_merged_sincos_differs.restype = C.c_long

@@ -20,6 +20,7 @@ void t_sincos_poly1(const double* x, double* s, double* c, long n) { for (long i
 void t_sincos_poly2(const double* x, double* s, double* c, long n) { for (long i = 0; i < n; i++) nsg::nsg_sincos_t<2>(x[i], s + i, c + i); }
 void t_pymod(const double* x, double m, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_pymod_pos(x[i], m); }
 void t_exp(const double* x, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_exp(x[i]); }
+void t_exp_libm(const double* x, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_exp_libm(x[i]); }
 void t_log1p(const double* x, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_log1p(x[i]); }
 void t_wrap(const double* x, double* y, long n) { for (long i = 0; i < n; i++) y[i] = nsg::nsg_wrap_pi(x[i]); }
 // gymnasium's wrap(x, -pi, pi) as written: the definition the closed form is measured against
@@ -36,7 +37,7 @@ def m():
     d = tempfile.mkdtemp()
     src, so = os.path.join(d, "m.cpp"), os.path.join(d, "m.so")
     open(src, "w").write(SRC)
-    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src])
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-mfma", "-I", os.path.join(ROOT, "include"), "-fPIC", "-shared", "-o", so, src])
     return C.CDLL(so)
 
 
@@ -90,6 +91,58 @@ def test_exp_and_log1p_within_one_ulp(m):
     assert np.isinf(y[0]) and y[1] == 0.0 and np.isnan(y[2]) and y[3] == 1.0
     (y,) = _call(m.t_log1p, np.array([-1.0, -2.0, 0.0, np.inf]))
     assert y[0] == -np.inf and np.isnan(y[1]) and y[2] == 0.0 and np.isinf(y[3])
+
+
+def _fma_libm():
+    flags = open("/proc/cpuinfo").read()
+    return " fma " in flags and " avx2 " in flags
+
+
+@pytest.mark.skipif(not _fma_libm(), reason="libm dispatches exp to its FMA build only on CPUs with FMA + AVX2; nsg_exp restates that build")
+def test_exp_and_log1p_equal_libm_bit_for_bit(m):
+    """The samplers NumPy's Generator runs in C call libm's exp and log1p; nsg_exp_libm (nsg_exp in a NSG_LIBM_EXACT unit) / nsg_log1p
+    (every build) are glibc 2.35's own algorithms with every rounding where libm has it: equal on every argument tried, subnormal results and special values included.
+    (np.exp / np.log1p on ARRAYS or scalars are NumPy's own SIMD kernels on an AVX-512 host and differ from libm - and so from what
+    NumPy's own random module computes - in the last bit; math.exp / math.log1p are libm's.)"""
+    import math
+
+    rng = np.random.default_rng(7)
+    for r in (1e-18, 1e-16, 1e-9, 1e-3, 0.5, 1.0, 5.0, 20.0, 100.0, 500.0, 700.0, 720.0, 746.0, 800.0, 1100.0):
+        x = rng.uniform(-r, r, 12_000)
+        (y,) = _call(m.t_exp_libm, x)
+        want = np.array([math.exp(v) if v < 709.78 else np.inf for v in x])
+        assert np.array_equal(y.view(np.uint64), want.view(np.uint64)), r
+    for r in (1e-17, 1e-12, 1e-9, 1e-6, 1e-3, 0.3, 0.5, 1.0, 3.0, 100.0, 1e6, 1e15, 1e17, 1e300):
+        x = rng.uniform(-min(r, 0.9999999), r, 12_000)
+        (y,) = _call(m.t_log1p, x)
+        want = np.array([math.log1p(v) for v in x])
+        assert np.array_equal(y.view(np.uint64), want.view(np.uint64)), r
+    # either side of every branch test of s_log1p.c (they are made on the high word) and of e_exp.c
+    e = np.array([-0.2928932188134524, -0.29289340972900390625, 0.41421356237309515, 0.41421365737915039, 2.0 ** -29, 2.0 ** -54, 2.0 ** 53, 2.0 ** -20, 1.0, 3.0])
+    x = (e[:, None] + np.arange(-2000, 2001)[None, :] * np.spacing(e)[:, None]).ravel()
+    (y,) = _call(m.t_log1p, x)
+    assert np.array_equal(y.view(np.uint64), np.array([math.log1p(v) for v in x]).view(np.uint64))
+    e = np.array([512.0, -512.0, 709.782712893384, -745.1332191019411, -708.3964185322641, 2.0 ** -54, -2.0 ** -54, 1.0, -1.0])
+    x = (e[:, None] + np.arange(-2000, 2001)[None, :] * np.spacing(np.abs(e))[:, None]).ravel()
+    (y,) = _call(m.t_exp_libm, x)
+    want = np.array([math.exp(v) if v < 709.782712893384 else np.inf for v in x])
+    ok = (y.view(np.uint64) == want.view(np.uint64)) | (x > 709.78)     # (math.exp raises OverflowError beyond; checked below)
+    assert ok.all()
+    (y,) = _call(m.t_exp_libm, np.array([710.0, 1e5, -1e5, -np.inf, np.inf]))
+    assert np.isinf(y[0]) and np.isinf(y[1]) and y[2] == 0.0 and y[3] == 0.0 and np.isinf(y[4])
+
+
+def test_exp_literals_are_the_tables_words():
+    import re
+    import struct
+
+    words = re.findall(r"0x([0-9a-f]{16})ULL", open(os.path.join(ROOT, "include", "nsg_pow_tab.inc")).read())
+    src = open(os.path.join(ROOT, "ns_gym_amd", "csrc", "nsg_math.hip.h")).read()
+    body = src[src.index("NSG_HD double nsg_exp_libm"):]
+    lits = re.findall(r"(?:InvLn2N|Shift|NegLn2hiN|NegLn2loN|C2|C3|C4|C5) = (-?0x[0-9a-f.]+p[+-]\d+)", body)[:8]
+    assert len(lits) == 8
+    for lit, w in zip(lits, words[9:17]):
+        assert struct.pack("<d", float.fromhex(lit)) == struct.pack("<Q", int(w, 16)), (lit, w)
 
 
 def test_pymod_equals_python_float_mod_bit_for_bit(m):

@@ -17,7 +17,7 @@ def test_oracle_follows_the_reference_past_done(name):
     spec, rec = NORESET[name], load(f"traj_{name}.npz")
     assert int(rec["was_reset"].sum()) == 0 and int((rec["terminated"] | rec["truncated"]).sum()) > 30
     env = make_env_from_spec(OracleVecEnv, spec, autoreset=False)
-    check_trajectory(OracleView(env), spec, rec, strict_theta=spec["env_id"] == "FrozenLake-v1")
+    check_trajectory(OracleView(env), spec, rec, strict=True)
 
 
 @pytest.mark.parametrize("name", sorted(NORESET_GRID))

@@ -43,7 +43,11 @@ def test_oracle_reproduces_the_reference_on_a_random_configuration(ref, case):
     wk = _decode(spec)
     rec = G.gen_trajectory(gym, S, U, CC, FL, {**spec, "wrapper_kwargs": wk})
     env = make_env_from_spec(OracleVecEnv, {**spec, "wrapper_kwargs": wk})
-    check_trajectory(OracleView(env), spec, rec)
+    # no tolerance - observation, reward, theta in every bit - unless a parameter goes through np.exp: on an AVX-512 host NumPy's float64
+    # exp / log are its own SIMD kernels, 1 ulp off libm's for 4.6 % of arguments here (sin / cos / pow ARE libm's), so an
+    # ExponentialDecay / SigmoidTransition theta is host-dependent in the reference itself and is compared at 1e-5 like before
+    np_exp = any(fs.get("update", [""])[0] in ("ExponentialDecay", "SigmoidTransition") for fs in spec["params"].values())
+    check_trajectory(OracleView(env), spec, rec, strict=not np_exp)
 
 
 class _Rec(dict):

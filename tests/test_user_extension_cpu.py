@@ -37,7 +37,7 @@ def test_oracle_reproduces_reference_with_user_subclasses(name):
 
     spec = USER_SPECS[name]
     env = make_env_from_spec(OracleVecEnv, spec)
-    check_trajectory(OracleView(env), spec, load(f"traj_{name}.npz"), strict_theta=spec["env_id"] == "FrozenLake-v1")
+    check_trajectory(OracleView(env), spec, load(f"traj_{name}.npz"), strict=True)
 
 
 # ------------------------------------------------------------------ what the tables hold

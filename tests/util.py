@@ -50,24 +50,31 @@ def make_env_from_spec(factory, spec, n=None, seeds=None, **extra):
     return factory(env, tp, n, **kw)
 
 
-def check_trajectory(view, spec, rec, T=None, strict_theta=False):
+def check_trajectory(view, spec, rec, T=None, strict_theta=False, strict=False):
     """`view` adapts an implementation: view.reset(seeds) / view.step(actions) return a dict of
     NumPy arrays: state[N,D] (or [N] ints), reward[N], terminated[N], truncated[N],
-    env_change[P,N], delta_change[P,N] (ground truth), t[N], theta[rows,N]."""
+    env_change[P,N], delta_change[P,N] (ground truth), t[N], theta[rows,N].
+    `strict`: no tolerance - the float32 observation, the reward as float32 and the float64 theta equal the reference's recorded values
+    in every bit (the oracle; the kernels' libm_exact units)."""
     seeds = np.asarray(spec["seeds"], dtype=np.uint64)
     T = T or spec["T"]
     is_fl = spec["env_id"] == "FrozenLake-v1"
     out = view.reset(seeds)
-    _cmp(out, rec, 0, is_fl, None, strict_theta)
+    _cmp(out, rec, 0, is_fl, None, strict_theta or strict, strict)
     for k in range(T):
         out = view.step(rec["actions"][k])
-        _cmp(out, rec, k + 1, is_fl, k, strict_theta)
+        _cmp(out, rec, k + 1, is_fl, k, strict_theta or strict, strict)
 
 
-def _cmp(out, rec, k, is_fl, kk, strict_theta):
+def _cmp(out, rec, k, is_fl, kk, strict_theta, strict=False):
     tag = f"step index {k}"
     if is_fl:
         np.testing.assert_array_equal(out["state"].reshape(-1), rec["state"][k, :, 0], err_msg=tag)
+    elif strict:
+        assert rec["state"].dtype == np.float32
+        np.testing.assert_array_equal(np.asarray(out["state"], dtype=np.float32).view(np.uint32), rec["state"][k].view(np.uint32), err_msg=tag + ": observation bits")
+        if kk is not None:
+            np.testing.assert_array_equal(np.asarray(out["reward"], dtype=np.float32), rec["reward"][kk].astype(np.float32), err_msg=tag + ": reward")
     else:
         np.testing.assert_allclose(out["state"], rec["state"][k], rtol=STATE_RTOL, atol=STATE_ATOL, err_msg=tag)
     np.testing.assert_array_equal(out["t"], rec["relative_time"][k], err_msg=tag)
