@@ -116,10 +116,14 @@ enum {
 #define NSG_F_TERMINAL_CLIFF 0x100u /* CliffWalking terminal_cliff (toy_text.py:39,126-128)              */
 #define NSG_F_SIM_ENV 0x40u        /* planning copy: is_sim_env (base.py:270, classic_control.py:184)   */
 #define NSG_F_IN_SIM_CHANGE 0x80u  /* in_sim_change: θ keeps evolving inside planning copies            */
-#define NSG_F_LIBM_EXACT 0x800u    /* classic-control envs: the integrators' sin / cos are libm's, bit for bit (glibc 2.35's FMA build, what np.sin / np.cos
-                                      resolve to in the reference): the float64 state then EQUALS the reference's instead of tracking it within
-                                      1e-5.  Runs on the handle's specialised unit only (nsg_specialize; nsg_step / nsg_rollout / ... refuse an
-                                      unspecialised handle with this flag); ~4-60 % more time per step by env type (nsg_envs.hip.h) */
+#define NSG_F_LIBM_EXACT 0x800u    /* classic-control envs: every sin / cos / scalar `** 2` of the integrators and every sin / exp of the θ-engine is
+                                      evaluated with libm's own algorithm and roundings (glibc 2.35's FMA builds - what np.sin / np.cos / scalar
+                                      power resolve to in the reference): float64 state, float32 observation, reward and θ then EQUAL the
+                                      reference's bit for bit instead of tracking them within 1e-5.  Runs on the handle's specialised unit only
+                                      (nsg_specialize; nsg_step / nsg_rollout / ... refuse an unspecialised handle with this flag, groups refuse
+                                      such a member).  Costs +4 % (CartPole) to x 2.1 (Acrobot) per step.  Added within ABI
+                                      version 4: an older library rejects the unknown flag bit. */
+#define NSG_F_KNOWN 0xfdfu         /* every flag bit this header defines; nsg_create refuses any other */
 #define NSG_F_NO_AUTORESET 0x400u  /* a finished env is NOT reset by the next step: it keeps stepping exactly like the reference's single
                                       wrappers, which forward to gymnasium whatever `done` said (base.py:313): CartPole integrates on and pays
                                       0.0 from the second terminated step (steps_beyond_terminated), TimeLimit keeps reporting truncated,

@@ -61,6 +61,9 @@ int validate(const nsg_config* cfg, size_t table_bytes) {
   if (cfg->env_type < 0 || cfg->env_type >= NSG_ENV_COUNT) return fail(NSG_EINVAL, "bad env_type %d", cfg->env_type);
   if (cfg->n_params < 0 || cfg->n_params > NSG_MAX_PARAMS) return fail(NSG_EINVAL, "bad n_params %d", cfg->n_params);
   if (table_bytes > (size_t)kMaxTableBytes) return fail(NSG_EINVAL, "constant tables are %zu bytes, limit %d", table_bytes, kMaxTableBytes);
+  if (cfg->flags & ~NSG_F_KNOWN) return fail(NSG_EINVAL, "unknown flag bits 0x%x (this library knows 0x%x)", cfg->flags & ~NSG_F_KNOWN, NSG_F_KNOWN);
+  if ((cfg->flags & NSG_F_LIBM_EXACT) && is_grid_env(cfg->env_type))
+    return fail(NSG_EINVAL, "NSG_F_LIBM_EXACT is for the classic-control envs (the grid envs' path is integer arithmetic: nothing to choose)");
   if ((cfg->flags & NSG_F_NO_AUTORESET) && (cfg->flags & NSG_F_TRACK_RETURNS))
     return fail(NSG_EINVAL, "NSG_F_TRACK_RETURNS needs the autoreset (an episode's return is closed by the step that resets it); not combinable with NSG_F_NO_AUTORESET");
   const bool fl = is_grid_env(cfg->env_type);

@@ -35,6 +35,15 @@ def test_live_handle_misuse_is_refused_and_harmless():
     for rc in (lib.nsg_step(raw, acts.data_ptr(), stream), lib.nsg_reset(raw, None, None, stream),
                lib.nsg_rollout(raw, acts.data_ptr(), 1, None, stream)):
         assert rc == ENOTBOUND and b"nsg_bind" in lib.nsg_last_error()
+    bad = type(cfg).from_buffer_copy(cfg)           # a flag bit this library does not know; libm-exact arithmetic asked of an integer path
+    bad.flags |= 0x20
+    hb = C.c_void_p()
+    assert lib.nsg_create(C.byref(bad), tables, len(tables), 256, C.byref(hb)) == EINVAL and b"unknown flag" in lib.nsg_last_error()
+    from ns_gym_amd.update_functions import DistributionStepWiseUpdate
+    fcfg, ftab, _, _ = compile_config(make("FrozenLake-v1"), {"P": DistributionStepWiseUpdate(ContinuousScheduler(), [[0.6, 0.2, 0.2]])})
+    fcfg.flags |= A.F_LIBM_EXACT
+    ftab = bytes(ftab)
+    assert lib.nsg_create(C.byref(fcfg), ftab, len(ftab), 256, C.byref(hb)) == EINVAL and b"NSG_F_LIBM_EXACT" in lib.nsg_last_error()
     bufs = A.Buffers()                              # binding without the required rows
     assert lib.nsg_bind(raw, C.byref(bufs)) == EINVAL and b"required" in lib.nsg_last_error()
     assert lib.nsg_destroy(raw) == 0

@@ -135,6 +135,34 @@ def test_acrobot_at_c4_size_full_horizon_without_an_allowance():
     env.close()
 
 
+@pytest.mark.parametrize("name,theta_mode,in_sim_change", [("c2_cartpole_gravity_rw", 0, True), ("c4_acrobot_mass2_inc", 0, False), ("c4_pendulum_m_inc", 1, False)])
+def test_planning_copies_of_an_exact_batch_are_exact(name, theta_mode, in_sim_change):
+    """nsg_fork of a libm_exact batch: the copy carries the flag, gets its own exact unit and equals the oracle's copy bit for bit, like its
+    source - the planner-shaped use (fork, then roll the copy forward)."""
+    import torch
+
+    from tests.golden.make_golden import make_actions
+
+    n, pre, post = 2048, 30, 120
+    spec = dict(TRAJ_SPECS[name])
+    spec["flags"] = {**spec["flags"], "in_sim_change": in_sim_change}
+    env = make_env_from_spec(_vec, spec, n=n, libm_exact=True)
+    orc = make_env_from_spec(_orc, spec, n=n)
+    env.reset(seed=3); orc.reset(seed=3)
+    acts = make_actions(spec["env_id"], pre + post, n)
+    for k in range(pre):
+        env.step(torch.from_numpy(acts[k]).cuda()); orc.step(acts[k])
+    sim, osim = env.fork(theta_mode=theta_mode, entropy=4242), orc.fork(theta_mode=theta_mode, entropy=4242)
+    assert sim.libm_exact and sim.specialized and sim.is_sim_env
+    _same_state(sim, osim, f"{name}: at fork")
+    for k in range(pre, pre + post):
+        sim.step(torch.from_numpy(acts[k]).cuda()); osim.step(acts[k])
+    _same_state(sim, osim, f"{name}: copy after {post} steps")
+    env.step(torch.from_numpy(acts[0]).cuda()); orc.step(acts[0])
+    _same_state(env, orc, f"{name}: source after the fork")
+    sim.close(); env.close()
+
+
 def test_exact_mode_is_refused_where_it_cannot_run():
     import torch
 
