@@ -4,7 +4,8 @@ of steps on the GPU, and the oracle's restatement of the same loop (orc_rollout_
 rows and episode accounts are compared.  A closed loop is the hardest case for parity: one differing observation bit can flip a
 decision, after which the two trajectories have nothing to do with each other - so every env that left the bar is counted and shown.
 
-    python tools/soak_policy.py c2 65536 4000 500        # workload, envs, steps, chunk"""
+    python tools/soak_policy.py c2 65536 4000 500        # workload, envs, steps, chunk
+    python tools/soak_policy.py c2 65536 4000 500 exact  # the same through the NSG_F_LIBM_EXACT unit (libm's sin / cos / exp, bit for bit)"""
 import os
 import sys
 import time
@@ -22,7 +23,9 @@ from oracle.oracle import OracleVecEnv
 def main():
     name, n, T, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     w = W.WORKLOADS[name]
-    env = W.build(name, n, track_returns=False, specialize=True, seed=None)
+    exact = len(sys.argv) > 5 and sys.argv[5] == "exact"
+    env = W.build(name, n, track_returns=False, specialize=True, seed=None, **({"libm_exact": True} if exact else {}))
+    print(f"{name}: {n} envs, {T} steps, libm_exact={env.libm_exact}", flush=True)
     orc = OracleVecEnv(make(w["env_id"], **w["make_kwargs"]), w["params"](), n, change_notification=True, delta_change_notification=True,
                        **w["wrapper_kwargs"])
     env.reset(seed=11)
