@@ -37,7 +37,7 @@ F_TERMINAL_CLIFF = 0x100
 F_SIM_ENV = 0x40
 F_IN_SIM_CHANGE = 0x80
 F_NO_AUTORESET = 0x400
-F_LIBM_EXACT = 0x800   # the integrators' sin / cos are libm's, bit for bit (specialised units only)
+F_LIBM_EXACT = 0x800   # sin / cos / scalar ** 2 / exp evaluated as glibc's libm does, bit for bit (specialised units only)
 
 ST_NEEDS_RESET = 0x1
 EP_COUNT_SHIFT = 1          # episode word of the classic-control envs: resets drawn so far << 1 | needs-reset

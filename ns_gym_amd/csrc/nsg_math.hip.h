@@ -219,15 +219,15 @@ namespace nsg {
 // Used by the "full" θ-engine: ExponentialDecay / SigmoidTransition (np.exp, single_param.py:286, 384) and by NumPy's samplers,
 // which run in C and call libm (the ziggurat's wedge tests: exp; its tails and geometric: log1p).  The device library's versions cost
 // ~60 VGPRs more, which costs the RandomWalk kernels a wave of occupancy.
-//   nsg_log1p      glibc 2.35's log1p [UPSTREAM sysdeps/ieee754/dbl-64/s_log1p.c] operation for operation, in every build: the
-//                  normal variates of a ziggurat tail and the geometric waits equal NumPy's in every bit (rounds 1-3 carried fdlibm's
-//                  original, equal to libm's for all but 0.08 % of arguments).
+//   nsg_log1p_libm glibc 2.35's log1p [UPSTREAM sysdeps/ieee754/dbl-64/s_log1p.c] operation for operation: the normal variates of a
+//                  ziggurat tail and the geometric waits equal NumPy's in every bit.  What nsg_log1p IS in a unit built with
+//                  NSG_LIBM_EXACT; elsewhere it is fdlibm's original (why: at the function).
 //   nsg_exp_libm   glibc 2.35's exp [UPSTREAM e_exp.c, __exp_fma, from ARM's optimized-routines: 128-entry table, degree-5
 //                  polynomial] with every fused multiply-add where the image's libm.so.6 has one.  The table is __exp_data, extracted
 //                  from the image's libm by tools/extract_libm_pow_tables.py (words 401..656 of include/nsg_pow_tab.inc; the log
 //                  side of the same file serves nsg_sq_libm).  What nsg_exp IS in a unit built with NSG_LIBM_EXACT.
 //   nsg_exp_fdlibm fdlibm's exp (< 1 ulp), what nsg_exp is everywhere else (why: below).
-// tests/test_math_cpu.py holds nsg_log1p and nsg_exp_libm equal to libm itself, subnormal results and special values included.
+// tests/test_math_cpu.py holds nsg_log1p_libm and nsg_exp_libm equal to libm itself, subnormal results and special values included.
 // (np.exp on a scalar or an array is NumPy's own SIMD kernel on an AVX-512 host, 1 ulp off libm's for 4.6 % of arguments: an
 // ExponentialDecay theta is host-dependent in the reference itself.  libm's is what the oracle - plain C - calls, and what a host
 // without AVX-512 gets.)
@@ -338,9 +338,9 @@ NSG_HD double nsg_exp(double x) {
 #endif
 }
 
-NSG_HD double nsg_log1p(double x) {
+NSG_HD double nsg_log1p_libm(double x) {
   // glibc 2.35's log1p [UPSTREAM sysdeps/ieee754/dbl-64/s_log1p.c: fdlibm's algorithm with the polynomial split in four] operation for
-  // operation - the function NumPy's generators call (ziggurat tails, geometric) - so that the streams equal NumPy's in every bit:
+  // operation - the function NumPy's generators call (ziggurat tails, geometric) - so that an exact unit's streams equal NumPy's in every bit:
   // branch tests on the HIGH WORD as upstream has them (they are not the double comparisons they approximate), the |x| < 2^-29 and
   // |f| < 2^-20 shortcuts, R = ((z Lp1 + z^2 (Lp2 + z Lp3)) + z^4 (Lp4 + z Lp5)) + z^6 (Lp6 + z Lp7).  The x86-64 build has no FMA
   // variant of this function.  tests/test_math_cpu.py: equal to libm on 6 M arguments over every branch.
@@ -395,6 +395,59 @@ NSG_HD double nsg_log1p(double x) {
   const double R = ((z * Lp1 + z2 * (Lp2 + z * Lp3)) + z4 * (Lp4 + z * Lp5)) + z6 * (Lp6 + z * Lp7);
   if (k == 0) return f - (hfsq - s * (hfsq + R));
   return kd * ln2_hi - ((hfsq - (s * (hfsq + R) + (kd * ln2_lo + c))) - f);
+}
+
+// fdlibm's log1p as published (< 1 ulp; equal to glibc's for all but 0.08 % of arguments - glibc tests the high word where this
+// compares doubles, has two more shortcuts and splits the polynomial).  What every build WITHOUT NSG_LIBM_EXACT evaluates: log1p only
+// runs in a ziggurat tail (2.6e-4 of the normal draws) and in geometric, and glibc's form costs C2's step kernel 14 more spilled SGPRs
+// - 4 % at BASELINE's 65 536 envs, where a launch is latency-bound (6.77 -> 7.04 us, profiles/r04_ab_log1p.txt).
+NSG_HD double nsg_log1p_fdlibm(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+               Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01, Lp3 = 2.857142874366239149e-01,
+               Lp4 = 2.222219843214978396e-01, Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
+               Lp7 = 1.479819860511658591e-01;
+  if (x != x) return x;
+  if (x < -1.0) return __builtin_nan("");
+  if (x == -1.0) return -__builtin_inf();
+  if (x == __builtin_inf()) return x;
+  const double ax = fabs(x);
+  if (ax < 5.55111512312578270212e-17) return x;  // |x| < 2^-54
+  int k = 1;
+  double f = x, c = 0.0;
+  if (x > -0.2928932188134524 && x < 0.41421356237309515) {
+    k = 0;  // sqrt(2)/2 - 1 < x < sqrt(2) - 1: no reduction
+  } else {
+    union { double d; unsigned long long u; } uu;
+    const double u1 = 1.0 + x;
+    uu.d = u1;
+    k = (int)((uu.u >> 52) & 0x7ff) - 1023;
+    // correction term for the rounding of 1 + x
+    c = (k > 0) ? 1.0 - (u1 - x) : x - (u1 - 1.0);
+    c /= u1;
+    unsigned long long m = uu.u & 0x000fffffffffffffULL;
+    if (m < 0x6a09e667f3bcdULL) {
+      uu.u = m | 0x3ff0000000000000ULL;  // normalise u
+    } else {
+      k += 1;
+      uu.u = m | 0x3fe0000000000000ULL;  // normalise u/2
+    }
+    f = uu.d - 1.0;
+  }
+  const double hfsq = 0.5 * f * f;
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  const double R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+  if (k == 0) return f - (hfsq - s * (hfsq + R));
+  const double kd = (double)k;
+  return kd * ln2_hi - ((hfsq - (s * (hfsq + R) + (kd * ln2_lo + c))) - f);
+}
+
+NSG_HD double nsg_log1p(double x) {
+#if NSG_LIBM_EXACT
+  return nsg_log1p_libm(x);
+#else
+  return nsg_log1p_fdlibm(x);
+#endif
 }
 
 }  // namespace nsg

@@ -57,11 +57,13 @@ class VecNSEnv:
         for bit, 10-35 % less time per step.  `False`: the precompiled generic kernels.  `None` (default): specialise
         batches of >= 65 536 envs when the runtime compiler is available, silently stay generic otherwise.
 
-        `libm_exact=True` (classic control): the integrators evaluate sin / cos with libm's own algorithm and roundings (glibc 2.35's FMA
-        build - what `np.sin` / `np.cos` resolve to in the reference), so the float64 state EQUALS the reference's, bit for bit, for
-        as long as the batch is stepped - also where an unstable or chaotic plant (a balanced CartPole, Acrobot) would otherwise
-        amplify the last ulp of the kernels' own < 1-ulp sincos into a different trajectory a few hundred steps later.  It runs on
-        the batch's specialised unit (implies `specialize=True`) and costs 4-60 % more time per step, by env type.
+        `libm_exact=True` (classic control): the integrators and the θ-engine evaluate sin / cos / exp and every `x ** 2` the reference
+        hands to libm's pow with libm's own algorithms and roundings (glibc 2.35's FMA builds - what `np.sin` / `np.cos` / a scalar
+        `** 2` resolve to in the reference), so float64 state, observation, reward and θ EQUAL the reference's, bit for bit, for as
+        long as the batch is stepped - also where an unstable or chaotic plant (a balanced CartPole, Acrobot) would otherwise amplify
+        the last ulp of the kernels' own < 1-ulp sincos into a different trajectory a few hundred steps later.  It runs on the
+        batch's specialised unit (implies `specialize=True`; raises if no unit can be had) and costs +4 % (CartPole) to x 2.1 (Acrobot)
+        per step.  Planning copies inherit it.
 
         `autoreset=True` (default): gymnasium's next-step vector autoreset - the step after an episode ended resets that env
         (reward 0, flags clear, relative_time 0, streams continue).  `autoreset=False`: nothing resets inside `step()`; a finished
