@@ -206,6 +206,10 @@ inline std::string group_source(const nsg_config* const* cfgs, const bool* full,
     if (!grid && cfg_uses_table_blob(*cfgs[k])) direct = false;
   }
   if (direct) s += "#ifndef NSG_TABLES_DIRECT\n#define NSG_TABLES_DIRECT 1\n#endif\n";
+  // libm's arithmetic is a property of the translation unit: a group is exact when every classic-control member is (the caller has
+  // refused mixed lists: check_group_members)
+  for (int k = 0; k < n; k++)
+    if (cfgs[k]->flags & NSG_F_LIBM_EXACT) { s += "#define NSG_LIBM_EXACT 1\n"; break; }
   s +=
       "#include \"nsg_rollout.hip.h\"\n"
       "namespace nsg {\n";

@@ -1128,17 +1128,38 @@ static int make_group_plan_locked(GroupPlan& plan, nsg_handle* const* hs, int n_
   return NSG_OK;
 }
 
+static bool group_is_exact(nsg_handle* const* hs, int n_handles) {
+  for (int k = 0; k < n_handles; k++)
+    if (hs[k]->host.cfg.flags & NSG_F_LIBM_EXACT) return true;
+  return false;
+}
+
+// An exact group runs on its own unit or not at all (the generic group kernels carry the fast sincos).
+static int exact_group_needs_unit(nsg_handle* const* hs, int n_handles, const void* kernel, const char* what) {
+  if (kernel || !group_is_exact(hs, n_handles)) return NSG_OK;
+  return fail(NSG_EUNSUPPORTED, "%s: the members were created with NSG_F_LIBM_EXACT and no specialised unit could be built for this member list "
+                                "(every member specialised? runtime compiler available? a unit that spills is refused) - the generic group kernels "
+                                "carry the fast arithmetic only", what);
+}
+
 static int check_group_members(nsg_handle* const* hs, int32_t n_handles) {
   if (!hs || n_handles <= 0 || n_handles > NSG_MAX_SEGMENTS) return fail(NSG_EINVAL, "bad group arguments");
   for (int k = 0; k < n_handles; k++) {
     if (!hs[k] || !hs[k]->bound) return fail(NSG_ENOTBOUND, "group member %d is not bound", k);
     if (hs[k]->device != hs[0]->device) return fail(NSG_EINVAL, "group member %d lives on device %d, member 0 on device %d", k, hs[k]->device, hs[0]->device);
-    if (hs[k]->host.cfg.flags & NSG_F_LIBM_EXACT)
-      return fail(NSG_EUNSUPPORTED, "group member %d was created with NSG_F_LIBM_EXACT: such handles step on their own specialised unit (nsg_step / nsg_rollout), "
-                                    "heterogeneous launches carry the fast sincos only", k);
     for (int j = 0; j < k; j++)
       if (hs[j] == hs[k]) return fail(NSG_EINVAL, "group member %d is listed twice", k);
   }
+  // NSG_F_LIBM_EXACT is a property of a whole unit: the classic-control members of one launch are all exact or none is (a member that
+  // silently stepped in the other arithmetic would void what the flag promises); grid members have nothing to choose
+  int exact = 0, fast = 0;
+  for (int k = 0; k < n_handles; k++) {
+    if (is_grid_env(hs[k]->host.cfg.env_type)) continue;
+    if (hs[k]->host.cfg.flags & NSG_F_LIBM_EXACT) exact++; else fast++;
+  }
+  if (exact && fast)
+    return fail(NSG_EUNSUPPORTED, "%d classic-control member(s) of this group were created with NSG_F_LIBM_EXACT and %d without: one launch runs one "
+                                  "arithmetic - create all of them with the flag, or step the exact ones on their own units", exact, fast);
   return NSG_OK;
 }
 
@@ -1204,6 +1225,7 @@ int nsg_step_group(nsg_handle* const* hs, int32_t n_handles, const void* const* 
   if (rc) return rc;
   int reverse = next_traversal(hs[0]);   // the members of a group alternate together
   const Segment* ga = ps.table;
+  if ((rc = exact_group_needs_unit(hs, n_handles, ps.group_spec ? (const void*)ps.group_spec->group : nullptr, "nsg_step_group"))) return rc;
   if (ps.group_spec) {
     void* args[] = {(void*)&ga, (void*)&n_handles, (void*)&ap, (void*)&reverse};
     HIP_TRY(hipModuleLaunchKernel(ps.group_spec->group, ps.total_blocks, 1, 1, kBlock, 1, 1, (unsigned)ps.group_lds, (hipStream_t)stream, args, nullptr));
@@ -1234,6 +1256,7 @@ int nsg_rollout_group(nsg_handle* const* hs, int32_t n_handles, const void* cons
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const Segment* ga = ps.table;
+  if ((rc = exact_group_needs_unit(hs, n_handles, ps.group_spec ? (const void*)ps.group_spec->group_rollout : nullptr, "nsg_rollout_group"))) return rc;
   if (ps.group_spec && ps.group_spec->group_rollout) {
     void* args[] = {(void*)&ga, (void*)&n_handles, (void*)&ap, (void*)&k_steps, (void*)&ro};
     HIP_TRY(hipModuleLaunchKernel(ps.group_spec->group_rollout, ps.total_blocks, 1, 1, kBlock, 1, 1, (unsigned)ps.group_rollout_lds, s, args, nullptr));

@@ -163,6 +163,44 @@ def test_planning_copies_of_an_exact_batch_are_exact(name, theta_mode, in_sim_ch
     sim.close(); env.close()
 
 
+def test_c4_as_one_group_launch_at_full_size_is_exact():
+    """BASELINE C4 in its own launch shape - Pendulum 262 144 + Acrobot 262 144 in ONE nsg_step_group launch per step - with both members
+    exact: every float64 state of both members equals the oracle's over 200 steps, then 64 more through one nsg_rollout_group launch."""
+    import os
+
+    import torch
+
+    from ns_gym_amd import make, workloads as W
+    from ns_gym_amd.vec_env import rollout_group, step_group
+
+    n, T, K = 1 << 18, 200, 64
+    threads = min(16, os.cpu_count() or 1)
+    envs, orcs = [], []
+    for name in ("pend", "acro"):
+        w = W.WORKLOADS[name]
+        e = W.build(name, n, track_returns=False, libm_exact=True, seed=None)
+        o = _orc(make(w["env_id"]), w["params"](), n, change_notification=True, delta_change_notification=True)
+        e.reset(seed=13); o.reset(seed=13)
+        envs.append(e); orcs.append(o)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    a_p = (torch.rand((T + K, n), device="cuda", generator=g) * 4 - 2).float()
+    a_a = torch.randint(0, 3, (T + K, n), dtype=torch.int32, device="cuda", generator=g)
+    hp, ha = a_p.cpu().numpy(), a_a.cpu().numpy()
+    for k in range(T):
+        step_group(envs, [a_p[k], a_a[k]])
+        orcs[0].step_mt(hp[k], threads); orcs[1].step_mt(ha[k], threads)
+        if k % 50 == 49:
+            _same_state(envs[0], orcs[0], f"C4 group, pendulum, step {k}")
+            _same_state(envs[1], orcs[1], f"C4 group, acrobot, step {k}")
+    rollout_group(envs, [a_p[T:], a_a[T:]])
+    for k in range(T, T + K):
+        orcs[0].step_mt(hp[k], threads); orcs[1].step_mt(ha[k], threads)
+    _same_state(envs[0], orcs[0], "C4 group rollout, pendulum")
+    _same_state(envs[1], orcs[1], "C4 group rollout, acrobot")
+    for e in envs:
+        e.close()
+
+
 def test_exact_mode_is_refused_where_it_cannot_run():
     import torch
 
@@ -171,12 +209,14 @@ def test_exact_mode_is_refused_where_it_cannot_run():
     from ns_gym_amd.vec_env import step_group
 
     p, a = W.build("pend", 4096, libm_exact=True), W.build("acro", 4096)
-    with pytest.raises(NsgError, match="NSG_F_LIBM_EXACT"):
+    with pytest.raises(NsgError, match="one launch runs one arithmetic"):     # a mixed member list
         step_group([p, a], [W.random_actions(p), W.random_actions(a)])
     p.step(W.random_actions(p))      # on its own unit it steps
+    fl = W.build("c3", 4096, libm_exact=True)       # the grid envs have nothing to choose: the flag is not even set for them ...
+    assert not fl.libm_exact and not fl.specialized
+    with pytest.raises(NsgError, match="every member specialised"):       # ... an exact launch needs its own unit, so every member's
+        step_group([p, fl], [W.random_actions(p), W.random_actions(fl)])
+    fl.specialize()
+    step_group([p, fl], [W.random_actions(p), W.random_actions(fl)])      # ... and then a grid member shares a launch with exact ones
     torch.cuda.synchronize()
-    p.close(); a.close()
-    # the grid envs have nothing to choose: the flag is not even set for them
-    fl = W.build("c3", 4096, libm_exact=True)
-    assert not fl.libm_exact
-    fl.close()
+    p.close(); a.close(); fl.close()
