@@ -21,7 +21,8 @@ one rank and `--gpus` must equal WORLD_SIZE.  It refuses to run on fewer devices
 Prints ONE JSON line on rank 0 (see the task contract) with `roofline`, `roofline_hbm_resident` and `cpu_baseline`.
 At N > 1 `roofline` prices the AGGREGATE: 120 B x `value` against N x 8 TB/s, rank 0's own kernel time beside it.
 `config.baseline_configs_at_own_size`: every BASELINE configuration at the batch size BASELINE quotes it at (C1 2^20, C2 65 536,
-C3 2^20, C4 Pendulum 2^18 + Acrobot 2^18 in one heterogeneous launch), step API and fused rollout, each with its own bytes.
+C3 2^20, C4 Pendulum 2^18 + Acrobot 2^18 in one heterogeneous launch), step API and fused rollout, each with its own bytes; its
+`libm_exact_step_us` times C1 / C2 / C4 through the opt-in bit-exact units (information, never `value`).
 """
 import argparse
 import json
@@ -157,7 +158,43 @@ def baseline_configs_at_own_size(dev, c1_step_us, c1_rollout_rate, n_c1):
                   "acrobot_alone_us": min(acro.time_steps(aa, 200) for _ in range(2)) * 1e3,
                   "bound": "the Acrobot member's float64 vector-ALU issue (RK4: 15 sincos + 12 divisions per step), not HBM"}
     pend.close(); acro.close()
+    try:   # what the opt-in bit-exact arithmetic (NSG_F_LIBM_EXACT: libm's sin / cos / pow / exp, rounding for rounding) costs per step
+        rows["libm_exact_step_us"] = _libm_exact_step_us(dev, n_c1)
+    except Exception as e:
+        rows["libm_exact_error"] = f"{type(e).__name__}: {e}"[:200]
     return rows
+
+
+def _libm_exact_step_us(dev, n_c1):
+    """`VecNSEnv(libm_exact=True)`: float64 state equal to the reference's in every bit (tests/test_gpu_libm_exact.py).  The same
+    configs at the same sizes as the rows above, through the exact unit (hiprtc builds it here); C4's pair in its one group launch."""
+    import torch
+
+    from ns_gym_amd import workloads as W
+    from ns_gym_amd.vec_env import step_group
+
+    out = {}
+    for tag, name, n in (("C1", "c1", n_c1), ("C2", "c2", None)):
+        env = W.build(name, n, specialize=True, device=dev, libm_exact=True)
+        a = W.random_actions(env)
+        for _ in range(30):
+            env.step(a)
+        out[tag] = min(env.time_steps(a, 300) for _ in range(2)) * 1e3
+        env.close()
+    pend, acro = W.build("pend", specialize=True, device=dev, libm_exact=True), W.build("acro", specialize=True, device=dev, libm_exact=True)
+    ap_, aa = W.random_actions(pend), W.random_actions(acro)
+    for _ in range(20):
+        step_group([pend, acro], [ap_, aa])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200):
+        step_group([pend, acro], [ap_, aa])
+    e1.record()
+    torch.cuda.synchronize()
+    out["C4"] = e0.elapsed_time(e1) * 1e3 / 200
+    pend.close(); acro.close()
+    return out
 
 
 def _fused_closed_loop_us(env, name, K=64, reps=8):
