@@ -85,7 +85,7 @@ template <int ENV> __device__ __forceinline__ void env_obs(const double* s, floa
   } else if constexpr (ENV == NSG_ENV_PENDULUM) {
     double sn, cs;
 #if NSG_LIBM_EXACT
-    cs = env_cos(s[0]); sn = env_sin(s[0]);
+    cs = env_cos_any(s[0]); sn = env_sin_any(s[0]);
 #else
     nsg_sincos_t<kLightPoly>(s[0], &sn, &cs);
 #endif
@@ -209,7 +209,7 @@ __device__ __forceinline__ bool env_step(const double* th, double* s, int ai, fl
     const double an = nsg_pymod_pos(t0 + NSG_PI, 2 * NSG_PI) - NSG_PI;  // angle_normalize: ((x + pi) % (2 pi)) - pi [UPSTREAM]
     double costs = env_sq(an) + 0.1 * env_sq(thdot) + 0.001 * env_sqf(u);   // `u ** 2`: a float32 scalar power upstream
 #if NSG_LIBM_EXACT
-    const double sin_t0 = env_sin(t0);
+    const double sin_t0 = env_sin_any(t0);
 #else
     const double sin_t0 = nsg_sin_t<kLightPoly>(t0);
 #endif

@@ -96,6 +96,107 @@ NSG_HD int lm_reduce(double x, double& a, double& da) {
   return n;
 }
 
+// do_sin and do_cos in ONE pass, the lane choosing: cosm ? cos(x + dx) : sin(x + dx).  The two share the table index, the table
+// reads and both polynomials, and differ in where dx enters and in how the table values combine; written with selects, a wavefront
+// whose lanes sit in different argument ranges (Pendulum's angle, Acrobot's) evaluates ONE body instead of do_sin, do_cos and
+// their callers' variants one after the other.  Every lane's operation sequence is do_sin's or do_cos's own: same bits.
+NSG_HD double lm_do_sincos(const LibmTab tb, double x, double dx, bool cosm) {
+  const double big = 52776558133248.0, sn3 = -0.16666666666666488, sn5 = 0.008333332142857223, cs2 = 0.5,
+               cs4 = -0.04166666666666644, cs6 = 0.001388888740079376;
+  const double ax = lm_abs(x);
+  const double d = x < 0.0 ? -dx : dx;            // (do_sin tests !(x > 0): the same but at x = 0, where TAYLOR_SIN answers)
+  const double u = big + ax;
+  const double base = ax - (u - big);
+  const double xr = cosm ? base + d : base;
+  const int k = (int)((unsigned)lm_bits(u) << 2);
+  const double xx = xr * xr;
+  const double p = __builtin_fma(xx, sn5, sn3);
+  const double q = __builtin_fma(xx, __builtin_fma(xx, cs6, cs4), cs2);
+  const double t3 = xr * xx, xq = xx * q;
+  const double s = cosm ? __builtin_fma(t3, p, xr) : xr + __builtin_fma(t3, p, d);
+  const double c = cosm ? xq : __builtin_fma(xr, d, xq);
+  const double sn = tb.x[k], ssn = tb.x[k + 1], cs = tb.x[k + 2], ccs = tb.x[k + 3];
+  const double s1 = cosm ? -s : s;
+  const double lead = cosm ? cs : sn;
+  const double cor = __builtin_fma(s1, cosm ? sn : cs, __builtin_fma(-c, lead, __builtin_fma(s1, cosm ? ssn : ccs, cosm ? ccs : ssn)));
+  const double r = lead + cor;
+  if (!cosm && ax < 0.126) return lm_taylor_sin(x, dx);
+  return cosm ? r : lm_copysign(lm_abs(r), x);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NSG_LM_ALL(c) __all(c)
+#else
+#define NSG_LM_ALL(c) (c)
+#endif
+
+// __sin / __cos with the ranges merged: each lane prepares its own (argument, tail, which function, sign) and one lm_do_sincos serves
+// them all.  FAST: when every lane of the wavefront is in the no-reduction range the plain do_sin / do_cos runs - no selects.
+// tests/test_libm_sincos_cpu.py runs both instantiations, and the branchy form below, against libm.
+template <bool FAST>
+NSG_HD double nsg_sin_libm_merged(const LibmTab tb, double x) {
+  const double hp0 = 1.5707963267948966, hp1 = 6.123233995736766e-17;
+  const unsigned k = (unsigned)((unsigned long long)lm_bits(x) >> 32) & 0x7fffffffu;
+  if (FAST && NSG_LM_ALL(k >= 0x3e500000u && k < 0x3feb6000u)) return lm_do_sin(tb, x, 0.0);   // 2^-26 <= |x| < 0.855469
+  double a = x, da = 0.0;
+  bool cosm = false;
+  int n = 0;
+  if (k >= 0x3feb6000u) {
+    if (k < 0x400368fdu) {                                           // |x| < 2.426265: sin x = +-cos(pi/2 - |x|)
+      a = hp0 - lm_abs(x);
+      da = hp1;
+      cosm = true;
+    } else if (k < 0x419921fbu) {                                    // |x| < 105414336
+      n = lm_reduce(x, a, da);
+      cosm = (n & 1) != 0;
+    }
+  }
+  double r = lm_do_sincos(tb, a, da, cosm);
+  if (k >= 0x3feb6000u && k < 0x400368fdu) r = lm_copysign(lm_abs(r), x);
+  if (n & 2) r = -r;
+  if (k < 0x3e500000u) r = x;                                        // |x| < 2^-26
+  if (k >= 0x419921fbu) {                                            // (the reference: __branred; never reached by an episode)
+    double sn, cs;
+    nsg_sincos(x, &sn, &cs);
+    r = sn;
+  }
+  return r;
+}
+
+template <bool FAST>
+NSG_HD double nsg_cos_libm_merged(const LibmTab tb, double x) {
+  const double hp0 = 1.5707963267948966, hp1 = 6.123233995736766e-17;
+  const unsigned k = (unsigned)((unsigned long long)lm_bits(x) >> 32) & 0x7fffffffu;
+  if (FAST && NSG_LM_ALL(k >= 0x3e400000u && k < 0x3feb6000u)) return lm_do_cos(tb, x, 0.0);   // 2^-27 <= |x| < 0.855469
+  double a = x, da = 0.0;
+  bool cosm = true;
+  int n = 0;
+  if (k >= 0x3feb6000u) {
+    if (k < 0x400368fdu) {                                           // cos x = sin(pi/2 - |x|)
+      const double y = hp0 - lm_abs(x);
+      a = y + hp1;
+      da = (y - a) + hp1;
+      cosm = false;
+    } else if (k < 0x419921fbu) {
+      n = lm_reduce(x, a, da) + 1;
+      cosm = (n & 1) != 0;
+    }
+  }
+  double r = lm_do_sincos(tb, a, da, cosm);
+  if (n & 2) r = -r;
+  if (k < 0x3e400000u) r = 1.0;                                      // |x| < 2^-27
+  if (k >= 0x419921fbu) {
+    double sn, cs;
+    nsg_sincos(x, &sn, &cs);
+    r = cs;
+  }
+  return r;
+}
+
+// __sin / __cos as written: one branch per argument range.  What the exact units of CartPole (one range per wavefront anyway), Acrobot
+// and the MountainCars call: there the merged form buys nothing and costs registers (MountainCar's fused rollout 71 -> 81 VGPRs, seven
+// wavefronts per SIMD -> five: +8 % per step; Acrobot +5 %), while Pendulum - whose angle is anywhere - gains 15 % per step from it
+// (12.9 -> 11.0 us at 2^18 envs; profiles/NOTEBOOK.md).
 NSG_HD double nsg_sin_libm(const LibmTab tb, double x) {
   const double hp0 = 1.5707963267948966, hp1 = 6.123233995736766e-17;
   const unsigned k = (unsigned)((unsigned long long)lm_bits(x) >> 32) & 0x7fffffffu;
@@ -256,6 +357,9 @@ __device__ static const unsigned long long kLibmPowfTab[NSG_POWF_TAB_WORDS] = {
 };
 __device__ __forceinline__ double env_sin(double x) { return nsg_sin_libm(LibmTab{reinterpret_cast<const double*>(kLibmSincosTab)}, x); }
 __device__ __forceinline__ double env_cos(double x) { return nsg_cos_libm(LibmTab{reinterpret_cast<const double*>(kLibmSincosTab)}, x); }
+// (Pendulum: lanes in every argument range at once)
+__device__ __forceinline__ double env_sin_any(double x) { return nsg_sin_libm_merged<true>(LibmTab{reinterpret_cast<const double*>(kLibmSincosTab)}, x); }
+__device__ __forceinline__ double env_cos_any(double x) { return nsg_cos_libm_merged<true>(LibmTab{reinterpret_cast<const double*>(kLibmSincosTab)}, x); }
 // `x ** 2` on a float64 / float32 SCALAR is libm's pow / powf in the reference (Acrobot's _dsdt, Pendulum's step), not the product
 __device__ __forceinline__ double env_sq(double x) { return nsg_sq_libm(PowTab{kNsgPowTab}, x); }
 __device__ __forceinline__ double env_sqf(double x) { return (double)nsg_sqf_libm(PowTab{kLibmPowfTab}, (float)x); }

@@ -37,7 +37,9 @@ long t_compare(const double* x, long n, double* first_bad) {
   long bad = 0;
   for (long i = 0; i < n; i++) {
     const double s = nsg::nsg_sin_libm(tb, x[i]), c = nsg::nsg_cos_libm(tb, x[i]), ls = psin(x[i]), lc = pcos(x[i]);
-    if (memcmp(&s, &ls, 8) || memcmp(&c, &lc, 8)) { if (!bad) *first_bad = x[i]; bad++; }
+    const double s2 = nsg::nsg_sin_libm_merged<false>(tb, x[i]), c2 = nsg::nsg_cos_libm_merged<false>(tb, x[i]);      // the merged body for every range
+    const double s3 = nsg::nsg_sin_libm_merged<true>(tb, x[i]), c3 = nsg::nsg_cos_libm_merged<true>(tb, x[i]);
+    if (memcmp(&s, &ls, 8) || memcmp(&c, &lc, 8) || memcmp(&s2, &ls, 8) || memcmp(&c2, &lc, 8) || memcmp(&s3, &ls, 8) || memcmp(&c3, &lc, 8)) { if (!bad) *first_bad = x[i]; bad++; }
   }
   return bad;
 }
