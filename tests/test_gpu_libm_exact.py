@@ -83,6 +83,69 @@ def test_open_loop_state_equals_oracle_bit_for_bit(name, T):
     env.close()
 
 
+def _classic(spec):
+    return spec["env_id"].split("-")[0] in ("CartPole", "Pendulum", "Acrobot", "MountainCar", "MountainCarContinuous")
+
+
+def test_the_references_planner_and_harness_loops_bit_for_bit():
+    """The fixtures the reference's own MCTS._default_policy and run_episode produced (tests/golden/policy_*.npz), classic-control
+    cases, through exact units with NO exception: Pendulum's discounted returns, episode totals and every action its linear agent
+    chose included (the default kernels need 1e-7 / 2e-5 there); the planning-copy fixtures (get_planning_env / deepcopy) likewise."""
+    from tests.policy_cases import EPISODE_CASES, MCTS_CASES, HipSide, run_episode_case, run_mcts_case
+    from tests.test_gpu_planning import _PlanView
+    from tests.test_oracle_planning import PLAN, run_planning
+
+    done = 0
+    for name, spec in MCTS_CASES.items():
+        if _classic(spec):
+            run_mcts_case(HipSide, name, strict=True, libm_exact=True); done += 1
+    for name, spec in EPISODE_CASES.items():
+        if _classic(spec):
+            run_episode_case(HipSide, name, strict=True, libm_exact=True); done += 1
+    for name, spec in PLAN.items():
+        if _classic(spec):
+            run_planning(lambda *a, **k: _vec(*a, libm_exact=True, **k), _PlanView, name, lambda env, mode: env.fork(theta_mode=mode, entropy=99), strict=True); done += 1
+    assert done >= 8, done
+
+
+@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("NSG_SWEEP_EXACT_CASES", "40"))))
+def test_random_classic_control_configuration_is_exact(case):
+    """The random-configuration sweep of tests/test_gpu_random_configs.py (any env type, 1-3 parameters, every scheduler and update
+    function of the catalogue, every wrapper flag) for the classic-control envs through exact units: where that sweep compares at
+    1e-5 and skips Acrobot envs that have left the oracle's episode, this one demands every bit of every env - float64 state,
+    observation, reward, theta, t, flags - and the counters, Acrobot included."""
+    import torch
+
+    from ns_gym_amd.envs import make
+    from ns_gym_amd.spec import build_tunable_params
+    from tests.golden.make_golden import make_actions
+    from tests.test_gpu_random_configs import GRID, _decode, random_spec
+
+    rng = np.random.default_rng(70_000 + case)
+    for _ in range(50):
+        spec = random_spec(rng)
+        if spec["env_id"] not in GRID:
+            break
+    n = int(rng.choice([1, 63, 64, 65, 200, 257, 700]))
+    T = 60
+    kw = {**spec["flags"], **_decode(spec), "track_returns": True}
+    env = _vec(make(spec["env_id"], **spec["make_kwargs"]), build_tunable_params(spec["params"]), n, libm_exact=True, **kw)
+    orc = _orc(make(spec["env_id"], **spec["make_kwargs"]), build_tunable_params(spec["params"]), n, **kw)
+    seeds = rng.integers(0, 2 ** 40, size=n).astype(np.uint64)
+    env.reset(seed=seeds); orc.reset(seed=seeds)
+    tag = f"case {case}: {spec}"
+    _same_state(env, orc, tag + " reset")
+    acts = make_actions(spec["env_id"], T, n)
+    for k in range(T):
+        env.step(torch.from_numpy(acts[k]).cuda()); orc.step(acts[k])
+        if k % 10 == 9 or k == T - 1:
+            _same_state(env, orc, tag + f" step {k}")
+    c = env.counters()
+    oc = orc.a["counters"].sum(axis=1)
+    assert [c["episodes"], c["updates_applied"], c["constraint_violations"], c["env_steps"]] == [int(x) for x in oc[:4]], tag
+    env.close()
+
+
 def test_closed_loop_on_the_unstable_plant_stays_exact():
     """C2's config under the balancing linear policy: the case in which the default sincos and libm's part ways after ~270 steps
     (0.4 % of the envs within 4000 steps).  With libm's arithmetic: every env, every row, every account, 3000 steps."""

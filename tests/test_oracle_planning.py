@@ -11,11 +11,12 @@ from tests.util import MANIFEST, OracleView, load, make_env_from_spec
 PLAN = MANIFEST["planning_specs"]
 
 
-def run_planning(factory, view_cls, name, fork):
-    run_planning_rec(factory, view_cls, PLAN[name], load(f"plan_{name}.npz"), fork)
+def run_planning(factory, view_cls, name, fork, strict=False):
+    run_planning_rec(factory, view_cls, PLAN[name], load(f"plan_{name}.npz"), fork, strict=strict)
 
 
-def run_planning_rec(factory, view_cls, spec, rec, fork):
+def run_planning_rec(factory, view_cls, spec, rec, fork, strict=False):
+    """`strict`: observation, reward (as float32) and theta of the copy's steps in every bit (the oracle; the kernels' libm_exact units)."""
     env = make_env_from_spec(factory, {**spec, "seeds": [spec["seed"]]}, n=1)
     v = view_cls(env)
     is_fl = spec["env_id"] in ("FrozenLake-v1", "CliffWalking-v1")
@@ -40,6 +41,10 @@ def run_planning_rec(factory, view_cls, spec, rec, fork):
         if is_fl:
             assert out["state"].reshape(-1)[0] == rec["state"][j, 0], tag
             assert out["prob"][0] == pytest.approx(rec["prob"][j], rel=1e-6), tag
+        elif strict:
+            np.testing.assert_array_equal(np.asarray(out["state"][0], dtype=np.float32), np.asarray(rec["state"][j], dtype=np.float32), err_msg=tag)
+            np.testing.assert_array_equal(out["theta"][:, 0], rec["theta"][j], err_msg=tag)
+            assert np.float32(out["reward"][0]) == np.float32(rec["reward"][j]), tag
         else:
             np.testing.assert_allclose(out["state"][0], rec["state"][j], rtol=1e-5, atol=1e-5, err_msg=tag)
         assert out["t"][0] == rec["relative_time"][j], tag
@@ -55,4 +60,4 @@ def run_planning_rec(factory, view_cls, spec, rec, fork):
 
 @pytest.mark.parametrize("name", sorted(PLAN))
 def test_oracle_planning_env_matches_reference(name):
-    run_planning(OracleVecEnv, OracleView, name, lambda env, mode: env.fork(theta_mode=mode, entropy=99))
+    run_planning(OracleVecEnv, OracleView, name, lambda env, mode: env.fork(theta_mode=mode, entropy=99), strict=True)

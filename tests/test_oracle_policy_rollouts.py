@@ -10,12 +10,12 @@ from tests.policy_cases import EPISODE_CASES, MCTS_CASES, OracleSide, run_episod
 
 @pytest.mark.parametrize("name", sorted(MCTS_CASES))
 def test_oracle_default_policy_matches_reference_mcts(name):
-    run_mcts_case(OracleSide, name)
+    run_mcts_case(OracleSide, name, strict=True)
 
 
 @pytest.mark.parametrize("name", sorted(EPISODE_CASES))
 def test_oracle_closed_loop_matches_reference_run_episode(name):
-    run_episode_case(OracleSide, name)
+    run_episode_case(OracleSide, name, strict=True)
 
 
 def test_oracle_policy_bits_are_the_python_restatement():
