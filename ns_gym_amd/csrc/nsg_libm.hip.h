@@ -1,14 +1,17 @@
-// nsg_libm.hip.h — float64 sin / cos that return what the reference's sin / cos return, bit for bit.
+// nsg_libm.hip.h — the transcendentals of the integrators as the reference's host evaluates them, bit for bit: float64 sin / cos,
+// `x ** 2` on a float64 / float32 scalar (libm's pow / powf), and the switch (NSG_LIBM_EXACT) that routes a unit through them.
+// (exp and log1p: nsg_math.hip.h.)
 //
-// The base MDPs call np.sin / np.cos on float64 scalars; NumPy 2.2 resolves those to libm's sin / cos (on this image: glibc 2.35,
-// whose x86-64 entry points dispatch to the FMA build of sysdeps/ieee754/dbl-64/s_sin.c on every CPU with FMA + AVX2).  An
-// integrator that is to reproduce the reference's float64 STATE - not merely stay within a tolerance until an unstable plant or a
-// chaotic one has amplified the last ulp (Acrobot, a balanced CartPole: profiles/NOTEBOOK.md) - has to evaluate the same
+// sin / cos.  The base MDPs call np.sin / np.cos on float64 scalars; NumPy 2.2 resolves those to libm's sin / cos (on this image:
+// glibc 2.35, whose x86-64 entry points dispatch to the FMA build of sysdeps/ieee754/dbl-64/s_sin.c on every CPU with FMA + AVX2).
+// An integrator that is to reproduce the reference's float64 STATE - not merely stay within a tolerance until an unstable plant or
+// a chaotic one has amplified the last ulp (Acrobot, a balanced CartPole: profiles/NOTEBOOK.md) - has to evaluate the same
 // algorithm with the same roundings.  This is a restatement of that algorithm [UPSTREAM glibc 2.35, IBM Accurate Mathematical
 // Library: s_sin.c __sin / __cos, do_sin, do_cos, reduce_sincos, TAYLOR_SIN; usncs.h constants], with every fused multiply-add
 // exactly where the image's libm.so.6 has one (read off the disassembly of its FMA variant; tools/extract_libm_sincos_table.py
-// documents the table), for |x| < 105414336 (high word below 0x419921fb; beyond that the reference takes __branred; no episode gets there, and nsg_sincos
-// answers).  tests/test_libm_sincos_cpu.py compiles this header for the host and compares it with libm over 4e8 arguments: equal.
+// documents the table), for |x| < 105414336 (high word below 0x419921fb; beyond that the reference takes __branred; no episode
+// gets there, and nsg_sincos answers).  tests/test_libm_sincos_cpu.py compiles this header for the host and compares every form
+// below with libm over 1.6e7 arguments in every range and around every threshold: equal.
 //
 // Everything outside __builtin_fma is a single IEEE operation (the build has -ffp-contract=off).
 #pragma once
