@@ -48,18 +48,27 @@ POLICIES = [
 ]
 POLICY_KIND_NAMES = {0: "action table", 1: "uniform", 2: "by state", 3: "linear"}
 GROUPS = [
-    ("C4 Pendulum + Acrobot in one launch (nsg_step_group / nsg_rollout_group)", [("pend", 1 << 18), ("acro", 1 << 18)], True),
-    ("C4 without episode accounting", [("pend", 1 << 18), ("acro", 1 << 18)], False),
+    ("C4 Pendulum + Acrobot in one launch (nsg_step_group / nsg_rollout_group)", [("pend", 1 << 18), ("acro", 1 << 18)], True, False),
+    ("C4 without episode accounting", [("pend", 1 << 18), ("acro", 1 << 18)], False, False),
+    ("C4 in one launch, NSG_F_LIBM_EXACT (both members)", [("pend", 1 << 18), ("acro", 1 << 18)], True, True),
+]
+# the same configurations with NSG_F_LIBM_EXACT (`libm_exact=True`: libm's sin / cos / pow / exp / log1p, rounding for rounding), so
+# that the bit-exact arithmetic of the BASELINE configurations needs no runtime compiler either
+EXACT = [
+    ("C1 / C5 with NSG_F_LIBM_EXACT, 2^20 envs", "c1", 1 << 20, True),
+    ("C2 with NSG_F_LIBM_EXACT, 65 536 envs", "c2", 1 << 16, True),
+    ("C4 member Pendulum with NSG_F_LIBM_EXACT, 2^18 envs", "pend", 1 << 18, True),
+    ("C4 member Acrobot with NSG_F_LIBM_EXACT, 2^18 envs", "acro", 1 << 18, True),
 ]
 
 
-def _config(name, track_returns):
+def _config(name, track_returns, libm_exact=False):
     from . import make
     from .workloads import WORKLOADS
 
     w = WORKLOADS[name]
     return compile_config(make(w["env_id"], **w["make_kwargs"]), w["params"](), change_notification=True,
-                          delta_change_notification=True, track_returns=track_returns, **w["wrapper_kwargs"])[0]
+                          delta_change_notification=True, track_returns=track_returns, libm_exact=libm_exact, **w["wrapper_kwargs"])[0]
 
 
 def _kernel_resources(path):
@@ -98,8 +107,8 @@ def build_all(directory: str = DIR, arch: str = ARCH, verbose: bool = False) -> 
                 raise RuntimeError(f"prebuilt unit {fname} ({tag}): kernel {kern} spills vector registers / owns scratch: {r}")
         manifest[fname] = {"what": tag, "arch": arch, "kernels": res}
 
-    for tag, name, n, track in SINGLES:
-        cfg = _config(name, track)
+    for tag, name, n, track, exact in [(*e, False) for e in SINGLES] + [(*e, True) for e in EXACT]:
+        cfg = _config(name, track, exact)
         before = set(os.listdir(directory))
         _lib.check(lib.nsg_spec_prebuild(C.byref(cfg), n, arch.encode(), directory.encode()), f"nsg_spec_prebuild({name}, {n})")
         new = set(os.listdir(directory)) - before
@@ -116,8 +125,8 @@ def build_all(directory: str = DIR, arch: str = ARCH, verbose: bool = False) -> 
             inspect(newest(before), f"{tag}: {POLICY_KIND_NAMES[kind]}")
             if verbose:
                 print("prebuilt", tag, POLICY_KIND_NAMES[kind], file=sys.stderr)
-    for tag, members, track in GROUPS:
-        cfgs = [_config(name, track) for name, _ in members]
+    for tag, members, track, exact in GROUPS:
+        cfgs = [_config(name, track, exact) for name, _ in members]
         arr = (C.c_void_p * len(cfgs))(*[C.addressof(c) for c in cfgs])
         ns = (C.c_int64 * len(cfgs))(*[n for _, n in members])
         before = set(os.listdir(directory))

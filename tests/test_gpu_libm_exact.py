@@ -264,6 +264,22 @@ def test_c4_as_one_group_launch_at_full_size_is_exact():
         e.close()
 
 
+def test_baseline_configurations_have_prebuilt_exact_units():
+    """The exact units of the BASELINE configurations ship with the library (built and inspected by `build()`, ns_gym_amd/prebuilt.py):
+    bit-exact arithmetic without a runtime compiler on the box."""
+    from ns_gym_amd import workloads as W
+    from ns_gym_amd.vec_env import step_group, step_group_kind
+
+    envs = {name: W.build(name, libm_exact=True) for name in ("c1", "c2", "pend", "acro")}
+    for name, e in envs.items():
+        assert e.libm_exact and e.kernels == "config-specialised (prebuilt)", (name, e.kernels)
+    pair = [envs["pend"], envs["acro"]]
+    step_group(pair, [W.random_actions(e) for e in pair])
+    assert step_group_kind(pair) == "specialised (prebuilt)"
+    for e in envs.values():
+        e.close()
+
+
 def test_exact_mode_is_refused_where_it_cannot_run():
     import torch
 

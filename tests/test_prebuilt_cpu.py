@@ -19,7 +19,7 @@ def units(tmp_path_factory):
 def test_every_listed_unit_is_built_and_clean(units):
     d, manifest = units
     files = sorted(f for f in os.listdir(d) if f.endswith(".hsaco"))
-    assert files == sorted(manifest) and len(files) == len(prebuilt.SINGLES) + len(prebuilt.GROUPS) + sum(len(p[4]) for p in prebuilt.POLICIES)
+    assert files == sorted(manifest) and len(files) == len(prebuilt.SINGLES) + len(prebuilt.EXACT) + len(prebuilt.GROUPS) + sum(len(p[4]) for p in prebuilt.POLICIES)
     kernels = 0
     for f, m in manifest.items():
         assert m["arch"] == "gfx950:sramecc+:xnack-"
@@ -32,8 +32,12 @@ def test_every_listed_unit_is_built_and_clean(units):
     assert text.count("vgpr_spill 0") == kernels and "C2 CartPole gravity RandomWalk" in text
     assert json.load(open(os.path.join(d, "manifest.json"))) == manifest
     # the CartPole step kernels keep the 6 wavefronts per SIMD the launch policy is built on (<= 80 VGPRs)
-    c1 = next(m for m in manifest.values() if m["what"].startswith("C1 / C5"))
+    c1 = next(m for m in manifest.values() if m["what"].startswith("C1 / C5 CartPole"))
     assert c1["kernels"]["nsg_spec_step"]["vgpr_count"] <= 80
+    # the NSG_F_LIBM_EXACT units of the same configurations ship too (and the exact C1 step kernel keeps those 6 wavefronts)
+    exact = [m for m in manifest.values() if "NSG_F_LIBM_EXACT" in m["what"]]
+    assert len(exact) == len(prebuilt.EXACT) + 1
+    assert next(m for m in exact if m["what"].startswith("C1 / C5"))["kernels"]["nsg_spec_step"]["vgpr_count"] <= 80
 
 
 def test_keys_are_stable_and_depend_on_what_they_should(units, tmp_path):
