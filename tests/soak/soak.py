@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Long-horizon parity soak: a BASELINE config stepped T times (tens of thousands of steps, thousands of autoresets per env)
 on the GPU and by the oracle's OpenMP stepper, every compared row checked every `--every` steps.
-    python tools/soak.py --spec c2_cartpole_gravity_rw --n 65536 --steps 20000"""
+    python tests/soak/soak.py --spec c2_cartpole_gravity_rw --n 65536 --steps 20000"""
 import argparse
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 

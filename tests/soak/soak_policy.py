@@ -4,13 +4,13 @@ of steps on the GPU, and the oracle's restatement of the same loop (orc_rollout_
 rows and episode accounts are compared.  A closed loop is the hardest case for parity: one differing observation bit can flip a
 decision, after which the two trajectories have nothing to do with each other - so every env that left the bar is counted and shown.
 
-    python tools/soak_policy.py c2 65536 4000 500        # workload, envs, steps, chunk
-    python tools/soak_policy.py c2 65536 4000 500 exact  # the same through the NSG_F_LIBM_EXACT unit (libm's sin / cos / exp, bit for bit)"""
+    python tests/soak/soak_policy.py c2 65536 4000 500        # workload, envs, steps, chunk
+    python tests/soak/soak_policy.py c2 65536 4000 500 exact  # the same through the NSG_F_LIBM_EXACT unit (libm's sin / cos / exp, bit for bit)"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 
