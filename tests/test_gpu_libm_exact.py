@@ -264,6 +264,36 @@ def test_c4_as_one_group_launch_at_full_size_is_exact():
         e.close()
 
 
+def test_resident_stepper_of_an_exact_batch_is_exact():
+    """The resident closed loop (nsg_resident_start: one kernel, K steps, the policy in another kernel) of a libm_exact batch runs the exact
+    arithmetic too: bit-identical to K step() calls of a second exact batch - which the tests above hold equal to the oracle."""
+    import torch
+
+    from ns_gym_amd import workloads as W
+    from ns_gym_amd.vec_env import ResidentStepper
+    from tests.test_gpu_resident import _policy, _same
+
+    n, K = 1 << 16, 600
+    ref = W.build("c2", n, seed=11, track_returns=False, libm_exact=True)
+    env = W.build("c2", n, seed=11, track_returns=False, libm_exact=True)
+    a = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for k in range(K):
+        _policy(ref, k, a)
+        ref.step(a)
+    loop = ResidentStepper(env, torch.zeros(n, dtype=torch.int32, device="cuda"), wait_budget_us=50_000)
+    loop.start(K)
+    loop.demo_policy(K, stream=torch.cuda.Stream())
+    assert loop.result() == ("finished", K)
+    _same(env, ref, f"exact c2 after {K} resident steps")
+    # ... and not the default arithmetic's: a default batch under the same loop has parted from it by now
+    dflt = W.build("c2", n, seed=11, track_returns=False)
+    for k in range(K):
+        _policy(dflt, k, a)
+        dflt.step(a)
+    assert not torch.equal(dflt.phys, ref.phys)
+    env.close(); ref.close(); dflt.close()
+
+
 def test_baseline_configurations_have_prebuilt_exact_units():
     """The exact units of the BASELINE configurations ship with the library (built and inspected by `build()`, ns_gym_amd/prebuilt.py):
     bit-exact arithmetic without a runtime compiler on the box."""

@@ -81,9 +81,14 @@ def test_host_driven_rows_then_silence_leaves_exactly_those_steps():
     for a in acts:
         ref.step(a)
     buf = torch.zeros(n, dtype=torch.int32, device="cuda")
-    loop = ResidentStepper(env, buf, wait_budget_us=20_000)
-    loop.start(100)
+    # (the budget is what the kernel waits for a row before it calls itself starved: generous, so that a cold process - first use of
+    # torch's copy / reduction kernels on the producer's side - cannot lose the first row; the ops are warmed up anyway)
     side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        buf.copy_(acts[0]); int(buf.to(torch.int64).min()); buf.zero_()
+    side.synchronize()
+    loop = ResidentStepper(env, buf, wait_budget_us=300_000)
+    loop.start(100)
     side.wait_event(loop._zeroed)
     with torch.cuda.stream(side):
         for k, a in enumerate(acts):
