@@ -103,6 +103,7 @@ NSG_HD int lm_reduce(double x, double& a, double& da) {
 // reads and both polynomials, and differ in where dx enters and in how the table values combine; written with selects, a wavefront
 // whose lanes sit in different argument ranges (Pendulum's angle, Acrobot's) evaluates ONE body instead of do_sin, do_cos and
 // their callers' variants one after the other.  Every lane's operation sequence is do_sin's or do_cos's own: same bits.
+// |x| < 0.8555 (the callers' ranges, as for do_sin / do_cos): the table index is the low word of 2^45 * 1.5 + |x|, 0 .. 4 * 109.
 NSG_HD double lm_do_sincos(const LibmTab tb, double x, double dx, bool cosm) {
   const double big = 52776558133248.0, sn3 = -0.16666666666666488, sn5 = 0.008333332142857223, cs2 = 0.5,
                cs4 = -0.04166666666666644, cs6 = 0.001388888740079376;
@@ -154,6 +155,7 @@ NSG_HD double nsg_sin_libm_merged(const LibmTab tb, double x) {
       cosm = (n & 1) != 0;
     }
   }
+  if (k >= 0x419921fbu) a = 0.0;        // (answered below; its bits must not reach the table index of the shared evaluation)
   double r = lm_do_sincos(tb, a, da, cosm);
   if (k >= 0x3feb6000u && k < 0x400368fdu) r = lm_copysign(lm_abs(r), x);
   if (n & 2) r = -r;
@@ -185,6 +187,7 @@ NSG_HD double nsg_cos_libm_merged(const LibmTab tb, double x) {
       cosm = (n & 1) != 0;
     }
   }
+  if (k >= 0x419921fbu) a = 0.0;        // (answered below; its bits must not reach the table index of the shared evaluation)
   double r = lm_do_sincos(tb, a, da, cosm);
   if (n & 2) r = -r;
   if (k < 0x3e400000u) r = 1.0;                                      // |x| < 2^-27

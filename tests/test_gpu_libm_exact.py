@@ -264,6 +264,35 @@ def test_c4_as_one_group_launch_at_full_size_is_exact():
         e.close()
 
 
+def test_angles_beyond_the_restated_range_are_harmless():
+    """Pendulum's exact unit evaluates libm's sin / cos with the argument ranges merged into one body, which every lane runs: an angle
+    beyond the restated range (|x| >= 105414336 - no episode gets there, a poked state does), inf or NaN must not reach that body's
+    table index.  Such lanes get the fallback's answer (a value in [-1, 1], or NaN), their neighbours stay exact."""
+    import torch
+
+    from ns_gym_amd import make, workloads as W
+
+    n = 4096
+    w = W.WORKLOADS["pend"]
+    env = W.build("pend", n, libm_exact=True, track_returns=False, seed=3)
+    orc = _orc(make(w["env_id"]), w["params"](), n, change_notification=True, delta_change_notification=True)
+    orc.reset(seed=3)
+    wild = torch.tensor([105414336.0, 1e9, -1e10, 3.3e12, 2.0 ** 45, 1.5 * 2.0 ** 45, -2.0 ** 52, 1e100, -1e300, float("inf"), float("-inf"), float("nan")],
+                        dtype=torch.float64, device="cuda")
+    idx = torch.arange(0, n, n // wild.numel(), device="cuda")[:wild.numel()]
+    env.phys[0, idx] = wild
+    a = W.random_actions(env)
+    for _ in range(3):
+        env.step(a); orc.step(a.cpu().numpy())
+    torch.cuda.synchronize()
+    obs = env.state.cpu().numpy()
+    poked = np.zeros(n, dtype=bool); poked[idx.cpu().numpy()] = True
+    assert np.all((np.abs(obs[poked, :2]) <= 1.0) | np.isnan(obs[poked, :2]))
+    got, want = env.phys.cpu().numpy()[:, ~poked], orc.a["phys"][:2][:, ~poked]
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    env.close()
+
+
 def test_resident_stepper_of_an_exact_batch_is_exact():
     """The resident closed loop (nsg_resident_start: one kernel, K steps, the policy in another kernel) of a libm_exact batch runs the exact
     arithmetic too: bit-identical to K step() calls of a second exact batch - which the tests above hold equal to the oracle."""

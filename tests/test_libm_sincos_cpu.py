@@ -64,6 +64,20 @@ long t_compare_sqf(const float* x, long n, float* first_bad, long* not_product) 
   }
   return bad;
 }
+// beyond the restated range (|x| >= 105414336, inf, NaN) every form answers with the kernels' own sincos - and none lets such bits reach its
+// table index: returns how many of the n arguments give different answers in the three forms (NaN == NaN here)
+long t_extremes_differ(const double* x, long n) {
+  double tab[NSG_SINCOS_TAB_WORDS];
+  memcpy(tab, TABW, sizeof(tab));
+  const nsg::LibmTab tb{tab};
+  long bad = 0;
+  for (long i = 0; i < n; i++) {
+    const double s1 = nsg::nsg_sin_libm(tb, x[i]), s2 = nsg::nsg_sin_libm_merged<false>(tb, x[i]), s3 = nsg::nsg_sin_libm_merged<true>(tb, x[i]);
+    const double c1 = nsg::nsg_cos_libm(tb, x[i]), c2 = nsg::nsg_cos_libm_merged<false>(tb, x[i]), c3 = nsg::nsg_cos_libm_merged<true>(tb, x[i]);
+    if (memcmp(&s1, &s2, 8) || memcmp(&s1, &s3, 8) || memcmp(&c1, &c2, 8) || memcmp(&c1, &c3, 8)) bad++;
+  }
+  return bad;
+}
 long t_merged_sincos_differs(const double* x, long n) {   // what gcc's sincos() merge would have compared against
   long bad = 0;
   for (long i = 0; i < n; i++) { double s, c; sincos(x[i], &s, &c); const double ls = psin(x[i]), lc = pcos(x[i]); if (s != ls || c != lc) bad++; }
@@ -82,6 +96,7 @@ def m():
     lib = C.CDLL(so)
     lib.t_compare.restype = C.c_long
     lib.t_merged_sincos_differs.restype = C.c_long
+    lib.t_extremes_differ.restype = C.c_long
     lib.t_compare_sq.restype = C.c_long
     lib.t_compare_sqf.restype = C.c_long
     return lib
@@ -118,6 +133,14 @@ def test_sin_and_cos_equal_libm_bit_for_bit(m):
         assert n == 0, (n, first)
         total += x.size
     assert total > 1.6e7
+
+
+def test_arguments_beyond_the_restated_range_never_reach_a_table_index(m):
+    """|x| >= 105414336, inf, NaN: the merged form evaluates its shared body for every lane, so such lanes must be handed a harmless
+    argument first (their bits as a table index would be a wild read); all three forms give the fallback's answer."""
+    x = np.array([105414336.0, 105414337.0, 1e9, -1e10, 3.3e12, 2.0 ** 45, 2.0 ** 45 * 1.5, -2.0 ** 52, 1e100, -1e300, np.inf, -np.inf, np.nan,
+                  np.nextafter(105414336.0, 0)] + list(np.random.default_rng(8).uniform(-1e15, 1e15, 2000)))
+    assert m.t_extremes_differ(x.ctypes.data_as(C.c_void_p), C.c_long(x.size)) == 0
 
 
 @pytest.mark.skipif(not _fma_libm(), reason="needs the FMA build")
