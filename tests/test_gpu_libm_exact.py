@@ -293,6 +293,34 @@ def test_angles_beyond_the_restated_range_are_harmless():
     env.close()
 
 
+@pytest.mark.parametrize("exact", [False, True])
+def test_blown_up_acrobot_states_end_every_launch(exact):
+    """acrobot_constraints lets the link parameters drift until RK4 blows up (~40 steps): angles of 1e60 rad, inf, NaN.  gymnasium's
+    wrap() loop never returns there, so there is no reference behaviour to equal - but every launch has to end, in both arithmetics
+    (nsg_wrap_pi's passes are bounded; beyond 2^56 rad the angle is left as it came), and the envs that did not blow up go on."""
+    import time
+
+    import torch
+
+    from tests.golden.make_golden import make_actions
+
+    spec = TRAJ_SPECS["acrobot_constraints"]
+    n, T = 4096, 300
+    env = make_env_from_spec(_vec, {**spec, "flags": {**spec["flags"], "autoreset": False}}, n=n, **({"libm_exact": True} if exact else {"specialize": True}))
+    env.reset(seed=21)
+    acts = torch.from_numpy(make_actions(spec["env_id"], T, n)).cuda()
+    t0 = time.perf_counter()
+    for k in range(T):
+        env.step(acts[k])
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 20.0
+    ph = env.phys.cpu().numpy()
+    assert (~np.isfinite(ph)).any() or np.abs(ph[:2]).max() > np.pi        # some env did blow up (or stands unwrapped beyond 2^56) ...
+    assert np.isfinite(ph).all(axis=0).sum() > 0                            # ... and not all of them
+    assert int(env.t.min()) == T
+    env.close()
+
+
 def test_resident_stepper_of_an_exact_batch_is_exact():
     """The resident closed loop (nsg_resident_start: one kernel, K steps, the policy in another kernel) of a libm_exact batch runs the exact
     arithmetic too: bit-identical to K step() calls of a second exact batch - which the tests above hold equal to the oracle."""
