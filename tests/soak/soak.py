@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Long-horizon parity soak: a BASELINE config stepped T times (tens of thousands of steps, thousands of autoresets per env)
 on the GPU and by the oracle's OpenMP stepper, every compared row checked every `--every` steps.
-    python tests/soak/soak.py --spec c2_cartpole_gravity_rw --n 65536 --steps 20000"""
+    python tests/soak/soak.py --spec c2_cartpole_gravity_rw --n 65536 --steps 20000
+    python tests/soak/soak.py --spec c4_acrobot_mass2_inc --n 262144 --steps 3000 --exact      # NSG_F_LIBM_EXACT unit: every BIT of the float64 state"""
 import argparse
 import os
 import sys
@@ -21,10 +22,11 @@ ap.add_argument("--n", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=20000)
 ap.add_argument("--every", type=int, default=1000)
 ap.add_argument("--rollout", type=int, default=0, help="drive the GPU side through nsg_rollout, K fused steps per launch")
+ap.add_argument("--exact", action="store_true", help="libm_exact=True, and the comparison is bit for bit (float64 state, observation, reward, theta, t, flags)")
 args = ap.parse_args()
 spec = TRAJ_SPECS[args.spec]
 is_fl = spec["env_id"] == "FrozenLake-v1"
-env = make_env_from_spec(lambda *a, **k: VecNSEnv(*a, **k), spec, n=args.n, track_returns=True, specialize=True)
+env = make_env_from_spec(lambda *a, **k: VecNSEnv(*a, **k), spec, n=args.n, track_returns=True, specialize=True, **({"libm_exact": True} if args.exact else {}))
 orc = make_env_from_spec(OracleVecEnv, spec, n=args.n, track_returns=True)
 seeds = np.arange(args.n, dtype=np.uint64) + np.uint64(777)
 env.reset(seed=seeds)
@@ -46,6 +48,11 @@ for k0 in range(0, args.steps, K):
         orc.step_mt(host[j], threads)
     k = k0 + K - 1
     if (k + 1) % args.every < K or k >= args.steps - 1:
-        compare_views(GpuView(env)._out(), OracleView(orc)._out(), is_fl, f"{args.spec}: step {k}")
-        print(f"step {k + 1}: all {args.n} envs agree ({env.counters()['episodes']:,} episodes so far, {time.time() - t0:.0f} s)", flush=True)
+        if args.exact:
+            from tests.test_gpu_libm_exact import _same_state
+
+            _same_state(env, orc, f"{args.spec}: step {k}")
+        else:
+            compare_views(GpuView(env)._out(), OracleView(orc)._out(), is_fl, f"{args.spec}: step {k}")
+        print(f"step {k + 1}: all {args.n} envs agree{' in every bit' if args.exact else ''} ({env.counters()['episodes']:,} episodes so far, {time.time() - t0:.0f} s)", flush=True)
 print("soak ok")
