@@ -47,6 +47,47 @@ def test_committed_reference_trajectories_bit_for_bit(name):
     env.close()
 
 
+def test_no_autoreset_and_user_extension_fixtures_bit_for_bit():
+    """The other two families of reference-generated trajectories through exact units, strictly: wrappers stepped far past `done`
+    (NSG_F_NO_AUTORESET) and wrappers driving user-defined Scheduler / UpdateFn subclasses - classic-control cases."""
+    from tests.util import MANIFEST, USER_SPECS, build_params
+
+    done = 0
+    for name, spec in MANIFEST["noreset_specs"].items():
+        if _classic(spec):
+            env = make_env_from_spec(_vec, spec, autoreset=False, libm_exact=True)
+            check_trajectory(GpuView(env), spec, load(f"traj_{name}.npz"), strict=True)
+            env.close(); done += 1
+    for name, spec in USER_SPECS.items():
+        if _classic(spec):
+            env = make_env_from_spec(_vec, spec, libm_exact=True)
+            check_trajectory(GpuView(env), spec, load(f"traj_{name}.npz"), strict=True)
+            env.close(); done += 1
+    assert done >= 6, done
+
+
+def test_single_wrapper_with_libm_exact_follows_the_reference_trajectory_bit_for_bit():
+    """The N = 1 adaptor (the reference's class name and return values) forwards `libm_exact`: C1's recorded reference trajectory, 1000
+    steps with resets, observation bits and float64 masspole equal at every step."""
+    import ns_gym_amd as nsg
+    from ns_gym_amd.schedulers import ContinuousScheduler
+    from ns_gym_amd.update_functions import IncrementUpdate
+    from ns_gym_amd.wrappers import NSClassicControlWrapper
+
+    spec, rec = TRAJ_SPECS["c1_cartpole_masspole_inc"], load("traj_c1_cartpole_masspole_inc.npz")
+    env = NSClassicControlWrapper(nsg.make("CartPole-v1"), {"masspole": IncrementUpdate(ContinuousScheduler(), k=0.1)},
+                                  change_notification=True, delta_change_notification=True, libm_exact=True, autoreset=True)
+    assert env._vec.libm_exact
+    obs, info = env.reset(seed=spec["seeds"][0])
+    assert np.array_equal(np.asarray(obs["state"], dtype=np.float32).view(np.uint32), rec["state"][0, 0].view(np.uint32))
+    for k in range(spec["T"]):
+        obs, r, term, trunc, info = env.step(int(rec["actions"][k, 0]))
+        assert np.array_equal(np.asarray(obs["state"], dtype=np.float32).view(np.uint32), rec["state"][k + 1, 0].view(np.uint32)), k
+        assert float(r) == rec["reward"][k, 0] and term == bool(rec["terminated"][k, 0]) and trunc == bool(rec["truncated"][k, 0]), k
+        assert env.unwrapped.masspole == rec["theta"][k + 1, 0, 0], k
+    env.close()
+
+
 @pytest.mark.parametrize("name,T", [("c1_cartpole_masspole_inc", 300), ("c2_cartpole_gravity_rw", 300), ("cartpole_two_params", 200),
                                     ("c4_pendulum_m_inc", 450), ("pendulum_l_and_g", 300), ("c4_acrobot_mass2_inc", 300), ("acrobot_constraints", 25),
                                     ("mountaincar", 450)])
