@@ -17,8 +17,11 @@ from ns_gym_amd import workloads as W  # noqa: E402
 WORK = {k: (v["env_id"], v["params"], v["make_kwargs"], v["bytes_per_env_step"]) for k, v in W.WORKLOADS.items()}
 
 
+EXACT = False
+
+
 def mk(name, n, track=True, spec=False):
-    return W.build(name, n, track_returns=track, specialize=spec)
+    return W.build(name, n, track_returns=track, specialize=spec, **({"libm_exact": True} if EXACT else {}))
 
 
 def actions(e, n):
@@ -34,10 +37,13 @@ def main():
     ap.add_argument("--work", default="c1,c2,c3,pend,acro")
     ap.add_argument("--no-track", action="store_true")
     ap.add_argument("--spec", action="store_true", help="config-specialised kernels (nsg_specialize)")
+    ap.add_argument("--exact", action="store_true", help="libm_exact=True: the NSG_F_LIBM_EXACT units (classic-control workloads)")
     ap.add_argument("--rollout", type=int, default=0, help="K fused steps per launch (nsg_rollout) instead of nsg_step")
     ap.add_argument("--resident", type=int, default=0, help="K steps through ONE resident launch (nsg_resident_start): closed loop with the library's "
                                                               "resident demo policy on a second stream, and open loop (action rows published in advance)")
     args = ap.parse_args()
+    global EXACT
+    EXACT = args.exact
     res = {}
     for name in args.work.split(","):
         n = args.n
