@@ -122,7 +122,7 @@ enum {
                                       reference's bit for bit instead of tracking them within 1e-5.  Runs on the handle's specialised unit only
                                       (nsg_specialize; nsg_step / nsg_rollout / ... refuse an unspecialised handle with this flag).  A group
                                       launch (nsg_step_group / nsg_rollout_group) is exact when ALL its classic-control members carry the flag -
-                                      it then needs the member list's own unit - and is refused when only some do.  Costs +4 % (CartPole) to x 2.1 (Acrobot) per step.  Added within ABI
+                                      it then needs the member list's own unit - and is refused when only some do.  Costs +4 % (CartPole) to x 1.9 (Acrobot) per step.  Added within ABI
                                       version 4: an older library rejects the unknown flag bit. */
 #define NSG_F_KNOWN 0xfdfu         /* every flag bit this header defines; nsg_create refuses any other */
 #define NSG_F_NO_AUTORESET 0x400u  /* a finished env is NOT reset by the next step: it keeps stepping exactly like the reference's single

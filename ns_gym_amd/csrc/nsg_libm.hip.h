@@ -36,10 +36,10 @@ NSG_HD double lm_taylor_sin(double x, double dx) {
   const double s1 = -0.16666666666666666, s2 = 0.008333333333332329, s3 = -0.00019841269834414642, s4 = 2.755729806860771e-06,
                s5 = -2.5022014848318398e-08;
   const double xx = x * x;
-  double p = __builtin_fma(xx, s5, s4);
-  p = __builtin_fma(xx, p, s3);
-  p = __builtin_fma(xx, p, s2);
-  p = __builtin_fma(xx, p, s1);
+  double p = nsg_fma_coef(xx, s5, s4);     // (constant addends through nsg_fma_coef: an SGPR operand of ONE v_fma_f64, not a coefficient parked
+  p = nsg_fma_coef(xx, p, s3);            //  in a VGPR pair for the whole kernel - nsg_math.hip.h; the same single rounding)
+  p = nsg_fma_coef(xx, p, s2);
+  p = nsg_fma_coef(xx, p, s1);
   const double t = __builtin_fma(p, x, -(0.5 * dx));
   return x + __builtin_fma(xx, t, dx);
 }
@@ -55,9 +55,9 @@ NSG_HD double lm_do_sin(const LibmTab tb, double x, double dx) {
   const double xr = ax - (u - big);
   const int k = (int)((unsigned)lm_bits(u) << 2);
   const double xx = xr * xr;
-  const double p = __builtin_fma(xx, sn5, sn3);
+  const double p = nsg_fma_coef(xx, sn5, sn3);
   const double s = xr + __builtin_fma(xr * xx, p, dx);
-  const double q = __builtin_fma(xx, __builtin_fma(xx, cs6, cs4), cs2);
+  const double q = nsg_fma_coef(xx, nsg_fma_coef(xx, cs6, cs4), cs2);
   const double c = __builtin_fma(xr, dx, xx * q);
   const double sn = tb.x[k], ssn = tb.x[k + 1], cs = tb.x[k + 2], ccs = tb.x[k + 3];
   const double cor = __builtin_fma(s, cs, __builtin_fma(-c, sn, __builtin_fma(s, ccs, ssn)));
@@ -74,9 +74,9 @@ NSG_HD double lm_do_cos(const LibmTab tb, double x, double dx) {
   const double xr = (ax - (u - big)) + dx;
   const int k = (int)((unsigned)lm_bits(u) << 2);
   const double xx = xr * xr;
-  const double p = __builtin_fma(xx, sn5, sn3);
+  const double p = nsg_fma_coef(xx, sn5, sn3);
   const double s = __builtin_fma(xr * xx, p, xr);
-  const double c = xx * __builtin_fma(xx, __builtin_fma(xx, cs6, cs4), cs2);
+  const double c = xx * nsg_fma_coef(xx, nsg_fma_coef(xx, cs6, cs4), cs2);
   const double sn = tb.x[k], ssn = tb.x[k + 1], cs = tb.x[k + 2], ccs = tb.x[k + 3];
   const double cor = __builtin_fma(-s, sn, __builtin_fma(-c, cs, __builtin_fma(-s, ssn, ccs)));
   return cs + cor;
@@ -86,7 +86,7 @@ NSG_HD double lm_do_cos(const LibmTab tb, double x, double dx) {
 NSG_HD int lm_reduce(double x, double& a, double& da) {
   const double hpinv = 0.6366197723675814, toint = 6755399441055744.0, mp1 = 1.5707963407039642, mp2 = -1.3909067564377153e-08,
                pp3 = -4.97899623147991e-17, pp4 = -1.9034889620193266e-25;
-  const double t = __builtin_fma(x, hpinv, toint);
+  const double t = nsg_fma_coef(x, hpinv, toint);
   const double xn = t - toint;
   const int n = (int)((unsigned)lm_bits(t) & 3u);
   const double y = __builtin_fma(-xn, mp2, __builtin_fma(-xn, mp1, x));
@@ -114,8 +114,8 @@ NSG_HD double lm_do_sincos(const LibmTab tb, double x, double dx, bool cosm) {
   const double xr = cosm ? base + d : base;
   const int k = (int)((unsigned)lm_bits(u) << 2);
   const double xx = xr * xr;
-  const double p = __builtin_fma(xx, sn5, sn3);
-  const double q = __builtin_fma(xx, __builtin_fma(xx, cs6, cs4), cs2);
+  const double p = nsg_fma_coef(xx, sn5, sn3);
+  const double q = nsg_fma_coef(xx, nsg_fma_coef(xx, cs6, cs4), cs2);
   const double t3 = xr * xx, xq = xx * q;
   const double s = cosm ? __builtin_fma(t3, p, xr) : xr + __builtin_fma(t3, p, d);
   const double c = cosm ? xq : __builtin_fma(xr, d, xq);
@@ -350,7 +350,7 @@ NSG_HD float nsg_sqf_libm(const PowTab tb, float x) {
 // ulp (Acrobot, a balanced CartPole after ~270 steps: profiles/NOTEBOOK.md).  1: libm's own algorithms with libm's own roundings for
 // every sin / cos / scalar power of the integrators and of the θ-engine - what the reference's host evaluates, bit for bit, so that
 // the float64 STATE of every classic-control env equals the reference's for as long as one cares to step it.  The price is in
-// DESIGN.md section 4 (C1 +4 % per step ... Acrobot x 2.1).  (exp and log1p are libm's in every build: nsg_math.hip.h.)
+// DESIGN.md section 4 (C1 +4 % per step ... Acrobot x 1.9).  (exp and log1p: nsg_math.hip.h.)
 #ifndef NSG_LIBM_EXACT
 #define NSG_LIBM_EXACT 0
 #endif

@@ -62,7 +62,7 @@ class VecNSEnv:
         `** 2` resolve to in the reference), so float64 state, observation, reward and θ EQUAL the reference's, bit for bit, for as
         long as the batch is stepped - also where an unstable or chaotic plant (a balanced CartPole, Acrobot) would otherwise amplify
         the last ulp of the kernels' own < 1-ulp sincos into a different trajectory a few hundred steps later.  It runs on the
-        batch's specialised unit (implies `specialize=True`; raises if no unit can be had) and costs +4 % (CartPole) to x 2.1 (Acrobot)
+        batch's specialised unit (implies `specialize=True`; raises if no unit can be had) and costs +4 % (CartPole) to x 1.9 (Acrobot)
         per step.  Planning copies inherit it.
 
         `autoreset=True` (default): gymnasium's next-step vector autoreset - the step after an episode ended resets that env
